@@ -1,0 +1,50 @@
+# Top-level build.  Everything is built IN-TREE so the binaries travel to the GPU box
+# with the source snapshot (they are git-ignored, not gpurun-ignored).
+#
+#   make            shim + host library + CLI + oracle checkers
+#   make shim       raytracer.c_amd/csrc/librt_hip.so        (hipcc, gfx950 only)
+#   make host       raytracer.c_amd/host/libraytracer_amd.so + raytracer (gcc, C99)
+#   make oracle     oracle/libpt_oracle.so (+ oracle/_ref/*.so when /root/reference exists)
+
+ROOT    := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+PKG     := $(ROOT)raytracer.c_amd
+CSRC    := $(PKG)/csrc
+HOST    := $(PKG)/host
+INC     := $(ROOT)include
+
+HIPCC   ?= /opt/rocm/bin/hipcc
+# -ffp-contract=off: decision-exact parity with the reference (gcc --std=c99 emits no FMA);
+# hipcc's default would fuse a*b+c.  No fast-math: IEEE fp64 sqrt and division.
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function \
+            -I$(INC) -I$(CSRC)
+CC      := gcc
+CFLAGS  := -std=c99 -D_DEFAULT_SOURCE -O2 -ffp-contract=off -fPIC -Wall -Wno-unused-function -I$(INC) -I$(HOST)
+
+SHIM    := $(CSRC)/librt_hip.so
+HOSTLIB := $(HOST)/libraytracer_amd.so
+CLI     := $(HOST)/raytracer
+
+HOST_SRC := $(HOST)/raytracer_amd.c $(HOST)/scenes.c $(HOST)/obj_load.c $(HOST)/png_out.c
+HOST_HDR := $(INC)/raytracer.h $(INC)/vector.h $(INC)/rt_hip.h $(INC)/rt_rng.h $(HOST)/scenes.h
+
+all: shim host oracle
+
+shim: $(SHIM)
+$(SHIM): $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC)/rt_hip.h $(INC)/rt_rng.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl
+
+host: $(HOSTLIB) $(CLI)
+$(HOSTLIB): $(HOST_SRC) $(HOST_HDR) $(SHIM)
+	$(CC) $(CFLAGS) -shared -o $@ $(HOST_SRC) -L$(CSRC) -lrt_hip -Wl,-rpath,'$$ORIGIN/../csrc' -lz -lm
+$(CLI): $(HOST)/main.c $(HOSTLIB)
+	$(CC) $(CFLAGS) -o $@ $(HOST)/main.c -L$(HOST) -lraytracer_amd -Wl,-rpath,'$$ORIGIN' \
+	    -Wl,-rpath-link,$(CSRC) -lm
+
+oracle:
+	$(MAKE) -C $(ROOT)oracle all
+
+clean:
+	rm -f $(SHIM) $(HOSTLIB) $(CLI)
+	$(MAKE) -C $(ROOT)oracle clean
+
+.PHONY: all shim host oracle clean

@@ -1,0 +1,223 @@
+/* raytracer.h -- the drop-in boundary: the reference's public C API, served by
+ * an MI355X (gfx950) path tracer.
+ *
+ * A caller written against gue-ni/raytracer.c's raytracer.h (its main.c, its
+ * test.c) compiles and links against this header + libraytracer_amd.so
+ * unchanged: every struct below has the reference's field order, size and
+ * offsets (checked against the compiled reference in tests/test_layout.py:
+ * Object 88 B, Camera 96 B, Options 56 B, Ray 48 B, Hit 80 B, Vertex 40 B), and
+ * every function the reference's raytracer.o exports is exported here with
+ * the same signature (reference raytracer.h:135-164).
+ *
+ * What is different behind the boundary: render() hands the per-pixel
+ * trace_path()/intersect() loop (reference raytracer.c:176-223, 482-554,
+ * 393-464, 77-174) to hand-written HIP through the C-ABI in rt_hip.h.  There
+ * is no CPU fallback: without a GPU render() reports the HIP error on stderr
+ * and exits, as the reference's main.c:415-419 does for its own failures.
+ *
+ * Build-defined extensions (not in the reference) are grouped at the end and
+ * prefixed rt_ / named *_ex.
+ */
+#ifndef RAYTRACER_H
+#define RAYTRACER_H
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#include <float.h>
+#include <math.h>
+#include <time.h>
+#include <assert.h>
+
+#include "vector.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants and helper macros (reference raytracer.h:21-56) ------------- */
+
+#ifndef PI
+#define PI 3.14159265359 /* the reference's truncated pi; it feeds parity */
+#endif
+#define EPSILON 1e-8
+#ifndef MAX_DEPTH
+#define MAX_DEPTH 5 /* default bounce limit; at run time: rt_set_max_depth() */
+#endif
+#define MONTE_CARLO_SAMPLES 1
+
+#define MAX(a, b) ((a) > (b) ? (a) : (b))
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
+#define CLAMP(x) (MAX(0, MIN(x, 1)))
+/* Reproduced quirk (reference raytracer.h:30): the first argument is ignored. */
+#define CLAMP_BETWEEN(x, min_v, max_v) (MAX(min_v, MIN(max_v, 1)))
+#define ABS(x) ((x < 0) ? (-x) : (x))
+#define EQ(a, b) (ABS((a) - (b)) < EPSILON)
+
+#ifdef __cplusplus
+#define VECTOR(x, y, z) (vec3{(x), (y), (z)})
+#else
+#define VECTOR(x, y, z) ((vec3){(x), (y), (z)})
+#endif
+#define RGB(r, g, b) (VECTOR((r) / 255.0, (g) / 255.0, (b) / 255.0))
+#define RAY(o, d) ((Ray){.origin = o, .direction = d})
+
+#define RED RGB(255, 0, 0)
+#define GREEN RGB(0, 192, 48)
+#define BLUE RGB(0, 0, 255)
+#define WHITE RGB(255, 255, 255)
+#define BLACK RGB(0, 0, 0)
+#define BACKGROUND RGB(10, 10, 10)
+#define ZERO_VECTOR RGB(0, 0, 0)
+#define ONE_VECTOR (VECTOR(1.0, 1.0, 1.0))
+#define RANDOM_COLOR VECTOR(random_double(), random_double(), random_double())
+
+/* material flags (raytracer.h:53-56): exactly one of the first three, | M_CHECKERED */
+#define M_DEFAULT ((uint)1 << 1)    /* diffuse */
+#define M_REFLECTION ((uint)1 << 2) /* perfect mirror */
+#define M_REFRACTION ((uint)1 << 3) /* the reference's two-child "glass" */
+#define M_CHECKERED ((uint)1 << 4)
+
+/* ---- types (reference raytracer.h:60-131) ----------------------------------- */
+
+typedef uint32_t uint;
+
+typedef struct { vec3 pos; vec2 tex; } Vertex;
+typedef struct { vec3 origin, direction; } Ray;
+
+typedef struct
+{
+  uint flags;
+  vec3 color, emission;
+  double ka, ks, kd;
+} Material;
+
+typedef struct
+{
+  vec3 center;
+  double radius;
+} Sphere;
+
+/* Unindexed triangle soup: vertices[3*i .. 3*i+2] is triangle i. */
+typedef struct
+{
+  size_t num_triangles;
+  Vertex *vertices;
+} TriangleMesh;
+
+typedef union
+{
+  TriangleMesh *mesh;
+  Sphere *sphere;
+} Geometry;
+
+typedef enum
+{
+  GEOMETRY_SPHERE,
+  GEOMETRY_MESH,
+} GeometryType;
+
+/* The live scene element: a sphere with its material inline. */
+typedef struct
+{
+  uint flags;
+  double radius;
+  vec3 center;
+  vec3 color;
+  vec3 emission;
+} Object;
+
+typedef struct
+{
+  double t, u, v;
+  vec3 point;
+  vec3 normal;
+  uint object_id;
+} Hit;
+
+typedef struct
+{
+  vec3 position, horizontal, vertical, lower_left_corner;
+} Camera;
+
+typedef struct
+{
+  vec3 background;
+  char *result, *obj;
+  int width, height, samples;
+} Options;
+
+/* ---- the reference's exported functions ------------------------------------- */
+
+/* Uniform [0,1) and [min,max) from the host-side stream (rt_set_seed). */
+double random_double(void);
+double random_range(double min, double max);
+
+vec3 point_at(const Ray *ray, double t);
+vec3 calculate_surface_normal(vec3 v0, vec3 v1, vec3 v2);
+vec3 clamp(const vec3 v);
+
+/* Host-side single-primitive tests, bit-identical to the device code's. */
+bool intersect_sphere(const Ray *ray, vec3 center, double radius, Hit *hit);
+bool intersect_triangle(const Ray *ray, Vertex vertex0, Vertex vertex1, Vertex vertex2, Hit *hit);
+
+void print_v(const char *msg, const vec3 v);
+void print_m(const mat4 m);
+
+void init_camera(Camera *camera, vec3 position, vec3 target, Options *options);
+
+/* framebuffer: caller-owned width*height*3 bytes, RGB, row 0 = top.
+ * Blocks until the image is complete; updates ray_count and
+ * intersection_test_count from the device counters. */
+void render(uint8_t *framebuffer, Object *objects, size_t n_objects, Camera *camera, Options *options);
+
+/* Declared by the reference (raytracer.h:158) but never defined there; defined
+ * here: Wavefront OBJ -> unindexed triangle soup, polygons fan-triangulated,
+ * positions read as float then widened (what the reference's vendored
+ * tinyobj_loader_c yields), tex = (0,0) where the file has no vt.
+ * mesh->vertices is malloc'd; the caller frees it. */
+bool load_obj(const char *filename, TriangleMesh *mesh);
+
+extern long long ray_count;               /* trace_path()-equivalent calls */
+extern long long intersection_test_count; /* primitive tests */
+
+/* ---- build-defined extensions ----------------------------------------------- */
+
+/* A triangle mesh with a material: the scene element the reference's retired
+ * Object layout (raytracer.h:95-102) and commented-out mesh scan
+ * (raytracer.c:417-435) describe.  Meshes are scanned after the spheres, in
+ * array order, triangles in index order. */
+typedef struct
+{
+  uint flags;
+  vec3 color, emission;
+  TriangleMesh mesh;
+} MeshObject;
+
+/* render() plus meshes and an optional linear output: linear_rgb, if not
+ * NULL, receives width*height*3 floats, the per-pixel sample MEAN before the
+ * gamma-5 tonemap.  framebuffer may be NULL when only linear_rgb is wanted. */
+void render_ex(uint8_t *framebuffer, float *linear_rgb, Object *objects, size_t n_objects,
+               MeshObject *meshes, size_t n_meshes, Camera *camera, Options *options);
+
+/* Run-time settings the reference fixes at compile time or takes from libc
+ * state.  Defaults: depth MAX_DEPTH (5), seed 1666943821 (main.c:182), 1 GPU. */
+void rt_set_max_depth(int max_depth);
+void rt_set_seed(uint64_t seed);
+void rt_set_devices(int n_devices);
+int rt_get_max_depth(void);
+uint64_t rt_get_seed(void);
+
+/* Kernel-only wall time of the last render()/render_ex(), seconds, and the
+ * count of scene casts (rays that ran the intersection scan). */
+double rt_last_render_seconds(void);
+long long rt_last_ray_bounces(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RAYTRACER_H */

@@ -1,0 +1,166 @@
+/* rt_hip.h -- C-ABI of the MI355X (gfx950) path-tracing shim, librt_hip.so.
+ *
+ * This is the drop-in boundary for the reference's hot path: everything
+ * render() (gue-ni/raytracer.c raytracer.c:176-223) does per pixel --
+ * get_camera_ray :375-384, trace_path :482-554, intersect :393-464,
+ * intersect_sphere :77-118, intersect_triangle :120-174,
+ * calculate_surface_normal :42-45, the sampling RNG :227-253, reflect /
+ * checkered_texture / refract :349-391, sample accumulation and the gamma-5
+ * tonemap :212-220 -- runs on the device behind the entry points below.
+ * Plain C: pointers and sizes only, no C++ or torch types, no exceptions.
+ * The reference has no FFI layer of its own (its API is raytracer.h); the
+ * host library libraytracer_amd.so implements raytracer.h on top of this
+ * header, and INTEGRATION.md shows the binding a maintainer of the reference
+ * would add to call it directly.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative RT_HIP_E* code;
+ *     rt_hip_last_error() gives the message (thread-local).
+ *   - "d_" pointers are device memory on the scene's device; "h_" are host.
+ *   - a stream argument is a hipStream_t passed as void* (NULL = the null
+ *     stream); calls taking a stream are asynchronous on it.
+ *   - there is NO CPU fallback anywhere: without a usable GPU every entry
+ *     point that needs one fails with RT_HIP_ENODEV.
+ *
+ * Image decomposition: the image is cut into 8x8-pixel tiles, numbered
+ * row-major (tiles_x = ceil(width/8)).  One call renders the tiles
+ *     t = tile_first + k * tile_stride,  k = 0 .. tile_count-1
+ * into a COMPACT tile-major buffer: tile k occupies floats
+ * [k*192, (k+1)*192) as 64 pixels (row-major inside the tile) x RGB.  With
+ * tile_first = rank, tile_stride = world size this is the interleaved
+ * multi-GPU partition; rt_hip_untile() scatters a (gathered) compact buffer
+ * back to a row-major image.  Pixels of edge tiles that fall outside the
+ * image are written as zeros and skipped by rt_hip_untile().
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_HIP_TILE 8        /* tile edge, pixels */
+#define RT_HIP_TILE_PIXELS 64
+
+enum
+{
+  RT_HIP_OK = 0,
+  RT_HIP_ENODEV = -1,   /* no usable HIP device */
+  RT_HIP_EINVAL = -2,   /* bad argument */
+  RT_HIP_ENOMEM = -3,   /* host or device allocation failed */
+  RT_HIP_ERUNTIME = -4, /* a HIP / RCCL runtime call failed */
+  RT_HIP_ELIMIT = -5,   /* scene exceeds what the kernel supports */
+};
+
+/* Layout-identical to the reference's Object (raytracer.h:104-111): 88 bytes. */
+typedef struct
+{
+  uint32_t flags; /* M_DEFAULT 2 | M_REFLECTION 4 | M_REFRACTION 8, | M_CHECKERED 16 */
+  double radius;
+  double center[3];
+  double color[3];
+  double emission[3];
+} RtHipSphere;
+
+/* Layout-identical to the reference's Vertex (raytracer.h:61): 40 bytes. */
+typedef struct
+{
+  double pos[3];
+  double tex[2];
+} RtHipVertex;
+
+/* A triangle mesh with its material (the MeshObject extension of
+ * include/raytracer.h; reference raytracer.h:77-81 + :95-102).
+ * vertices: host pointer, 3*num_triangles entries, unindexed. */
+typedef struct
+{
+  uint32_t flags;
+  double color[3];
+  double emission[3];
+  size_t num_triangles;
+  const RtHipVertex *vertices;
+} RtHipMesh;
+
+/* Layout-identical to the reference's Camera (raytracer.h:121-124): 96 bytes. */
+typedef struct
+{
+  double position[3];
+  double horizontal[3];
+  double vertical[3];
+  double lower_left_corner[3];
+} RtHipCamera;
+
+typedef struct
+{
+  int32_t width, height; /* pixels */
+  int32_t samples;       /* per pixel (Options.samples) */
+  int32_t max_depth;     /* the reference's compile-time MAX_DEPTH (raytracer.h:25) */
+  uint64_t seed;         /* stream key, see rt_rng.h */
+  uint32_t tile_first, tile_stride, tile_count;
+  uint32_t reserved;
+} RtHipParams;
+
+/* counters accumulated (+=) by a render call */
+enum
+{
+  RT_HIP_STAT_RAYS = 0,  /* reference ray_count: trace_path calls (raytracer.c:484) */
+  RT_HIP_STAT_CASTS = 1, /* rays that ran the scene scan = "ray-bounces" */
+  RT_HIP_STAT_TESTS = 2, /* reference intersection_test_count (raytracer.c:79,122) */
+  RT_HIP_STAT_SAMPLES = 3,
+  RT_HIP_NSTATS = 4
+};
+
+typedef struct RtHipScene RtHipScene; /* opaque, device-resident */
+
+/* ---- device / errors ---------------------------------------------------------- */
+
+int rt_hip_device_count(void);
+const char *rt_hip_last_error(void);
+/* name and compute-unit count of a device (name_cap bytes incl. NUL) */
+int rt_hip_device_info(int device, char *name, size_t name_cap, int *compute_units);
+
+/* ---- scene: replaces the Object[] argument of render() ------------------------- */
+
+/* Uploads spheres and meshes to `device` in the kernel's layout.  Object ids
+ * follow the reference's scan order: spheres 0..n_spheres-1, then meshes. */
+int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
+                        size_t n_meshes, int device, RtHipScene **out_scene);
+void rt_hip_scene_destroy(RtHipScene *scene);
+int rt_hip_scene_device(const RtHipScene *scene);
+size_t rt_hip_scene_primitives(const RtHipScene *scene); /* spheres + triangles */
+
+/* ---- the hot path: replaces the loop nest of render() (raytracer.c:184-222) ---- */
+
+/* d_tiles_rgb : tile_count*192 floats  (linear per-pixel sample mean)
+ * d_tiles_rgb8: tile_count*192 bytes   (gamma-5 tonemap, raytracer.c:218-220); may be NULL
+ * d_stats     : RT_HIP_NSTATS uint64 accumulators; may be NULL */
+int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
+                        float *d_tiles_rgb, uint8_t *d_tiles_rgb8, uint64_t *d_stats, void *stream);
+
+/* Scatter a compact tile buffer into row-major images (either output may be
+ * NULL together with its input). */
+int rt_hip_untile(const float *d_tiles_rgb, const uint8_t *d_tiles_rgb8, int32_t width, int32_t height,
+                  uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count, float *d_image_rgb,
+                  uint8_t *d_image_rgb8, void *stream);
+
+/* ---- convenience for C hosts: whole image, host buffers, synchronous ----------- */
+
+/* Renders width x height on n_devices GPUs of this process (tiles interleaved
+ * over devices, tile buffers gathered onto device 0 with RCCL when
+ * n_devices > 1), then copies to the host.  h_image_rgb (w*h*3 floats) and
+ * h_image_rgb8 (w*h*3 bytes) may each be NULL.  h_stats: RT_HIP_NSTATS values,
+ * overwritten.  kernel_seconds: device time of the render kernels (max over
+ * devices), may be NULL.  params->tile_* are ignored. */
+int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
+                        size_t n_meshes, const RtHipCamera *camera, const RtHipParams *params,
+                        int n_devices, float *h_image_rgb, uint8_t *h_image_rgb8, uint64_t *h_stats,
+                        double *kernel_seconds);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_HIP_H */

@@ -1,0 +1,202 @@
+"""oracle/oracle_py.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes bindings of the two CPU checkers:
+  * PtOracle  -- oracle/libpt_oracle.so, our C restatement of the reference hot path;
+  * RefOracle -- oracle/_ref/libref_oracle_d<N>.so, the reference's own compiled code
+                 (one library per MAX_DEPTH, see oracle/Makefile).
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import this.
+Nothing here reads /root/reference at run time: the _ref libraries are prebuilt.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "raytracer.c_amd"))
+from rt_amd import abi  # noqa: E402  (struct layouts only)
+
+PT_PATH = os.path.join(HERE, "libpt_oracle.so")
+REF_DEPTHS = (4, 5, 8, 16)
+
+
+def ref_path(depth):
+    return os.path.join(HERE, "_ref", f"libref_oracle_d{depth}.so")
+
+
+def ref_available(depth=None):
+    depths = REF_DEPTHS if depth is None else (depth,)
+    return all(os.path.exists(ref_path(d)) for d in depths)
+
+
+def _dbl(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, ctype=C.c_double):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _pixels_arg(pixels, w, h):
+    if pixels is None:
+        return None, w * h, None
+    px = np.ascontiguousarray(pixels, dtype=np.uint32)
+    return _ptr(px, C.c_uint32), px.size, px
+
+
+class _Common:
+    """Primitive known-answer wrappers shared by both libraries (prefix differs)."""
+
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def init_camera(self, pos, target, w, h):
+        cam = abi.Camera()
+        self._fn("init_camera")(C.byref(cam), _ptr(_dbl(pos)), _ptr(_dbl(target)), C.c_int(w), C.c_int(h))
+        return cam
+
+    def camera_ray(self, cam, u, v):
+        out = np.zeros(6)
+        self._fn("camera_ray")(C.byref(cam), C.c_double(u), C.c_double(v), _ptr(out))
+        return out
+
+    def intersect_sphere(self, ray, center, radius):
+        t = C.c_double(0)
+        fn = self._fn("intersect_sphere")
+        fn.restype = C.c_int
+        ok = fn(_ptr(_dbl(ray)), _ptr(_dbl(center)), C.c_double(radius), C.byref(t))
+        return bool(ok), t.value
+
+    def intersect_triangle(self, ray, verts15):
+        out = np.zeros(3)
+        fn = self._fn("intersect_triangle")
+        fn.restype = C.c_int
+        ok = fn(_ptr(_dbl(ray)), _ptr(_dbl(verts15)), _ptr(out))
+        return bool(ok), out
+
+    def surface_normal(self, v9):
+        out = np.zeros(3)
+        self._fn("surface_normal")(_ptr(_dbl(v9)), _ptr(out))
+        return out
+
+    def reflect(self, i, n):
+        out = np.zeros(3)
+        self._fn("reflect")(_ptr(_dbl(i)), _ptr(_dbl(n)), _ptr(out))
+        return out
+
+    def refract(self, i, n, iot):
+        out = np.zeros(3)
+        self._fn("refract")(_ptr(_dbl(i)), _ptr(_dbl(n)), C.c_double(iot), _ptr(out))
+        return out
+
+    def checkered(self, color, u, v, m):
+        out = np.zeros(3)
+        self._fn("checkered")(_ptr(_dbl(color)), C.c_double(u), C.c_double(v), C.c_double(m), _ptr(out))
+        return out
+
+    def intersect_scene(self, ray, objs, n):
+        pn, tuv, oid = np.zeros(6), np.zeros(3), C.c_uint32(0)
+        fn = self._fn("intersect_scene")
+        fn.restype = C.c_int
+        ok = fn(_ptr(_dbl(ray)), objs, C.c_size_t(n), _ptr(pn), _ptr(tuv), C.byref(oid))
+        return bool(ok), pn, tuv, oid.value
+
+    def random_doubles(self, seed, pixel, sample, count):
+        out = np.zeros(count)
+        self._fn("random_doubles")(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_int(count), _ptr(out))
+        return out
+
+
+class PtOracle(_Common):
+    prefix = "pto_"
+
+    def __init__(self):
+        if not os.path.exists(PT_PATH):
+            raise RuntimeError(f"{PT_PATH} missing: run `make oracle`")
+        self.lib = C.CDLL(PT_PATH)
+
+    def render_pixels(self, scene, seed, pixels=None, spp=None, max_depth=None, want_rgb8=True):
+        """-> mean (npix,3) float64, rgb8 (npix,3) uint8, stats dict."""
+        ptr, npix, keep = _pixels_arg(pixels, scene.width, scene.height)
+        mean = np.zeros((npix, 3))
+        rgb8 = np.zeros((npix, 3), dtype=np.uint8)
+        stats = (C.c_longlong * 4)()
+        self.lib.pto_render_pixels(
+            scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
+            C.byref(scene.camera), C.c_int(scene.width), C.c_int(scene.height),
+            C.c_int(spp or scene.samples), C.c_int(scene.max_depth if max_depth is None else max_depth),
+            C.c_uint64(seed), ptr, C.c_size_t(npix), _ptr(mean), _ptr(rgb8, C.c_uint8) if want_rgb8 else None, stats)
+        return mean, rgb8, dict(rays=stats[0], tests=stats[1], casts=stats[2], draws=stats[3])
+
+    def trace_sample(self, scene, x, y, s, seed, max_depth=None):
+        rgb = np.zeros(3)
+        stats = (C.c_longlong * 4)()
+        self.lib.pto_trace_sample(
+            scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
+            C.byref(scene.camera), C.c_int(scene.width), C.c_int(scene.height),
+            C.c_int(scene.max_depth if max_depth is None else max_depth), C.c_uint32(x), C.c_uint32(y),
+            C.c_uint32(s), C.c_uint64(seed), _ptr(rgb), stats)
+        return rgb, dict(rays=stats[0], tests=stats[1], casts=stats[2], draws=stats[3])
+
+    def tonemap(self, mean):
+        mean = _dbl(mean)
+        out = np.zeros(mean.shape, dtype=np.uint8)
+        self.lib.pto_tonemap(_ptr(mean), C.c_size_t(mean.size // 3), _ptr(out, C.c_uint8))
+        return out
+
+
+class RefOracle(_Common):
+    """The reference's compiled trace_path()/intersect() at one MAX_DEPTH.  Spheres only
+    (the reference's live intersect() has no mesh branch, raytracer.c:401-412)."""
+    prefix = "ref_"
+
+    def __init__(self, depth):
+        path = ref_path(depth)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing (built by `make oracle` where /root/reference exists)")
+        self.lib = C.CDLL(path)
+        self.depth = depth
+        assert self.lib.ref_max_depth() == depth
+
+    def layout(self):
+        out = (C.c_uint64 * 16)()
+        self.lib.ref_layout(out)
+        return list(out)
+
+    def render_pixels(self, scene, seed, pixels=None, spp=None, want_rgb8=True):
+        assert scene.n_meshes == 0, "the compiled reference scans spheres only"
+        ptr, npix, keep = _pixels_arg(pixels, scene.width, scene.height)
+        mean = np.zeros((npix, 3))
+        rgb8 = np.zeros((npix, 3), dtype=np.uint8)
+        stats = (C.c_longlong * 2)()
+        self.lib.ref_render_pixels(
+            scene.objects, C.c_size_t(scene.n_objects), C.byref(scene.camera), C.c_int(scene.width),
+            C.c_int(scene.height), C.c_int(spp or scene.samples), C.c_uint64(seed), ptr, C.c_size_t(npix),
+            _ptr(mean), _ptr(rgb8, C.c_uint8) if want_rgb8 else None, stats)
+        return mean, rgb8, dict(rays=stats[0], tests=stats[1])
+
+    def trace_sample(self, scene, x, y, s, seed):
+        rgb = np.zeros(3)
+        stats = (C.c_longlong * 3)()
+        self.lib.ref_trace_sample(
+            scene.objects, C.c_size_t(scene.n_objects), C.byref(scene.camera), C.c_int(scene.width),
+            C.c_int(scene.height), C.c_uint32(x), C.c_uint32(y), C.c_uint32(s), C.c_uint64(seed), _ptr(rgb), stats)
+        return rgb, dict(rays=stats[0], tests=stats[1], draws=stats[2])
+
+    def render_as_shipped(self, scene, libc_seed, spp=None):
+        """The reference's render() itself, libc rand(): -> (h,w,3) uint8, stats."""
+        fb = np.zeros((scene.height, scene.width, 3), dtype=np.uint8)
+        stats = (C.c_longlong * 2)()
+        self.lib.ref_render_as_shipped(
+            _ptr(fb, C.c_uint8), scene.objects, C.c_size_t(scene.n_objects), C.byref(scene.camera),
+            C.c_int(scene.width), C.c_int(scene.height), C.c_int(spp or scene.samples), C.c_uint(libc_seed), stats)
+        return fb, dict(rays=stats[0], tests=stats[1])
+
+    def render_loop_libc(self, scene, libc_seed, spp=None):
+        fb = np.zeros((scene.height, scene.width, 3), dtype=np.uint8)
+        stats = (C.c_longlong * 2)()
+        self.lib.ref_render_loop_libc(
+            _ptr(fb, C.c_uint8), scene.objects, C.c_size_t(scene.n_objects), C.byref(scene.camera),
+            C.c_int(scene.width), C.c_int(scene.height), C.c_int(spp or scene.samples), C.c_uint(libc_seed), stats)
+        return fb, dict(rays=stats[0], tests=stats[1])

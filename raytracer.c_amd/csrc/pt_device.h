@@ -1,0 +1,80 @@
+/* pt_device.h -- device-side data layout shared by the kernels and the shim.
+ *
+ * HBM layout of a scene (RtHipScene), all fp64, built once by
+ * rt_hip_scene_create() and read-only afterwards:
+ *
+ *   sphere_geom [n_spheres] x 4 doubles : cx, cy, cz, radius*radius
+ *       what the scan of intersect() touches per test (32 B, one ds_read_b128
+ *       pair once staged in LDS).  radius*radius is the product the reference
+ *       forms per test (raytracer.c:87); forming it once is the same double.
+ *   material    [n_spheres + n_meshes] x 8 doubles :
+ *       prob, albedo_rr xyz, emission xyz, flags (as a double-sized slot)
+ *       prob      = MAX(color) (raytracer.c:497)
+ *       albedo_rr = color * (1/prob), the albedo after a survived Russian
+ *                   roulette (:500); same operands, same two operations as the
+ *                   reference performs per bounce, so the same doubles.
+ *   tri_geom    [n_triangles] x 9 doubles : v0, edge1 = v1-v0, edge2 = v2-v0
+ *       (raytracer.c:132-133 forms the edges per test; precomputed = same).
+ *   tri_normal  [n_triangles] x 3 doubles : calculate_surface_normal(v0,v1,v2)
+ *       (raytracer.c:42-45), read only for the winning triangle.
+ *   tri_tex     [n_triangles] x 6 doubles : st0, st1, st2 (read only for a
+ *       winning triangle of an M_CHECKERED mesh).
+ *   tri_object  [n_triangles] uint32     : material slot of the owning mesh.
+ */
+#ifndef PT_DEVICE_H
+#define PT_DEVICE_H
+
+#include <stdint.h>
+
+#define PT_TILE 8
+#define PT_TILE_PIXELS 64
+#define PT_SLICES 4         /* sample slices per pixel inside one wavefront */
+#define PT_BLOCK 256        /* 4 wavefronts: 64 pixels x 4 slices */
+#define PT_MAT_STRIDE 8     /* doubles per material record */
+#define PT_MAX_LDS_SPHERES 1024
+#define PT_MAX_LDS_TRIS 1024 /* triangles staged in LDS in one piece */
+
+#define PT_FLAG_DIFFUSE 2u
+#define PT_FLAG_MIRROR 4u
+#define PT_FLAG_REFRACT 8u
+#define PT_FLAG_CHECKER 16u
+
+struct PtSceneView
+{
+  const double *sphere_geom;
+  const double *material;
+  const double *tri_geom;
+  const double *tri_normal;
+  const double *tri_tex;
+  const uint32_t *tri_object;
+  uint32_t n_spheres, n_meshes, n_triangles, any_checker;
+};
+
+struct PtCamera
+{
+  double pos[3], horizontal[3], vertical[3], llc[3];
+};
+
+struct PtLaunch
+{
+  PtSceneView scene;
+  PtCamera cam;
+  int32_t width, height, samples, max_depth;
+  uint64_t seed;
+  uint32_t tile_first, tile_stride, tile_count, tiles_x;
+  float *tiles_rgb;
+  uint8_t *tiles_rgb8;
+  unsigned long long *stats;
+};
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+/* host-side launchers, defined next to the kernels in pt_kernel.hip */
+size_t pt_render_lds_bytes(const PtSceneView &scene);
+hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream);
+hipError_t pt_launch_untile(const float *tiles_rgb, const uint8_t *tiles_rgb8, int width, int height,
+                            uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count, float *image_rgb,
+                            uint8_t *image_rgb8, hipStream_t stream);
+#endif
+
+#endif /* PT_DEVICE_H */

@@ -1,0 +1,560 @@
+/* rt_hip_shim.hip -- the C-ABI of include/rt_hip.h over the kernels of
+ * pt_kernel.hip.  Thin by design: argument checks, the one-time conversion of
+ * the reference's scene structs (Object raytracer.h:104-111, Vertex :61) into
+ * the kernel's HBM layout (pt_device.h), launches, and the single-process
+ * multi-GPU gather.  No CPU rendering path exists here: every failure is
+ * reported, never papered over.
+ */
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pt_device.h"
+#include "rt_hip.h"
+
+static_assert(sizeof(RtHipSphere) == 88, "RtHipSphere must match the reference Object");
+static_assert(sizeof(RtHipVertex) == 40, "RtHipVertex must match the reference Vertex");
+static_assert(sizeof(RtHipCamera) == 96, "RtHipCamera must match the reference Camera");
+static_assert(RT_HIP_TILE == PT_TILE && RT_HIP_TILE_PIXELS == PT_TILE_PIXELS, "tile shape");
+
+struct RtHipScene
+{
+  int device = 0;
+  PtSceneView view{};
+  void *blob = nullptr; /* one device allocation holding every array */
+};
+
+namespace
+{
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do                                                                                                \
+  {                                                                                                 \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(e_ == hipErrorOutOfMemory ? RT_HIP_ENOMEM : RT_HIP_ERUNTIME, "%s: %s", #expr,     \
+                  hipGetErrorString(e_));                                                           \
+  } while (0)
+
+#define NCCL_TRY(expr)                                                                              \
+  do                                                                                                \
+  {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                       \
+    if (r_ != ncclSuccess)                                                                          \
+      return fail(RT_HIP_ERUNTIME, "%s: %s", #expr, ncclGetErrorString(r_));                        \
+  } while (0)
+
+int usable_devices()
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+/* host mirrors of the reference's vector.h operations (order matters) */
+struct H3
+{
+  double x, y, z;
+};
+H3 h_sub(H3 a, H3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+double h_dot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+H3 h_cross(H3 a, H3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+H3 h_scale(H3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+H3 h3(const double *p) { return {p[0], p[1], p[2]}; }
+
+void put_material(double *m, uint32_t flags, const double *color, const double *emission)
+{
+  /* raytracer.c:497: prob = MAX(albedo.x, MAX(albedo.y, albedo.z)) */
+  double yz = color[1] > color[2] ? color[1] : color[2];
+  double prob = color[0] > yz ? color[0] : yz;
+  double inv = 1 / prob; /* :500 vec3_scalar_mult(albedo, 1 / prob) */
+  m[0] = prob;
+  m[1] = color[0] * inv;
+  m[2] = color[1] * inv;
+  m[3] = color[2] * inv;
+  m[4] = emission[0];
+  m[5] = emission[1];
+  m[6] = emission[2];
+  uint64_t bits = flags;
+  memcpy(&m[7], &bits, sizeof bits);
+}
+
+uint32_t tiles_x_of(int width) { return ((uint32_t)width + PT_TILE - 1) / PT_TILE; }
+uint32_t tiles_y_of(int height) { return ((uint32_t)height + PT_TILE - 1) / PT_TILE; }
+
+int check_params(const RtHipParams *p)
+{
+  if (!p)
+    return fail(RT_HIP_EINVAL, "params is NULL");
+  if (p->width < 2 || p->height < 2)
+    return fail(RT_HIP_EINVAL, "width and height must be >= 2 (the reference divides by width-1, height-1)");
+  if (p->samples < 1)
+    return fail(RT_HIP_EINVAL, "samples must be >= 1");
+  if (p->max_depth < 0 || p->max_depth > 1000000)
+    return fail(RT_HIP_EINVAL, "max_depth out of range");
+  if ((uint64_t)p->width * (uint64_t)p->height > 0xFFFFFFFFull)
+    return fail(RT_HIP_EINVAL, "image has more than 2^32 pixels");
+  return RT_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_hip_last_error(void) { return g_err; }
+
+int rt_hip_device_count(void) { return usable_devices(); }
+
+int rt_hip_device_info(int device, char *name, size_t name_cap, int *compute_units)
+{
+  if (device < 0 || device >= usable_devices())
+    return fail(RT_HIP_ENODEV, "no HIP device %d", device);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (name && name_cap)
+    snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+  if (compute_units)
+    *compute_units = prop.multiProcessorCount;
+  return RT_HIP_OK;
+}
+
+int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
+                        size_t n_meshes, int device, RtHipScene **out_scene)
+{
+  if (!out_scene)
+    return fail(RT_HIP_EINVAL, "out_scene is NULL");
+  *out_scene = nullptr;
+  if ((n_spheres && !spheres) || (n_meshes && !meshes))
+    return fail(RT_HIP_EINVAL, "NULL scene array with non-zero count");
+  if (device < 0 || device >= usable_devices())
+    return fail(RT_HIP_ENODEV, "no HIP device %d (found %d)", device, usable_devices());
+
+  size_t n_tri = 0;
+  bool any_checker = false;
+  for (size_t i = 0; i < n_spheres; i++)
+  {
+    if (spheres[i].flags & PT_FLAG_REFRACT)
+      return fail(RT_HIP_ELIMIT, "sphere %zu is M_REFRACTION: the two-child refraction tree "
+                                 "(raytracer.c:514-529) is not implemented on the device yet", i);
+    any_checker |= (spheres[i].flags & PT_FLAG_CHECKER) != 0;
+  }
+  for (size_t m = 0; m < n_meshes; m++)
+  {
+    if (meshes[m].flags & PT_FLAG_REFRACT)
+      return fail(RT_HIP_ELIMIT, "mesh %zu is M_REFRACTION: not implemented on the device yet", m);
+    if (meshes[m].num_triangles && !meshes[m].vertices)
+      return fail(RT_HIP_EINVAL, "mesh %zu has triangles but no vertices", m);
+    any_checker |= (meshes[m].flags & PT_FLAG_CHECKER) != 0;
+    n_tri += meshes[m].num_triangles;
+  }
+  if (n_spheres + n_meshes > 0xFFFFFFu || n_tri > 0x7FFFFFFFu - n_spheres)
+    return fail(RT_HIP_ELIMIT, "scene too large");
+  const size_t n_mat = n_spheres + n_meshes;
+  if ((4 * n_spheres + PT_MAT_STRIDE * n_mat) * sizeof(double) > 150 * 1024)
+    return fail(RT_HIP_ELIMIT, "%zu spheres + %zu meshes do not fit the LDS staging area", n_spheres, n_meshes);
+
+  /* ---- build the kernel layout on the host (pt_device.h) ---- */
+  std::vector<double> geom(4 * n_spheres), mat(PT_MAT_STRIDE * n_mat), tgeom(9 * n_tri), tnorm(3 * n_tri),
+      ttex(6 * n_tri);
+  std::vector<uint32_t> tobj(n_tri);
+  for (size_t i = 0; i < n_spheres; i++)
+  {
+    geom[4 * i + 0] = spheres[i].center[0];
+    geom[4 * i + 1] = spheres[i].center[1];
+    geom[4 * i + 2] = spheres[i].center[2];
+    geom[4 * i + 3] = spheres[i].radius * spheres[i].radius; /* raytracer.c:87 */
+    put_material(&mat[PT_MAT_STRIDE * i], spheres[i].flags, spheres[i].color, spheres[i].emission);
+  }
+  size_t t = 0;
+  for (size_t m = 0; m < n_meshes; m++)
+  {
+    put_material(&mat[PT_MAT_STRIDE * (n_spheres + m)], meshes[m].flags, meshes[m].color, meshes[m].emission);
+    for (size_t k = 0; k < meshes[m].num_triangles; k++, t++)
+    {
+      const RtHipVertex *v = meshes[m].vertices + 3 * k;
+      H3 v0 = h3(v[0].pos), v1 = h3(v[1].pos), v2 = h3(v[2].pos);
+      H3 e1 = h_sub(v1, v0), e2 = h_sub(v2, v0); /* raytracer.c:132-133 */
+      /* calculate_surface_normal :42-45: normalize(cross(v2-v0, v1-v0)) */
+      H3 c = h_cross(e2, e1);
+      H3 n = h_scale(c, 1.0 / std::sqrt(h_dot(c, c)));
+      double *g = &tgeom[9 * t];
+      g[0] = v0.x; g[1] = v0.y; g[2] = v0.z;
+      g[3] = e1.x; g[4] = e1.y; g[5] = e1.z;
+      g[6] = e2.x; g[7] = e2.y; g[8] = e2.z;
+      tnorm[3 * t + 0] = n.x; tnorm[3 * t + 1] = n.y; tnorm[3 * t + 2] = n.z;
+      for (int j = 0; j < 3; j++)
+      {
+        ttex[6 * t + 2 * j + 0] = v[j].tex[0];
+        ttex[6 * t + 2 * j + 1] = v[j].tex[1];
+      }
+      tobj[t] = (uint32_t)(n_spheres + m);
+    }
+  }
+
+  /* ---- one device blob ---- */
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t off_geom = 0;
+  const size_t off_mat = off_geom + pad(geom.size() * 8);
+  const size_t off_tgeom = off_mat + pad(mat.size() * 8);
+  const size_t off_tnorm = off_tgeom + pad(tgeom.size() * 8);
+  const size_t off_ttex = off_tnorm + pad(tnorm.size() * 8);
+  const size_t off_tobj = off_ttex + pad(ttex.size() * 8);
+  const size_t total = off_tobj + pad(tobj.size() * 4) + 256;
+
+  int prev = 0;
+  HIP_TRY(hipGetDevice(&prev));
+  HIP_TRY(hipSetDevice(device));
+  RtHipScene *sc = new (std::nothrow) RtHipScene;
+  if (!sc)
+    return fail(RT_HIP_ENOMEM, "host allocation failed");
+  sc->device = device;
+  hipError_t e = hipMalloc(&sc->blob, total);
+  if (e != hipSuccess)
+  {
+    delete sc;
+    (void)hipSetDevice(prev);
+    return fail(RT_HIP_ENOMEM, "hipMalloc(%zu): %s", total, hipGetErrorString(e));
+  }
+  char *base = static_cast<char *>(sc->blob);
+  auto up = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  e = up(off_geom, geom.data(), geom.size() * 8);
+  if (e == hipSuccess) e = up(off_mat, mat.data(), mat.size() * 8);
+  if (e == hipSuccess) e = up(off_tgeom, tgeom.data(), tgeom.size() * 8);
+  if (e == hipSuccess) e = up(off_tnorm, tnorm.data(), tnorm.size() * 8);
+  if (e == hipSuccess) e = up(off_ttex, ttex.data(), ttex.size() * 8);
+  if (e == hipSuccess) e = up(off_tobj, tobj.data(), tobj.size() * 4);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess)
+  {
+    (void)hipFree(sc->blob);
+    delete sc;
+    return fail(RT_HIP_ERUNTIME, "scene upload: %s", hipGetErrorString(e));
+  }
+  sc->view.sphere_geom = reinterpret_cast<const double *>(base + off_geom);
+  sc->view.material = reinterpret_cast<const double *>(base + off_mat);
+  sc->view.tri_geom = reinterpret_cast<const double *>(base + off_tgeom);
+  sc->view.tri_normal = reinterpret_cast<const double *>(base + off_tnorm);
+  sc->view.tri_tex = reinterpret_cast<const double *>(base + off_ttex);
+  sc->view.tri_object = reinterpret_cast<const uint32_t *>(base + off_tobj);
+  sc->view.n_spheres = (uint32_t)n_spheres;
+  sc->view.n_meshes = (uint32_t)n_meshes;
+  sc->view.n_triangles = (uint32_t)n_tri;
+  sc->view.any_checker = any_checker ? 1u : 0u;
+  *out_scene = sc;
+  return RT_HIP_OK;
+}
+
+void rt_hip_scene_destroy(RtHipScene *scene)
+{
+  if (!scene)
+    return;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(scene->device);
+  (void)hipFree(scene->blob);
+  (void)hipSetDevice(prev);
+  delete scene;
+}
+
+int rt_hip_scene_device(const RtHipScene *scene) { return scene ? scene->device : -1; }
+
+size_t rt_hip_scene_primitives(const RtHipScene *scene)
+{
+  return scene ? (size_t)scene->view.n_spheres + scene->view.n_triangles : 0;
+}
+
+int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
+                        float *d_tiles_rgb, uint8_t *d_tiles_rgb8, uint64_t *d_stats, void *stream)
+{
+  if (!scene || !camera || !d_tiles_rgb)
+    return fail(RT_HIP_EINVAL, "scene, camera and d_tiles_rgb are required");
+  int rc = check_params(params);
+  if (rc)
+    return rc;
+  const uint32_t tx = tiles_x_of(params->width), ty = tiles_y_of(params->height);
+  const uint64_t n_tiles = (uint64_t)tx * ty;
+  if (params->tile_count == 0)
+    return RT_HIP_OK;
+  if (params->tile_stride == 0 && params->tile_count > 1)
+    return fail(RT_HIP_EINVAL, "tile_stride must be >= 1");
+  const uint64_t last = (uint64_t)params->tile_first + (uint64_t)(params->tile_count - 1) * params->tile_stride;
+  if (last >= n_tiles)
+    return fail(RT_HIP_EINVAL, "tile range [%u + k*%u, k < %u] exceeds the image's %llu tiles", params->tile_first,
+                params->tile_stride, params->tile_count, (unsigned long long)n_tiles);
+
+  PtLaunch L;
+  memset(&L, 0, sizeof L);
+  L.scene = scene->view;
+  memcpy(L.cam.pos, camera->position, sizeof L.cam.pos);
+  memcpy(L.cam.horizontal, camera->horizontal, sizeof L.cam.horizontal);
+  memcpy(L.cam.vertical, camera->vertical, sizeof L.cam.vertical);
+  memcpy(L.cam.llc, camera->lower_left_corner, sizeof L.cam.llc);
+  L.width = params->width;
+  L.height = params->height;
+  L.samples = params->samples;
+  L.max_depth = params->max_depth;
+  L.seed = params->seed;
+  L.tile_first = params->tile_first;
+  L.tile_stride = params->tile_stride;
+  L.tile_count = params->tile_count;
+  L.tiles_x = tx;
+  L.tiles_rgb = d_tiles_rgb;
+  L.tiles_rgb8 = d_tiles_rgb8;
+  L.stats = reinterpret_cast<unsigned long long *>(d_stats);
+
+  int prev = 0;
+  HIP_TRY(hipGetDevice(&prev));
+  if (prev != scene->device)
+    HIP_TRY(hipSetDevice(scene->device));
+  hipError_t e = pt_launch_render(L, static_cast<hipStream_t>(stream));
+  if (prev != scene->device)
+    (void)hipSetDevice(prev);
+  if (e != hipSuccess)
+    return fail(RT_HIP_ERUNTIME, "pt_render_tiles launch: %s", hipGetErrorString(e));
+  return RT_HIP_OK;
+}
+
+int rt_hip_untile(const float *d_tiles_rgb, const uint8_t *d_tiles_rgb8, int32_t width, int32_t height,
+                  uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count, float *d_image_rgb,
+                  uint8_t *d_image_rgb8, void *stream)
+{
+  if (width < 1 || height < 1)
+    return fail(RT_HIP_EINVAL, "bad image size");
+  if ((d_image_rgb && !d_tiles_rgb) || (d_image_rgb8 && !d_tiles_rgb8))
+    return fail(RT_HIP_EINVAL, "an output image needs its tile buffer");
+  if (tile_count == 0 || (!d_image_rgb && !d_image_rgb8))
+    return RT_HIP_OK;
+  const uint64_t n_tiles = (uint64_t)tiles_x_of(width) * tiles_y_of(height);
+  if ((uint64_t)tile_first + (uint64_t)(tile_count - 1) * tile_stride >= n_tiles)
+    return fail(RT_HIP_EINVAL, "tile range exceeds the image");
+  hipError_t e = pt_launch_untile(d_tiles_rgb, d_tiles_rgb8, width, height, tile_first, tile_stride, tile_count,
+                                  d_image_rgb, d_image_rgb8, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess)
+    return fail(RT_HIP_ERUNTIME, "pt_untile launch: %s", hipGetErrorString(e));
+  return RT_HIP_OK;
+}
+
+/* Whole image on n_devices GPUs of this process.  Device g renders tiles
+ * g, g+G, g+2G, ... into its own compact buffer; the buffers are gathered on
+ * device 0 with grouped ncclSend/ncclRecv (point-to-point over xGMI: a gather
+ * to one root uses the root's 7 direct links concurrently, there is no ring),
+ * scattered to the row-major image there, and copied to the host. */
+int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
+                        size_t n_meshes, const RtHipCamera *camera, const RtHipParams *params,
+                        int n_devices, float *h_image_rgb, uint8_t *h_image_rgb8, uint64_t *h_stats,
+                        double *kernel_seconds)
+{
+  int rc = check_params(params);
+  if (rc)
+    return rc;
+  if (!camera)
+    return fail(RT_HIP_EINVAL, "camera is NULL");
+  const int have = usable_devices();
+  if (have < 1)
+    return fail(RT_HIP_ENODEV, "no HIP device is available (this library has no CPU path)");
+  if (n_devices < 1 || n_devices > have)
+    return fail(RT_HIP_ENODEV, "asked for %d devices, %d available", n_devices, have);
+  const int G = n_devices;
+  const int W = params->width, H = params->height;
+  const uint32_t n_tiles = tiles_x_of(W) * tiles_y_of(H);
+  const size_t n_px = (size_t)W * H;
+
+  struct Dev
+  {
+    RtHipScene *scene = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    float *tiles = nullptr;
+    uint8_t *tiles8 = nullptr;
+    uint64_t *stats = nullptr;
+    uint32_t count = 0;
+  };
+  std::vector<Dev> dev(G);
+  std::vector<ncclComm_t> comms(G, nullptr);
+  float *all_tiles = nullptr, *image = nullptr;
+  uint8_t *all_tiles8 = nullptr, *image8 = nullptr;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+
+  auto cleanup = [&]() {
+    for (int g = 0; g < G; g++)
+    {
+      (void)hipSetDevice(g);
+      if (comms[g]) (void)ncclCommDestroy(comms[g]);
+      if (dev[g].t0) (void)hipEventDestroy(dev[g].t0);
+      if (dev[g].t1) (void)hipEventDestroy(dev[g].t1);
+      if (dev[g].stream) (void)hipStreamDestroy(dev[g].stream);
+      (void)hipFree(dev[g].tiles);
+      (void)hipFree(dev[g].tiles8);
+      (void)hipFree(dev[g].stats);
+      rt_hip_scene_destroy(dev[g].scene);
+    }
+    (void)hipSetDevice(0);
+    (void)hipFree(all_tiles);
+    (void)hipFree(all_tiles8);
+    (void)hipFree(image);
+    (void)hipFree(image8);
+    (void)hipSetDevice(prev);
+  };
+#define IMG_TRY(expr)                                                                               \
+  do                                                                                                \
+  {                                                                                                 \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+    {                                                                                               \
+      int c_ = fail(e_ == hipErrorOutOfMemory ? RT_HIP_ENOMEM : RT_HIP_ERUNTIME, "%s: %s", #expr,   \
+                    hipGetErrorString(e_));                                                         \
+      cleanup();                                                                                    \
+      return c_;                                                                                    \
+    }                                                                                               \
+  } while (0)
+
+  /* ---- launch every device's share ---- */
+  for (int g = 0; g < G; g++)
+  {
+    Dev &d = dev[g];
+    d.count = (n_tiles > (uint32_t)g) ? (n_tiles - g + G - 1) / G : 0;
+    rc = rt_hip_scene_create(spheres, n_spheres, meshes, n_meshes, g, &d.scene);
+    if (rc)
+    {
+      cleanup();
+      return rc;
+    }
+    IMG_TRY(hipSetDevice(g));
+    IMG_TRY(hipStreamCreate(&d.stream));
+    IMG_TRY(hipEventCreate(&d.t0));
+    IMG_TRY(hipEventCreate(&d.t1));
+    const size_t slots = d.count ? d.count : 1;
+    IMG_TRY(hipMalloc(&d.tiles, slots * 192 * sizeof(float)));
+    IMG_TRY(hipMalloc(&d.tiles8, slots * 192));
+    IMG_TRY(hipMalloc(&d.stats, RT_HIP_NSTATS * sizeof(uint64_t)));
+    IMG_TRY(hipMemsetAsync(d.stats, 0, RT_HIP_NSTATS * sizeof(uint64_t), d.stream));
+    RtHipParams p = *params;
+    p.tile_first = (uint32_t)g;
+    p.tile_stride = (uint32_t)G;
+    p.tile_count = d.count;
+    IMG_TRY(hipEventRecord(d.t0, d.stream));
+    rc = rt_hip_render_tiles(d.scene, camera, &p, d.tiles, d.tiles8, d.stats, d.stream);
+    if (rc)
+    {
+      cleanup();
+      return rc;
+    }
+    IMG_TRY(hipEventRecord(d.t1, d.stream));
+  }
+
+  /* ---- gather on device 0 ---- */
+  IMG_TRY(hipSetDevice(0));
+  IMG_TRY(hipMalloc(&image, n_px * 3 * sizeof(float)));
+  IMG_TRY(hipMalloc(&image8, n_px * 3));
+  std::vector<size_t> first_slot(G, 0);
+  for (int g = 1; g < G; g++)
+    first_slot[g] = first_slot[g - 1] + dev[g - 1].count;
+  if (G > 1)
+  {
+    IMG_TRY(hipMalloc(&all_tiles, (size_t)n_tiles * 192 * sizeof(float)));
+    IMG_TRY(hipMalloc(&all_tiles8, (size_t)n_tiles * 192));
+    std::vector<int> ids(G);
+    for (int g = 0; g < G; g++)
+      ids[g] = g;
+    ncclResult_t nr = ncclCommInitAll(comms.data(), G, ids.data());
+    if (nr != ncclSuccess)
+    {
+      int c = fail(RT_HIP_ERUNTIME, "ncclCommInitAll: %s", ncclGetErrorString(nr));
+      cleanup();
+      return c;
+    }
+    nr = ncclGroupStart();
+    for (int g = 1; g < G && nr == ncclSuccess; g++)
+    {
+      if (!dev[g].count)
+        continue;
+      const size_t nf = (size_t)dev[g].count * 192;
+      nr = ncclSend(dev[g].tiles, nf, ncclFloat, 0, comms[g], dev[g].stream);
+      if (nr == ncclSuccess) nr = ncclSend(dev[g].tiles8, nf, ncclUint8, 0, comms[g], dev[g].stream);
+      if (nr == ncclSuccess) nr = ncclRecv(all_tiles + first_slot[g] * 192, nf, ncclFloat, g, comms[0], dev[0].stream);
+      if (nr == ncclSuccess) nr = ncclRecv(all_tiles8 + first_slot[g] * 192, nf, ncclUint8, g, comms[0], dev[0].stream);
+    }
+    ncclResult_t ne = ncclGroupEnd();
+    if (nr == ncclSuccess)
+      nr = ne;
+    if (nr != ncclSuccess)
+    {
+      int c = fail(RT_HIP_ERUNTIME, "RCCL gather: %s", ncclGetErrorString(nr));
+      cleanup();
+      return c;
+    }
+  }
+  /* scatter each device's segment into the row-major image (device 0) */
+  for (int g = 0; g < G; g++)
+  {
+    if (!dev[g].count)
+      continue;
+    const float *src = (g == 0) ? dev[0].tiles : all_tiles + first_slot[g] * 192;
+    const uint8_t *src8 = (g == 0) ? dev[0].tiles8 : all_tiles8 + first_slot[g] * 192;
+    rc = rt_hip_untile(src, src8, W, H, (uint32_t)g, (uint32_t)G, dev[g].count, image, image8, dev[0].stream);
+    if (rc)
+    {
+      cleanup();
+      return rc;
+    }
+  }
+  for (int g = 0; g < G; g++)
+  {
+    IMG_TRY(hipSetDevice(g));
+    IMG_TRY(hipStreamSynchronize(dev[g].stream));
+  }
+
+  /* ---- results ---- */
+  IMG_TRY(hipSetDevice(0));
+  if (h_image_rgb)
+    IMG_TRY(hipMemcpy(h_image_rgb, image, n_px * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (h_image_rgb8)
+    IMG_TRY(hipMemcpy(h_image_rgb8, image8, n_px * 3, hipMemcpyDeviceToHost));
+  double worst = 0;
+  uint64_t sums[RT_HIP_NSTATS] = {0, 0, 0, 0};
+  for (int g = 0; g < G; g++)
+  {
+    IMG_TRY(hipSetDevice(g));
+    float ms = 0;
+    IMG_TRY(hipEventElapsedTime(&ms, dev[g].t0, dev[g].t1));
+    if (ms * 1e-3 > worst)
+      worst = ms * 1e-3;
+    uint64_t st[RT_HIP_NSTATS];
+    IMG_TRY(hipMemcpy(st, dev[g].stats, sizeof st, hipMemcpyDeviceToHost));
+    for (int k = 0; k < RT_HIP_NSTATS; k++)
+      sums[k] += st[k];
+  }
+  if (h_stats)
+    memcpy(h_stats, sums, sizeof sums);
+  if (kernel_seconds)
+    *kernel_seconds = worst;
+  cleanup();
+#undef IMG_TRY
+  return RT_HIP_OK;
+}
+
+} /* extern "C" */
