@@ -1,0 +1,146 @@
+"""GPU parity: the HIP path, called through the C-ABI (rt_hip.h), against the CPU oracle
+(oracle/pt_oracle.c, itself pinned bit-for-bit to the compiled reference in
+test_oracle_ref.py / test_golden.py).  Tolerance: BASELINE.json north_star, <= 1e-4
+per-channel RMS on the linear float framebuffer; in addition the ray / test counters must
+be EQUAL (every branch decision identical) and tonemapped bytes within 1 LSB.
+"""
+import numpy as np
+import pytest
+
+from conftest import SEED
+from util import assert_parity, tile_pixels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from rt_amd import abi, gpu as G
+    assert abi.load_shim().rt_hip_device_count() >= 1, "no HIP device: the GPU tests must run on the GPU box"
+    assert torch.cuda.is_available()
+    return G
+
+
+def _full(gpu, pt, sc, seed=SEED):
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(seed)
+    mean, rgb8, ost = pt.render_pixels(sc, seed)
+    assert st["samples"] == sc.width * sc.height * sc.samples
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"config {sc.config}")
+    gs.close()
+    return st
+
+
+def test_config1_full(gpu, pt):
+    """BASELINE configs[0]: 256x256, 4 spp, depth 4 -- whole image vs oracle."""
+    from rt_amd import scene as S
+    _full(gpu, pt, S.build_scene(1))
+
+
+def test_config2_reduced(gpu, pt):
+    from rt_amd import scene as S
+    _full(gpu, pt, S.build_scene(2, 200, 152, 16))
+
+
+def test_config4_reduced(gpu, pt):
+    """the reference's own 38-sphere room (r = 1e4 wall spheres: fp32 would fail here)"""
+    from rt_amd import scene as S
+    _full(gpu, pt, S.build_scene(4, 160, 96, 16))
+
+
+def test_config3_mesh_reduced(gpu, pt):
+    from rt_amd import scene as S
+    sc = S.build_scene(3, 240, 136, 8)
+    _full(gpu, pt, sc)
+    sc.free()
+
+
+def test_ragged_size_and_odd_samples(gpu, pt):
+    """width/height not multiples of the 8-pixel tile; spp not a multiple of the 4 slices"""
+    from rt_amd import scene as S
+    for (w, h, spp) in [(37, 21, 5), (9, 10, 1), (64, 8, 3)]:
+        _full(gpu, pt, S.build_scene(1, w, h, spp))
+
+
+def test_depth_zero_and_empty_scene(gpu, pt):
+    from rt_amd import scene as S
+    sc = S.build_scene(1, 32, 32, 4, max_depth=0)
+    _full(gpu, pt, sc)
+    empty = S.custom_scene([], 24, 16, 2, 4, (0, 0, 10), (0, 0, 0))
+    st = _full(gpu, pt, empty)
+    assert st["rays"] == 24 * 16 * 2 and st["tests"] == 0
+
+
+def test_tile_partition_is_bit_invariant(gpu, pt):
+    """rendering interleaved tile subsets (the multi-GPU partition) == one full render, bitwise"""
+    import torch
+    from rt_amd import scene as S
+    sc = S.build_scene(2, 120, 72, 8)
+    gs = gpu.GpuScene(sc)
+    full, full8, st = gs.render_image(SEED)
+    world = 3
+    image = torch.zeros_like(full)
+    image8 = torch.zeros_like(full8)
+    tot = torch.zeros(4, dtype=torch.int64, device=full.device)
+    for r in range(world):
+        first, stride, count = gpu.rank_tiles(sc.width, sc.height, r, world)
+        t, t8, s = gs.render_tiles(SEED, first, stride, count)
+        gs.untile(t, t8, first, stride, count, image, image8)
+        tot += s
+    torch.cuda.synchronize()
+    assert torch.equal(image, full) and torch.equal(image8, full8)
+    assert tot.cpu().tolist()[0] == st["rays"]
+    gs.close()
+
+
+def test_run_to_run_determinism(gpu):
+    import torch
+    from rt_amd import scene as S
+    sc = S.build_scene(4, 96, 56, 8)
+    gs = gpu.GpuScene(sc)
+    a, a8, sa = gs.render_image(SEED)
+    b, b8, sb = gs.render_image(SEED)
+    assert torch.equal(a, b) and torch.equal(a8, b8) and sa == sb
+    c, _, _ = gs.render_image(SEED + 1)
+    assert not torch.equal(a, c)
+    gs.close()
+
+
+def test_full_size_config4_tiles_vs_oracle(gpu, pt):
+    """BASELINE configs[3] geometry at FULL 1920x1080 (reduced spp so the oracle finishes):
+    whole-frame counters are self-consistent and 24 scattered tiles match the oracle."""
+    from rt_amd import scene as S
+    sc = S.build_scene(4, samples=8)
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(SEED)
+    assert st["samples"] == 1920 * 1080 * 8
+    assert st["tests"] == st["casts"] * 38
+    assert st["samples"] <= st["casts"] <= st["rays"] <= st["samples"] * (sc.max_depth + 2)
+    rng = np.random.default_rng(7)
+    tiles = rng.choice(gpu.n_tiles(1920, 1080), size=24, replace=False)
+    px = tile_pixels(1920, 1080, tiles)
+    mean, rgb8, _ = pt.render_pixels(sc, SEED, pixels=px)
+    g = img.cpu().numpy().reshape(-1, 3)[px]
+    g8 = img8.cpu().numpy().reshape(-1, 3)[px]
+    assert_parity(g, g8, None, mean, rgb8, None, what="config 4 full-size tiles")
+    gs.close()
+
+
+def test_host_api_render_matches_tiles(gpu, pt):
+    """render() of the raytracer.h boundary (C host -> rt_hip_render_image) == tile API"""
+    import ctypes as C
+    from rt_amd import abi, scene as S
+    sc = S.build_scene(1, 64, 40, 4)
+    host = abi.load_host()
+    fb = np.zeros((sc.height, sc.width, 3), dtype=np.uint8)
+    opt = abi.Options()
+    opt.width, opt.height, opt.samples = sc.width, sc.height, sc.samples
+    host.rt_set_max_depth(sc.max_depth)
+    host.rt_set_seed(SEED)
+    rc0 = C.c_longlong.in_dll(host, "ray_count").value
+    host.render(fb.ctypes.data, sc.objects, sc.n_objects, C.byref(sc.camera), C.byref(opt))
+    rays = C.c_longlong.in_dll(host, "ray_count").value - rc0
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert rays == ost["rays"]
+    assert np.abs(fb.reshape(-1, 3).astype(np.int16) - rgb8.astype(np.int16)).max() <= 1

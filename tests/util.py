@@ -1,0 +1,43 @@
+"""Shared helpers of the parity tests."""
+import numpy as np
+
+RMS_TOL = 1e-4  # BASELINE.json north_star: per-channel RMS of the linear float framebuffer
+
+
+def channel_rms(a, b):
+    d = np.asarray(a, dtype=np.float64).reshape(-1, 3) - np.asarray(b, dtype=np.float64).reshape(-1, 3)
+    return np.sqrt((d * d).mean(axis=0))
+
+
+def tile_pixels(width, height, tiles):
+    """linear pixel indices (row-major inside each 8x8 tile) of the given tile ids, inside-image only"""
+    tx = (width + 7) // 8
+    out = []
+    for t in tiles:
+        x0, y0 = (t % tx) * 8, (t // tx) * 8
+        for r in range(8):
+            for c in range(8):
+                if x0 + c < width and y0 + r < height:
+                    out.append((y0 + r) * width + x0 + c)
+    return np.array(out, dtype=np.uint32)
+
+
+def assert_parity(gpu_img, gpu_img8, gpu_stats, mean, rgb8, stats, what=""):
+    """gpu_img: (...,3) float32 linear; mean: same pixels, float64 oracle"""
+    g = np.asarray(gpu_img, dtype=np.float64).reshape(-1, 3)
+    m = np.asarray(mean).reshape(-1, 3)
+    assert g.shape == m.shape
+    rms = channel_rms(g, m)
+    assert (rms <= RMS_TOL).all(), f"{what}: per-channel RMS {rms} > {RMS_TOL}"
+    # the float32 store is the only rounding that should be visible
+    rel = np.abs(g - m) / np.maximum(np.abs(m), 1e-30)
+    assert rel.max() < 1e-6, f"{what}: max relative error {rel.max()}"
+    if gpu_img8 is not None:
+        d8 = np.abs(np.asarray(gpu_img8, dtype=np.int16).reshape(-1, 3) - np.asarray(rgb8, dtype=np.int16).reshape(-1, 3))
+        assert d8.max() <= 1, f"{what}: tonemapped bytes differ by {d8.max()} LSB"
+    if gpu_stats is not None:
+        # decision-exactness: every branch taken identically => identical counters
+        assert gpu_stats["rays"] == stats["rays"], f"{what}: rays {gpu_stats['rays']} != {stats['rays']}"
+        assert gpu_stats["tests"] == stats["tests"], f"{what}: tests {gpu_stats['tests']} != {stats['tests']}"
+        if "casts" in stats:
+            assert gpu_stats["casts"] == stats["casts"]
