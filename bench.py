@@ -109,7 +109,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from rt_amd import abi, gpu as G, scene as S
+    from rt_amd import abi, dist as D, gpu as G, scene as S
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -127,12 +127,8 @@ def main():
     sc = S.build_scene(args.config, args.width or None, args.height or None, args.spp or None)
     W, H, spp, depth = sc.width, sc.height, sc.samples, sc.max_depth
     gs = G.GpuScene(sc, device=local_rank)            # scene resident in HBM from here on
-    first, stride, count = G.rank_tiles(W, H, rank, world)
-    total_tiles = G.n_tiles(W, H)
-    max_count = (total_tiles + world - 1) // world     # ranks differ by at most one tile: pad to this
-
-    tiles = torch.zeros((max_count, abi.TILE_PIXELS, 3), dtype=torch.float32, device=dev)
-    tiles8 = torch.zeros((max_count, abi.TILE_PIXELS, 3), dtype=torch.uint8, device=dev)
+    first, stride, count = D.rank_tiles(W, H, rank, world)
+    tiles, tiles8 = D.alloc_tile_buffers(W, H, world, dev)   # padded: ranks differ by at most one tile
     stats = torch.zeros(abi.NSTATS, dtype=torch.int64, device=dev)
     image = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
     image8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -150,15 +146,11 @@ def main():
         e1.record()
         if timed:
             kernel_events.append((e0, e1))
-        if world > 1:
-            dist.gather(tiles, gathered, dst=0)        # RCCL over xGMI: the one exchange of the path
-            dist.gather(tiles8, gathered8, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    f, s_, c = G.rank_tiles(W, H, r, world)
-                    gs.untile(gathered[r], gathered8[r], f, s_, c, image, image8)
-        else:
-            gs.untile(tiles, tiles8, first, stride, count, image, image8)
+        # RCCL over xGMI when world > 1: the one exchange of the path
+        parts, parts8 = D.gather_tiles(tiles, tiles8, rank, world, gathered, gathered8)
+        if rank == 0:
+            for r, f, s_, c in D.segments(W, H, world):
+                gs.untile(parts[r], parts8[r], f, s_, c, image, image8)
 
     def fence():
         torch.cuda.synchronize(dev)

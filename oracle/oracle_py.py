@@ -184,8 +184,10 @@ class RefOracle(_Common):
             C.c_int(scene.height), C.c_uint32(x), C.c_uint32(y), C.c_uint32(s), C.c_uint64(seed), _ptr(rgb), stats)
         return rgb, dict(rays=stats[0], tests=stats[1], draws=stats[2])
 
-    def render_as_shipped(self, scene, libc_seed, spp=None):
-        """The reference's render() itself, libc rand(): -> (h,w,3) uint8, stats."""
+    def render_as_shipped(self, scene, libc_seed, spp=None, threads=1):
+        """The reference's render() itself, libc rand(): -> (h,w,3) uint8, stats.
+        threads=1 is its deterministic (and fastest) mode."""
+        self.lib.ref_set_threads(C.c_int(threads))
         fb = np.zeros((scene.height, scene.width, 3), dtype=np.uint8)
         stats = (C.c_longlong * 2)()
         self.lib.ref_render_as_shipped(

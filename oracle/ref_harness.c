@@ -74,6 +74,9 @@ extern inline void mat4_mult(mat4 A, mat4 B, mat4 C);
 
 int ref_max_depth(void) { return MAX_DEPTH; }
 
+/* OpenMP team size of the as-shipped render() (raytracer.c:184); 1 = deterministic */
+void ref_set_threads(int n) { omp_set_num_threads(n); }
+
 /* sizeof / offsetof of the boundary structs, for the layout tests */
 void ref_layout(uint64_t out[16])
 {

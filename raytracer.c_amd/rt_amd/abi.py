@@ -145,6 +145,12 @@ def load_shim():
     """librt_hip.so.  Raises if it is not built: there is no fallback path."""
     global _shim
     if _shim is None:
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / librccl.so.1 / libhsa-runtime64.so.1.
+        # The dynamic loader de-duplicates by SONAME only for libraries loaded EARLIER, so
+        # torch must come first: the shim then binds to the very runtime instance torch uses
+        # (one HIP runtime per process => torch streams and device pointers are valid in the
+        # shim).  Loading the shim first would pull in /opt/rocm's copies next to torch's.
+        import torch  # noqa: F401
         if not os.path.exists(SHIM_PATH):
             raise RuntimeError(f"{SHIM_PATH} is missing: build it with `make shim` "
                                "(or __graft_entry__.build()); this package has no CPU fallback")

@@ -8,6 +8,7 @@ import ctypes as C
 import torch
 
 from . import abi
+from .dist import n_tiles, rank_tiles  # noqa: F401  (re-exported)
 
 
 class ShimError(RuntimeError):
@@ -18,17 +19,6 @@ def _check(rc, what):
     if rc != 0:
         msg = abi.load_shim().rt_hip_last_error()
         raise ShimError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
-
-
-def n_tiles(width, height):
-    return ((width + abi.TILE - 1) // abi.TILE) * ((height + abi.TILE - 1) // abi.TILE)
-
-
-def rank_tiles(width, height, rank, world):
-    """The interleaved partition: rank r renders tiles r, r+world, ...  -> (first, stride, count)."""
-    total = n_tiles(width, height)
-    count = (total - rank + world - 1) // world if total > rank else 0
-    return rank, world, count
 
 
 class GpuScene:

@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("OMP_NUM_THREADS", "1")  # the reference's render() is only deterministic single-threaded
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "raytracer.c_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:

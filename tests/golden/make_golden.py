@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory from the COMPILED REFERENCE
+(oracle/_ref/libref_oracle_d<N>.so = gue-ni/raytracer.c's own trace_path()/intersect(),
+built in place from /root/reference by oracle/Makefile; RNG = include/rt_rng.h on both
+sides).  Run in the build container, where /root/reference exists:
+
+    make oracle && python tests/golden/make_golden.py
+
+The fixtures are DATA (inputs + expected outputs as float64 / integer arrays in .npz,
+loadable with allow_pickle=False); no reference source text is stored.  cube.obj is the
+reference's 753-byte asset assets/cube.obj, an input data file.
+
+Files
+  primitives.npz   ray/sphere and ray/triangle known answers (incl. grazing, inside,
+                   t ~ EPSILON, radius-1e4 wall spheres), surface normals, reflect /
+                   refract / checker values, camera frames for 4 aspect ratios, camera
+                   rays, the reference's own test.c vectors, RNG stream heads
+  frames.npz       linear fp64 means + tonemapped bytes + ray/test counts:
+                   config 1 whole frame at 64x64; tiles of configs 1, 2, 4 at full size
+  samples.npz      per-(pixel, sample) traces: radiance, rays, tests, draws
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "raytracer.c_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+import oracle_py  # noqa: E402
+from rt_amd import scene as S  # noqa: E402
+from util import tile_pixels  # noqa: E402
+
+SEED = 1666943821
+
+
+def primitives(ref):
+    rng = np.random.default_rng(20221028)
+    out = {}
+
+    # ---- ray / sphere ----
+    rays, centers, radii = [], [], []
+    for _ in range(600):  # generic
+        o = rng.uniform(-30, 30, 3)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        rays.append(np.concatenate([o, d]))
+        centers.append(rng.uniform(-30, 30, 3))
+        radii.append(rng.uniform(0.5, 12))
+    for _ in range(150):  # aimed near the silhouette (grazing)
+        c = rng.uniform(-20, 20, 3)
+        r = rng.uniform(1, 8)
+        o = c + rng.normal(size=3) * 40
+        to_c = c - o
+        dist = np.linalg.norm(to_c)
+        perp = np.cross(to_c, rng.normal(size=3))
+        perp /= np.linalg.norm(perp)
+        aim = c + perp * r * (1 + rng.uniform(-1e-9, 1e-9))
+        d = (aim - o) / np.linalg.norm(aim - o)
+        rays.append(np.concatenate([o, d]))
+        centers.append(c)
+        radii.append(r)
+    for _ in range(100):  # origin inside the sphere
+        c = rng.uniform(-5, 5, 3)
+        r = rng.uniform(3, 9)
+        o = c + rng.uniform(-1, 1, 3)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        rays.append(np.concatenate([o, d]))
+        centers.append(c)
+        radii.append(r)
+    for _ in range(100):  # origin ON the surface (the bounce case), both directions
+        c = rng.uniform(-5, 5, 3)
+        r = rng.uniform(1, 9)
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        o = c + n * r
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        rays.append(np.concatenate([o, d]))
+        centers.append(c)
+        radii.append(r)
+    for _ in range(100):  # radius-1e4 "wall" spheres (reference main.c:258-299)
+        axis = rng.integers(0, 3)
+        sign = rng.choice([-1.0, 1.0])
+        c = np.zeros(3)
+        c[axis] = sign * (10000 + rng.uniform(15, 40))
+        o = rng.uniform(-14, 14, 3)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        rays.append(np.concatenate([o, d]))
+        centers.append(c)
+        radii.append(10000.0)
+    for _ in range(50):  # t within a few EPSILON of the origin
+        c = rng.uniform(-5, 5, 3)
+        r = rng.uniform(1, 5)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        o = c - d * (r + rng.uniform(-3e-8, 3e-8))
+        rays.append(np.concatenate([o, d]))
+        centers.append(c)
+        radii.append(r)
+    rays, centers, radii = np.array(rays), np.array(centers), np.array(radii)
+    hit = np.zeros(len(rays), dtype=np.uint8)
+    t = np.zeros(len(rays))
+    for k in range(len(rays)):
+        ok, tv = ref.intersect_sphere(rays[k], centers[k], radii[k])
+        hit[k], t[k] = ok, tv
+    out.update(sph_ray=rays, sph_center=centers, sph_radius=radii, sph_hit=hit, sph_t=t)
+
+    # ---- ray / triangle ----
+    trays, tverts = [], []
+    for k in range(700):
+        v = rng.uniform(-10, 10, (3, 3))
+        tex = rng.uniform(0, 1, (3, 2))
+        if k % 7 == 0:  # aimed at an edge / vertex
+            w = rng.dirichlet([0.3, 0.3, 0.3])
+            if k % 14 == 0:
+                w = np.array([1.0, 0.0, 0.0])
+            target = (w[:, None] * v).sum(axis=0)
+        else:
+            w = rng.dirichlet([1, 1, 1]) * rng.uniform(0.5, 1.6)
+            target = (w[:, None] * v).sum(axis=0)
+        o = rng.uniform(-25, 25, 3)
+        d = target - o
+        d /= np.linalg.norm(d)
+        if k % 11 == 0:  # parallel to the plane
+            n = np.cross(v[1] - v[0], v[2] - v[0])
+            d = np.cross(n, rng.normal(size=3))
+            d /= np.linalg.norm(d)
+        trays.append(np.concatenate([o, d]))
+        tverts.append(np.concatenate([np.concatenate([v[j], tex[j]]) for j in range(3)]))
+    trays, tverts = np.array(trays), np.array(tverts)
+    thit = np.zeros(len(trays), dtype=np.uint8)
+    ttuv = np.zeros((len(trays), 3))
+    tnorm = np.zeros((len(trays), 3))
+    for k in range(len(trays)):
+        ok, tuv = ref.intersect_triangle(trays[k], tverts[k])
+        thit[k], ttuv[k] = ok, tuv
+        v = tverts[k].reshape(3, 5)[:, :3].reshape(-1)
+        tnorm[k] = ref.surface_normal(v)
+    out.update(tri_ray=trays, tri_verts=tverts, tri_hit=thit, tri_tuv=ttuv, tri_normal=tnorm)
+
+    # ---- the reference's own unit test vectors (test.c:60-63, 74-78) ----
+    out["testc_cross"] = np.zeros(3)
+    ref.lib.ref_cross(oracle_py._ptr(np.array([2.0, 3, 4])), oracle_py._ptr(np.array([5.0, 6, 7])),
+                      oracle_py._ptr(out["testc_cross"]))
+    out["testc_normal"] = ref.surface_normal([-1, 1, 1, 1, 1, 1, 1, 1, -1])  # what the function returns
+
+    # ---- reflect / refract / checker ----
+    vecs = rng.normal(size=(64, 2, 3))
+    vecs /= np.linalg.norm(vecs, axis=2, keepdims=True)
+    out["brdf_in"] = vecs
+    out["reflect"] = np.array([ref.reflect(a, b) for a, b in vecs])
+    out["refract"] = np.array([ref.refract(a, b, 1.0) for a, b in vecs])
+    uv = rng.uniform(0, 1, (64, 2))
+    col = rng.uniform(0, 1, (64, 3))
+    out["checker_uvc"] = np.concatenate([uv, col], axis=1)
+    out["checker"] = np.array([ref.checkered(col[k], uv[k, 0], uv[k, 1], 100000.0) for k in range(64)])
+
+    # ---- camera ----
+    sizes = np.array([[256, 256], [800, 600], [1920, 1080], [3840, 2160]])
+    poses = np.array([[0, 5, 40, 0, 0, 0], [0, 8, 45, 0, 0, 0], [16, 9, 42, 0, 0, 0], [0, 0, 50, 0, 0, 0]], dtype=float)
+    cams = np.zeros((4, 12))
+    crays = np.zeros((4, 16, 8))
+    for k in range(4):
+        cam = ref.init_camera(poses[k, :3], poses[k, 3:], int(sizes[k, 0]), int(sizes[k, 1]))
+        cams[k] = np.frombuffer(bytes(cam), dtype=np.float64)
+        for j in range(16):
+            u, v = rng.uniform(0, 1.001, 2)
+            crays[k, j, :2] = (u, v)
+            crays[k, j, 2:] = ref.camera_ray(cam, u, v)
+    out.update(cam_size=sizes, cam_pose=poses, cam_frame=cams, cam_rays=crays)
+
+    # ---- RNG stream heads ----
+    keys = np.array([[SEED, 0, 0], [SEED, 1, 0], [SEED, 0, 1], [SEED, 2073599, 1023], [1, 8294399, 4095],
+                     [0, 0, 0], [2**63 + 12345, 77, 3]], dtype=np.uint64)
+    out["rng_keys"] = keys
+    out["rng_draws"] = np.array([ref.random_doubles(int(a), int(b), int(c), 16) for a, b, c in keys])
+    return out
+
+
+def frames():
+    out = {}
+    # config 1, whole frame at 64x64 (4 spp, depth 4)
+    sc = S.build_scene(1, 64, 64, 4)
+    ref = oracle_py.RefOracle(sc.max_depth)
+    mean, rgb8, st = ref.render_pixels(sc, SEED)
+    out.update(c1_64_mean=mean, c1_64_rgb8=rgb8, c1_64_stats=np.array([st["rays"], st["tests"]]))
+    # tiles at full size
+    rng = np.random.default_rng(4)
+    for cfg, ntiles, spp in [(1, 32, None), (2, 16, None), (4, 8, 64), (4, 8, 1024)]:
+        sc = S.build_scene(cfg, samples=spp)
+        ref = oracle_py.RefOracle(sc.max_depth)
+        total = ((sc.width + 7) // 8) * ((sc.height + 7) // 8)
+        tiles = np.sort(rng.choice(total, size=ntiles, replace=False)).astype(np.uint32)
+        px = tile_pixels(sc.width, sc.height, tiles)
+        mean, rgb8, st = ref.render_pixels(sc, SEED, pixels=px)
+        tag = f"c{cfg}_s{sc.samples}"
+        out[tag + "_tiles"] = tiles
+        out[tag + "_mean"] = mean
+        out[tag + "_rgb8"] = rgb8
+        out[tag + "_stats"] = np.array([st["rays"], st["tests"]])
+        out[tag + "_dims"] = np.array([sc.width, sc.height, sc.samples, sc.max_depth])
+    return out
+
+
+def samples():
+    out = {}
+    rng = np.random.default_rng(5)
+    for cfg in (1, 2, 4):
+        sc = S.build_scene(cfg)
+        ref = oracle_py.RefOracle(sc.max_depth)
+        keys = np.stack([rng.integers(0, sc.width, 256), rng.integers(0, sc.height, 256),
+                         rng.integers(0, sc.samples, 256)], axis=1).astype(np.uint32)
+        rgb = np.zeros((256, 3))
+        stats = np.zeros((256, 3), dtype=np.int64)
+        for k, (x, y, s) in enumerate(keys):
+            c, st = ref.trace_sample(sc, int(x), int(y), int(s), SEED)
+            rgb[k] = c
+            stats[k] = (st["rays"], st["tests"], st["draws"])
+        out[f"c{cfg}_keys"] = keys
+        out[f"c{cfg}_rgb"] = rgb
+        out[f"c{cfg}_stats"] = stats
+    return out
+
+
+def main():
+    assert oracle_py.ref_available(), "build oracle/_ref first (make oracle, needs /root/reference)"
+    np.savez_compressed(os.path.join(HERE, "primitives.npz"), **primitives(oracle_py.RefOracle(5)))
+    np.savez_compressed(os.path.join(HERE, "frames.npz"), **frames())
+    np.savez_compressed(os.path.join(HERE, "samples.npz"), **samples())
+    for f in ("primitives.npz", "frames.npz", "samples.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

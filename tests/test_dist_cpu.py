@@ -1,0 +1,79 @@
+"""The N > 1 frame assembly on CPU: 2 (and 3) ranks over gloo.  Each rank fills the tile
+buffer of ITS interleaved tile set (values from the CPU oracle, standing in for the kernel),
+rt_amd.dist.gather_tiles() collects them on rank 0 -- the same function bench.py runs over
+RCCL -- and the scattered image must equal the single-process image bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import SEED
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, w, h, spp, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      OMP_NUM_THREADS="1")
+    for p in (os.path.join(ROOT, "raytracer.c_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import oracle_py
+    from rt_amd import abi, dist as D, scene as S
+    from util import tile_pixels, untile_numpy
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = S.build_scene(2, w, h, spp)
+    pt = oracle_py.PtOracle()
+    first, stride, count = D.rank_tiles(w, h, rank, world)
+    tiles, tiles8 = D.alloc_tile_buffers(w, h, world, torch.device("cpu"))
+    assert tiles.shape[0] == D.padded_count(w, h, world) >= count
+    tx = (w + 7) // 8
+    for k in range(count):  # "render" my tiles into the compact tile-major layout
+        t = first + k * stride
+        x0, y0 = (t % tx) * 8, (t // tx) * 8
+        for pit in range(64):
+            x, y = x0 + (pit & 7), y0 + (pit >> 3)
+            if x < w and y < h:
+                mean, rgb8, _ = pt.render_pixels(sc, SEED, pixels=np.array([y * w + x], dtype=np.uint32))
+                tiles[k, pit] = torch.from_numpy(mean[0].astype(np.float32))
+                tiles8[k, pit] = torch.from_numpy(rgb8[0])
+    parts, parts8 = D.gather_tiles(tiles, tiles8, rank, world)
+    if rank == 0:
+        image = np.zeros((h, w, 3), dtype=np.float32)
+        image8 = np.zeros((h, w, 3), dtype=np.uint8)
+        for r, f, s_, c in D.segments(w, h, world):
+            untile_numpy(parts[r].numpy(), w, h, f, s_, c, image)
+            untile_numpy(parts8[r].numpy(), w, h, f, s_, c, image8)
+        mean, rgb8, _ = pt.render_pixels(sc, SEED)
+        ok = np.array_equal(image.reshape(-1, 3), mean.astype(np.float32)) and np.array_equal(image8.reshape(-1, 3), rgb8)
+        open(out_path, "w").write("OK" if ok else "MISMATCH")
+    else:
+        assert parts is None and parts8 is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 40, 24), (3, 37, 21)])
+def test_gather_assembles_the_frame(tmp_path, world, w, h):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, 2, out), nprocs=world, join=True)
+    assert open(out).read() == "OK"
+
+
+def test_world_one_needs_no_collective():
+    import torch
+    from rt_amd import dist as D
+    a, b = D.alloc_tile_buffers(16, 16, 1, torch.device("cpu"))
+    parts, parts8 = D.gather_tiles(a, b, 0, 1)
+    assert parts[0] is a and parts8[0] is b

@@ -1,0 +1,118 @@
+"""The oracle against the committed golden vectors (tests/golden/*.npz, produced by the
+COMPILED REFERENCE via tests/golden/make_golden.py).  Runs everywhere, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SEED
+from util import tile_pixels
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def prim():
+    return np.load(os.path.join(GOLD, "primitives.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def frames():
+    return np.load(os.path.join(GOLD, "frames.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def samples():
+    return np.load(os.path.join(GOLD, "samples.npz"), allow_pickle=False)
+
+
+def test_sphere_known_answers(pt, prim):
+    hits = 0
+    for k in range(len(prim["sph_ray"])):
+        ok, t = pt.intersect_sphere(prim["sph_ray"][k], prim["sph_center"][k], float(prim["sph_radius"][k]))
+        assert ok == bool(prim["sph_hit"][k]), k
+        if ok:
+            assert t == prim["sph_t"][k], k
+            hits += 1
+    assert 200 < hits < len(prim["sph_ray"])  # both outcomes are exercised
+
+
+def test_triangle_known_answers(pt, prim):
+    hits = 0
+    for k in range(len(prim["tri_ray"])):
+        ok, tuv = pt.intersect_triangle(prim["tri_ray"][k], prim["tri_verts"][k])
+        assert ok == bool(prim["tri_hit"][k]), k
+        if ok:
+            assert np.array_equal(tuv, prim["tri_tuv"][k]), k
+            hits += 1
+        v = prim["tri_verts"][k].reshape(3, 5)[:, :3].reshape(-1)
+        assert np.array_equal(pt.surface_normal(v), prim["tri_normal"][k])
+    assert 100 < hits < len(prim["tri_ray"])
+
+
+def test_reference_unit_test_vectors(pt, prim):
+    """the reference's test.c: cross((2,3,4),(5,6,7)) == (-3,6,-3) (test.c:60-63, passes there);
+    calculate_surface_normal((-1,1,1),(1,1,1),(1,1,-1)) is (0,-1,0) -- test.c:78 expects (0,1,0)
+    and FAILS in the reference; the function's behaviour is the contract."""
+    assert np.array_equal(prim["testc_cross"], [-3.0, 6.0, -3.0])
+    assert np.array_equal(prim["testc_normal"], [0.0, -1.0, 0.0])
+    assert np.array_equal(pt.surface_normal([-1, 1, 1, 1, 1, 1, 1, 1, -1]), [0.0, -1.0, 0.0])
+
+
+def test_brdf_helpers(pt, prim):
+    for k in range(len(prim["brdf_in"])):
+        a, b = prim["brdf_in"][k]
+        assert np.array_equal(pt.reflect(a, b), prim["reflect"][k])
+        assert np.array_equal(pt.refract(a, b, 1.0), prim["refract"][k])
+        u, v, *col = prim["checker_uvc"][k]
+        assert np.array_equal(pt.checkered(col, u, v, 100000.0), prim["checker"][k])
+    # the CLAMP_BETWEEN quirk: refract(I, N, 1.0) is I (up to the sign of zero)
+    assert np.allclose(prim["refract"], prim["brdf_in"][:, 0], atol=0, rtol=0)
+
+
+def test_camera(pt, prim):
+    for k in range(4):
+        w, h = prim["cam_size"][k]
+        cam = pt.init_camera(prim["cam_pose"][k][:3], prim["cam_pose"][k][3:], int(w), int(h))
+        assert np.array_equal(np.frombuffer(bytes(cam), dtype=np.float64), prim["cam_frame"][k])
+        for row in prim["cam_rays"][k]:
+            assert np.array_equal(pt.camera_ray(cam, row[0], row[1]), row[2:])
+
+
+def test_rng_streams(pt, prim):
+    for key, want in zip(prim["rng_keys"], prim["rng_draws"]):
+        got = pt.random_doubles(int(key[0]), int(key[1]), int(key[2]), 16)
+        assert np.array_equal(got, want)
+        assert ((got >= 0) & (got < 1)).all()
+
+
+def test_config1_frame(pt, frames):
+    from rt_amd import scene as S
+    sc = S.build_scene(1, 64, 64, 4)
+    mean, rgb8, st = pt.render_pixels(sc, SEED)
+    assert np.array_equal(mean, frames["c1_64_mean"])
+    assert np.array_equal(rgb8, frames["c1_64_rgb8"])
+    assert [st["rays"], st["tests"]] == frames["c1_64_stats"].tolist()
+
+
+@pytest.mark.parametrize("tag,cfg", [("c1_s4", 1), ("c2_s64", 2), ("c4_s64", 4), ("c4_s1024", 4)])
+def test_full_size_tiles(pt, frames, tag, cfg):
+    from rt_amd import scene as S
+    w, h, spp, depth = [int(v) for v in frames[tag + "_dims"]]
+    sc = S.build_scene(cfg, w, h, spp)
+    assert sc.max_depth == depth
+    px = tile_pixels(w, h, frames[tag + "_tiles"])
+    mean, rgb8, st = pt.render_pixels(sc, SEED, pixels=px)
+    assert np.array_equal(mean, frames[tag + "_mean"])
+    assert np.array_equal(rgb8, frames[tag + "_rgb8"])
+    assert [st["rays"], st["tests"]] == frames[tag + "_stats"].tolist()
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4])
+def test_sample_traces(pt, samples, cfg):
+    from rt_amd import scene as S
+    sc = S.build_scene(cfg)
+    for (x, y, s), rgb, st in zip(samples[f"c{cfg}_keys"], samples[f"c{cfg}_rgb"], samples[f"c{cfg}_stats"]):
+        c, got = pt.trace_sample(sc, int(x), int(y), int(s), SEED)
+        assert np.array_equal(c, rgb)
+        assert [got["rays"], got["tests"], got["draws"]] == st.tolist()

@@ -144,3 +144,74 @@ def test_host_api_render_matches_tiles(gpu, pt):
     mean, rgb8, ost = pt.render_pixels(sc, SEED)
     assert rays == ost["rays"]
     assert np.abs(fb.reshape(-1, 3).astype(np.int16) - rgb8.astype(np.int16)).max() <= 1
+
+
+# ---- against the committed golden vectors (produced by the COMPILED REFERENCE) -----------
+
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def test_golden_config1_frame(gpu):
+    from rt_amd import scene as S
+    fr = np.load(GOLD + "/frames.npz", allow_pickle=False)
+    sc = S.build_scene(1, 64, 64, 4)
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(SEED)
+    ost = dict(rays=int(fr["c1_64_stats"][0]), tests=int(fr["c1_64_stats"][1]))
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, fr["c1_64_mean"], fr["c1_64_rgb8"], ost,
+                  what="golden config 1 64x64")
+    gs.close()
+
+
+@pytest.mark.parametrize("tag,cfg", [("c1_s4", 1), ("c2_s64", 2), ("c4_s64", 4), ("c4_s1024", 4)])
+def test_golden_full_size_tiles(gpu, tag, cfg):
+    """tiles of the FULL-SIZE configurations (config 4 at its full 1024 spp included)"""
+    import torch
+    from rt_amd import scene as S
+    fr = np.load(GOLD + "/frames.npz", allow_pickle=False)
+    w, h, spp, depth = [int(v) for v in fr[tag + "_dims"]]
+    sc = S.build_scene(cfg, w, h, spp)
+    gs = gpu.GpuScene(sc)
+    got, got8 = [], []
+    stats = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for t in fr[tag + "_tiles"]:
+        tl, tl8, _ = gs.render_tiles(SEED, int(t), 1, 1, stats=stats)
+        got.append(tl[0])
+        got8.append(tl8[0])
+    torch.cuda.synchronize()
+    g = torch.stack(got).cpu().numpy().reshape(-1, 3)
+    g8 = torch.stack(got8).cpu().numpy().reshape(-1, 3)
+    st = stats.cpu().tolist()
+    ost = dict(rays=int(fr[tag + "_stats"][0]), tests=int(fr[tag + "_stats"][1]))
+    assert_parity(g, g8, dict(rays=st[0], tests=st[2]), fr[tag + "_mean"], fr[tag + "_rgb8"], ost, what=tag)
+    gs.close()
+
+
+def test_untile_matches_numpy(gpu):
+    import torch
+    from rt_amd import scene as S
+    from util import untile_numpy
+    sc = S.build_scene(1, 37, 21, 1)
+    gs = gpu.GpuScene(sc)
+    total = gpu.n_tiles(37, 21)
+    rng = np.random.default_rng(0)
+    for first, stride in [(0, 1), (1, 3), (2, 5)]:
+        count = (total - first + stride - 1) // stride
+        t = rng.uniform(0, 1, (count, 64, 3)).astype(np.float32)
+        t8 = rng.integers(0, 256, (count, 64, 3), dtype=np.uint8)
+        img, img8 = gs.untile(torch.from_numpy(t).cuda(), torch.from_numpy(t8).cuda(), first, stride, count)
+        torch.cuda.synchronize()
+        want = untile_numpy(t, 37, 21, first, stride, count, np.zeros((21, 37, 3), dtype=np.float32))
+        want8 = untile_numpy(t8, 37, 21, first, stride, count, np.zeros((21, 37, 3), dtype=np.uint8))
+        assert np.array_equal(img.cpu().numpy(), want) and np.array_equal(img8.cpu().numpy(), want8)
+    gs.close()
+
+
+def test_render_image_c_host_entry(gpu, pt):
+    """rt_hip_render_image(): host buffers in, synchronous -- what the C host calls"""
+    from rt_amd import scene as S
+    sc = S.build_scene(2, 72, 40, 8)
+    img, img8, st, secs = gpu.render_image_host(sc, SEED, n_devices=1)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img, img8, st, mean, rgb8, ost, what="rt_hip_render_image")
+    assert secs > 0

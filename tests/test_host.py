@@ -1,0 +1,218 @@
+"""Host-side logic of the boundary (no GPU): camera, primitives, OBJ loader, PNG writer,
+scene builders, the shared RNG, tile partition arithmetic."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import SEED
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def host():
+    from rt_amd import abi
+    return abi.load_host()
+
+
+@pytest.fixture(scope="module")
+def prim():
+    return np.load(os.path.join(GOLD, "primitives.npz"), allow_pickle=False)
+
+
+def test_init_camera_matches_golden(prim):
+    from rt_amd import scene as S
+    for k in range(4):
+        w, h = [int(v) for v in prim["cam_size"][k]]
+        cam = S.make_camera(w, h, tuple(prim["cam_pose"][k][:3]), tuple(prim["cam_pose"][k][3:]))
+        assert np.array_equal(np.frombuffer(bytes(cam), dtype=np.float64), prim["cam_frame"][k])
+
+
+def test_host_primitives_match_golden(host, prim):
+    from rt_amd import abi
+    for k in range(0, len(prim["sph_ray"]), 3):
+        r = prim["sph_ray"][k]
+        ray = abi.Ray(abi.Vec3(*r[:3]), abi.Vec3(*r[3:]))
+        hit = abi.Hit()
+        ok = host.intersect_sphere(C.byref(ray), abi.Vec3(*prim["sph_center"][k]), float(prim["sph_radius"][k]),
+                                   C.byref(hit))
+        assert ok == bool(prim["sph_hit"][k])
+        if ok:
+            assert hit.t == prim["sph_t"][k]
+    for k in range(0, len(prim["tri_ray"]), 3):
+        r = prim["tri_ray"][k]
+        ray = abi.Ray(abi.Vec3(*r[:3]), abi.Vec3(*r[3:]))
+        v = prim["tri_verts"][k].reshape(3, 5)
+        vs = [abi.Vertex(abi.Vec3(*row[:3]), abi.Vec2(*row[3:])) for row in v]
+        hit = abi.Hit()
+        ok = host.intersect_triangle(C.byref(ray), vs[0], vs[1], vs[2], C.byref(hit))
+        assert ok == bool(prim["tri_hit"][k])
+        if ok:
+            assert [hit.t, hit.u, hit.v] == prim["tri_tuv"][k].tolist()
+        n = host.calculate_surface_normal(vs[0].pos, vs[1].pos, vs[2].pos)
+        assert list(n.tuple()) == prim["tri_normal"][k].tolist()
+
+
+def test_counters_and_point_at(host):
+    from rt_amd import abi
+    before = C.c_longlong.in_dll(host, "intersection_test_count").value
+    ray = abi.Ray(abi.Vec3(0, 0, 0), abi.Vec3(0, 0, 1))
+    hit = abi.Hit()
+    assert host.intersect_sphere(C.byref(ray), abi.Vec3(0, 0, 5), 1.0, C.byref(hit)) and hit.t == 4.0
+    assert C.c_longlong.in_dll(host, "intersection_test_count").value == before + 1
+    assert host.point_at(C.byref(ray), 2.5).tuple() == (0.0, 0.0, 2.5)
+    assert host.clamp(abi.Vec3(-1, 0.5, 7)).tuple() == (0.0, 0.5, 1.0)
+
+
+def test_host_rng_stream(host, pt):
+    host.rt_set_seed(SEED)
+    got = [host.random_double() for _ in range(8)]
+    want = pt.random_doubles(SEED, 0xFFFFFFFF, 0xFFFFFFFF, 8)
+    assert got == want.tolist()
+    r = host.random_range(-3.0, 5.0)
+    assert -3.0 <= r < 5.0
+
+
+def test_rng_python_reimplementation(pt):
+    """rt_rng.h restated in Python integers: the header is the single definition both the
+    oracle and the kernel include; this guards it against accidental edits."""
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z ^= z >> 30
+        z = (z * 0xBF58476D1CE4E5B9) & M
+        z ^= z >> 27
+        z = (z * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    def stream(seed, pixel, sample, n):
+        h = mix((seed + 0x9E3779B97F4A7C15 * (pixel + 1)) & M)
+        h = mix((h + 0xD1B54A32D192ED03 * (sample + 1)) & M) or 0x9E3779B97F4A7C15
+        out = []
+        for _ in range(n):
+            h ^= (h << 13) & M
+            h ^= h >> 7
+            h ^= (h << 17) & M
+            out.append((h >> 33) / 2147483648.0)
+        return out
+    for key in [(SEED, 0, 0), (SEED, 2073599, 1023), (2**63 + 5, 17, 4095)]:
+        assert stream(*key, 12) == pt.random_doubles(*key, 12).tolist()
+
+
+def test_load_obj_cube(host, pt):
+    """load_obj() on the reference's assets/cube.obj == the procedural cube of scene 3"""
+    from rt_amd import abi, scene as S
+    mesh = abi.TriangleMesh()
+    assert host.load_obj(os.path.join(GOLD, "cube.obj").encode(), C.byref(mesh))
+    assert mesh.num_triangles == 12
+    sc = S.build_scene(3, 64, 36, 1)
+    assert sc.n_meshes == 1 and sc.meshes[0].mesh.num_triangles == 12
+    host.rt_mesh_flip_winding(C.byref(mesh))
+    for k in range(36):
+        a, b = mesh.vertices[k], sc.meshes[0].mesh.vertices[k]
+        # scene 3 = file vertices * 6 + (0, 1, 0)
+        assert (a.pos.x * 6.0, a.pos.y * 6.0 + 1.0, a.pos.z * 6.0) == b.pos.tuple()
+        assert (a.tex.x, a.tex.y) == (0.0, 0.0)
+    # positions are floats widened to double (what the vendored OBJ parser yields)
+    xs = sorted({mesh.vertices[k].pos.x for k in range(36)})
+    assert float(np.float32(0.999999)) in xs and 0.999999 not in xs
+    # outward normals after the flip, under the reference's winding formula
+    for t in range(12):
+        v = [mesh.vertices[3 * t + j].pos.tuple() for j in range(3)]
+        n = pt.surface_normal(np.array(v).reshape(-1))
+        assert np.dot(n, np.mean(v, axis=0)) > 0.5
+    assert not host.load_obj(b"/nonexistent.obj", C.byref(mesh))
+    sc.free()
+
+
+def test_load_obj_features(host, tmp_path):
+    from rt_amd import abi
+    p = tmp_path / "t.obj"
+    p.write_text("# quad + tri, vt, negative indices\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+                 "vn 0 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\nf -4 -3 -2\n")
+    mesh = abi.TriangleMesh()
+    assert host.load_obj(str(p).encode(), C.byref(mesh))
+    assert mesh.num_triangles == 3
+    got = [(mesh.vertices[k].pos.tuple(), (mesh.vertices[k].tex.x, mesh.vertices[k].tex.y)) for k in range(9)]
+    assert got[0] == ((0, 0, 0), (0, 0)) and got[1] == ((1, 0, 0), (1, 0)) and got[2] == ((1, 1, 0), (1, 1))
+    assert got[3] == ((0, 0, 0), (0, 0)) and got[4] == ((1, 1, 0), (1, 1)) and got[5] == ((0, 1, 0), (0, 1))
+    assert [g[0] for g in got[6:]] == [(0, 0, 0), (1, 0, 0), (1, 1, 0)] and got[6][1] == (0, 0)
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")
+    assert not host.load_obj(str(bad).encode(), C.byref(mesh))
+
+
+def test_png_writer_roundtrip(host, tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    path = str(tmp_path / "o.png")
+    assert host.stbi_write_png(path.encode(), 17, 13, 3, img.ctypes.data, 17 * 3) == 1
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        (n,), typ = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(typ + body)
+        chunks.append((typ, body))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (17, 13, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(13, 1 + 17 * 3)
+    assert (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(13, 17, 3), img)
+    assert host.stbi_write_png(b"/nonexistent_dir/x.png", 17, 13, 3, img.ctypes.data, 51) == 0
+
+
+def test_scene_builders(pt):
+    from rt_amd import abi, scene as S
+    counts = {1: (4, 0, 0), 2: (10, 0, 0), 3: (5, 1, 12), 4: (38, 0, 0), 5: (8, 1, 10240)}
+    for cfg, (no, nm, nt) in counts.items():
+        sc = S.build_scene(cfg, 64, 36, 1)
+        assert (sc.n_objects, sc.n_meshes, sc.n_triangles) == (no, nm, nt)
+        for i in range(no):
+            o = sc.objects[i]
+            assert o.flags in (abi.M_DEFAULT, abi.M_REFLECTION) and o.radius > 0
+        sc.free()
+    # config 2: spheres rest on the ground and do not overlap
+    sc = S.build_scene(2)
+    sph = [(np.array(sc.objects[i].center.tuple()), sc.objects[i].radius) for i in range(1, 10)]
+    for i, (c, r) in enumerate(sph):
+        assert abs(c[1] - (r - 5.0)) < 1e-12
+        for c2, r2 in sph[i + 1:]:
+            assert np.linalg.norm(c - c2) >= r + r2
+    # config 4 follows the aspect ratio (reference main.c:244-247)
+    a = S.build_scene(4, 1920, 1080, 1)
+    assert a.objects[3].center.x == 10000 + 20 * (1920 / 1080)
+    assert a.objects[36].emission.tuple() == (0.0, 0x32 * 15 / 255.0, 0xA0 * 15 / 255.0)
+    # config 5: the UV sphere's non-degenerate triangles face outward under the reference's winding
+    sc = S.build_scene(5, 64, 36, 1)
+    m = sc.meshes[0].mesh
+    centre = np.array([0.0, -8.0, 4.0])
+    checked = 0
+    for t in range(0, m.num_triangles, 97):
+        v = np.array([m.vertices[3 * t + j].pos.tuple() for j in range(3)])
+        if np.linalg.norm(np.cross(v[1] - v[0], v[2] - v[0])) < 1e-9:
+            continue
+        n = pt.surface_normal(v.reshape(-1))
+        assert np.dot(n, v.mean(axis=0) - centre) > 0
+        checked += 1
+    assert checked > 50
+    sc.free()
+
+
+def test_tile_partition_arithmetic():
+    from rt_amd import dist as D
+    for (w, h) in [(1920, 1080), (37, 21), (8, 8), (9, 9), (3840, 2160)]:
+        total = D.n_tiles(w, h)
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                f, s, c = D.rank_tiles(w, h, r, world)
+                seen += [f + k * s for k in range(c)]
+                assert c <= D.padded_count(w, h, world)
+            assert sorted(seen) == list(range(total))

@@ -41,3 +41,16 @@ def assert_parity(gpu_img, gpu_img8, gpu_stats, mean, rgb8, stats, what=""):
         assert gpu_stats["tests"] == stats["tests"], f"{what}: tests {gpu_stats['tests']} != {stats['tests']}"
         if "casts" in stats:
             assert gpu_stats["casts"] == stats["casts"]
+
+
+def untile_numpy(tiles, width, height, first, stride, count, image):
+    """numpy statement of rt_hip_untile(): tiles [>=count, 64, 3] -> image [H, W, 3] in place"""
+    tx = (width + 7) // 8
+    for k in range(count):
+        t = first + k * stride
+        x0, y0 = (t % tx) * 8, (t // tx) * 8
+        block = np.asarray(tiles[k]).reshape(8, 8, 3)
+        h = min(8, height - y0)
+        w = min(8, width - x0)
+        image[y0:y0 + h, x0:x0 + w] = block[:h, :w]
+    return image
