@@ -33,6 +33,11 @@ shim: $(SHIM)
 $(SHIM): $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC)/rt_hip.h $(INC)/rt_rng.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl
 
+# diagnostic build: wave-level event counters in stats[4..15] (tools/diag.py); never shipped
+shim-diag: $(CSRC)/librt_hip_diag.so
+$(CSRC)/librt_hip_diag.so: $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC)/rt_hip.h $(INC)/rt_rng.h
+	$(HIPCC) $(HIPFLAGS) -DPT_DIAG -shared -o $@ $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl
+
 host: $(HOSTLIB) $(CLI)
 $(HOSTLIB): $(HOST_SRC) $(HOST_HDR) $(SHIM)
 	$(CC) $(CFLAGS) -shared -o $@ $(HOST_SRC) -L$(CSRC) -lrt_hip -Wl,-rpath,'$$ORIGIN/../csrc' -lz -lm
@@ -47,4 +52,4 @@ clean:
 	rm -f $(SHIM) $(HOSTLIB) $(CLI)
 	$(MAKE) -C $(ROOT)oracle clean
 
-.PHONY: all shim host oracle clean
+.PHONY: all shim shim-diag host oracle clean

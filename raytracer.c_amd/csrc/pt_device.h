@@ -3,7 +3,7 @@
  * HBM layout of a scene (RtHipScene), all fp64, built once by
  * rt_hip_scene_create() and read-only afterwards:
  *
- *   sphere_geom [n_spheres] x 4 doubles : cx, cy, cz, radius*radius
+ *   sphere_geom [n_spheres] x 5 doubles : cx, cy, cz, radius*radius, |c| (upper bound)
  *       what the scan of intersect() touches per test (32 B, one ds_read_b128
  *       pair once staged in LDS).  radius*radius is the product the reference
  *       forms per test (raytracer.c:87); forming it once is the same double.
@@ -31,6 +31,8 @@
 #define PT_SLICES 4         /* sample slices per pixel inside one wavefront */
 #define PT_BLOCK 256        /* 4 wavefronts: 64 pixels x 4 slices */
 #define PT_MAT_STRIDE 8     /* doubles per material record */
+#define PT_GEOM_STRIDE 6     /* LDS doubles per sphere: cx cy cz r2 r2_hi neg_tol */
+#define PT_GEOM_SRC_STRIDE 5 /* HBM doubles per sphere: cx cy cz r2 |c| */
 #define PT_MAX_LDS_SPHERES 1024
 #define PT_MAX_LDS_TRIS 1024 /* triangles staged in LDS in one piece */
 
@@ -61,6 +63,8 @@ struct PtLaunch
   PtCamera cam;
   int32_t width, height, samples, max_depth;
   uint64_t seed;
+  double bound_R; /* >= |o| of every ray origin: scene reach and camera distance, see scan_spheres */
+  double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
   float *tiles_rgb;
   uint8_t *tiles_rgb8;
@@ -71,7 +75,7 @@ struct PtLaunch
 #include <hip/hip_runtime.h>
 /* host-side launchers, defined next to the kernels in pt_kernel.hip */
 size_t pt_render_lds_bytes(const PtSceneView &scene);
-hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream);
+hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant);
 hipError_t pt_launch_untile(const float *tiles_rgb, const uint8_t *tiles_rgb8, int width, int height,
                             uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count, float *image_rgb,
                             uint8_t *image_rgb8, hipStream_t stream);

@@ -8,28 +8,35 @@
  * :227-253, reflect :349-352, checkered_texture :386-391, the sample mean and
  * gamma-5 tonemap :212-220.
  *
- * Mapping (one workgroup = one 8x8 pixel tile):
- *   256 threads = 4 wavefronts.  Wavefront w owns tile rows 2w, 2w+1 (16
- *   pixels); lane l of it works on pixel (l >> 2) of those 16 and on sample
- *   slice (l & 3): samples s = slice, slice+4, ... of that pixel.  Each lane
- *   runs a FLATTENED loop -- one iteration = one trace_path() call of the
- *   reference; a lane whose path ends starts its next sample in the same
- *   iteration slot -- so all 64 lanes stay busy in the scene scan, which is
- *   wave-uniform (every lane tests the same primitive, read from LDS as a
- *   broadcast).  The four slice partial sums of a pixel are combined with two
- *   xor-shuffles in a fixed order, the tile is staged in LDS and leaves as one
- *   fully coalesced 768-byte float3 store (plus 192 tonemapped bytes).
+ * pt_render_tiles (shipped).  One workgroup = one 8x8 pixel tile = 4 wavefronts;
+ * wavefront w owns tile rows 2w, 2w+1 (16 pixels) and their 16*spp samples as a POOL of
+ * jobs.  Each lane runs a flattened state machine: one loop iteration = one
+ * trace_path() call of the reference; a lane whose path ends adds its sample to the
+ * pixel's accumulator and pulls the next (pixel, sample) job of the pool in the same
+ * iteration slot (wave-synchronous: ballot + prefix count, no atomics), so all 64 lanes
+ * stay busy until the pool is dry whatever the individual path lengths are.  The scene
+ * scan -- 80 % of the work -- is split into a wave-uniform conservative filter and a
+ * per-lane exact test over the survivors (scan_spheres below).  Per-pixel sums are
+ * kept in LDS as 64-bit FIXED-POINT integers (power-of-two scale chosen per launch from a
+ * bound on the radiance, ~2^-40 relative resolution): integer addition is associative,
+ * so the image is bit-identical under any lane / tile / GPU assignment although samples
+ * finish in a data-dependent order.  The tile leaves as one coalesced 768-byte float3
+ * store (+192 tonemapped bytes).
  *
- * Numerics: everything on the decision path (hit / miss, closest index,
- * Russian roulette, rejection sampling, hemisphere flip) is fp64 in exactly
- * the reference's operation order, compiled with -ffp-contract=off, IEEE
- * sqrt and division -- so every branch decision, hence every RNG draw and
- * the ray / test counters, equals the CPU reference's bit for bit.  Only the
- * radiance VALUE is accumulated differently (forward: L += T*e; T *= albedo*cos
- * instead of the recursive nesting), a ~1e-16 relative difference.
+ * pt_render_tiles_v0 (kept for A/B and as the plainest statement of the algorithm): static
+ * assignment lane = (pixel, sample slice), literal scan, fp64 partial sums combined by
+ * xor-shuffles in a fixed order.
  *
- * No MFMA: this is branchy fp64 scalar-per-lane math with no dense
- * contraction.  The bounding roof is the fp64 VALU issue rate.
+ * Numerics: everything on the decision path (hit / miss, closest index, Russian
+ * roulette, rejection sampling, hemisphere flip) is fp64 in exactly the reference's
+ * operation order, compiled with -ffp-contract=off, IEEE sqrt and division -- so every
+ * branch decision, hence every RNG draw and the ray / test counters, equals the CPU
+ * reference's bit for bit.  Only the radiance VALUE is accumulated differently (forward:
+ * L += T*e; T *= albedo*cos instead of the recursive nesting; fixed-point sample sum), a
+ * ~1e-12 relative difference, far inside the float32 output's rounding.
+ *
+ * No MFMA: branchy fp64 scalar-per-lane math with no dense contraction.  The bounding
+ * roof is the fp64 VALU issue rate.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,6 +71,14 @@ __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; 
 /* raytracer.c:227 */
 __device__ __forceinline__ double rnd(uint64_t &state) { return rt_rng_double(&state); }
 
+/* random_range(-1, 1) (raytracer.c:229, :239) = rnd * (1 - -1) + -1.  rnd = r * 2^-31 and
+ * the product by 2 are exact, so the only rounding is the final add: one fused
+ * r * 2^-30 - 1 is the same double. */
+__device__ __forceinline__ double rnd_pm1(uint64_t &state)
+{
+  return __builtin_fma((double)rt_rng_next31(&state), 1.0 / 1073741824.0, -1.0);
+}
+
 /* raytracer.c:218-220 */
 __device__ __forceinline__ uint8_t tonemap(double x)
 {
@@ -73,11 +88,438 @@ __device__ __forceinline__ uint8_t tonemap(double x)
   return (uint8_t)(255.0 * cl);
 }
 
+/* PT_DIAG builds (make shim-diag, tools/diag.py) count wave-level events into stats[4..];
+ * the shipped build compiles every DIAG(...) away. */
+#ifdef PT_DIAG
+#define DIAG(slot, value)                                                                   \
+  do                                                                                        \
+  {                                                                                         \
+    const unsigned long long m_ = __ballot(1);                                              \
+    const unsigned long long v_ = (unsigned long long)(value);                              \
+    if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m_))                               \
+      atomicAdd(&diag_ptr[4 + (slot)], v_);                                                  \
+  } while (0)
+#define DIAG_LANES(slot) DIAG(slot, __popcll(__ballot(1)))
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+  for (int off = 32; off > 0; off >>= 1)
+    v = max(v, (uint32_t)__shfl_xor((int)v, off));
+  return v;
+}
+#else
+#define DIAG(slot, value) do { } while (0)
+#define DIAG_LANES(slot) do { } while (0)
+#endif
+
 constexpr double kEps = 1e-8;       /* raytracer.h:24 */
 constexpr double kBg = 10 / 255.0;  /* raytracer.h:46 BACKGROUND */
 constexpr double kPi = 3.14159265359; /* raytracer.h:22 */
 
 } // namespace
+
+/* ---- the sphere scan of intersect() (raytracer.c:401-412) ---------------------------
+ *
+ * VARIANT 0: the literal scan -- every lane runs intersect_sphere() on sphere i, in
+ *   lock step; the sqrt / t0,t1 block sits under a per-lane branch.  Correct but
+ *   wasteful on a 64-wide wavefront: with incoherent rays almost every sphere is
+ *   passed by SOME lane, so the wave pays for the expensive block at ~10-20 % lane
+ *   occupancy (measured: VALU busy 89 %, average 41 % of lanes active).
+ *
+ * VARIANT 1 (shipped): filter, then compact.
+ *   Phase 1, wave-uniform over spheres: a CONSERVATIVE version of the two early
+ *     rejects of intersect_sphere (tca < 0, d2 > r*r) in fused arithmetic (10 fp64
+ *     ops instead of 15).  Fused and unfused results differ by a few ulp of |L|^2; the
+ *     thresholds are widened by a rigorous bound on that difference (staged per sphere
+ *     as neg_tol / r2_hi), so phase 1 never drops a sphere the reference accepts.  It
+ *     only records, per lane, a bit mask of surviving spheres.
+ *   Phase 2, per lane over its own set bits: the EXACT intersect_sphere() (reference
+ *     operation order, no fusion) on that lane's next candidate, sphere data gathered
+ *     from LDS by index.  Lanes test different spheres in the same instruction, so the
+ *     sqrt block now runs at (mean / max candidates per lane) occupancy instead of
+ *     (lanes passing sphere i) / 64.  Visiting candidates in increasing index order with
+ *     strict < keeps the reference's first-index-wins tie rule.
+ *   Exactness: every accept/reject that reaches the result is made by phase 2's exact
+ *   arithmetic; phase 1 can only add work, never change an outcome.
+ */
+template <int VARIANT>
+__device__ __forceinline__ void scan_spheres(const double *geom, uint32_t n_sph, const V3 &o, const V3 &d,
+                                             double &min_t, int &best, unsigned long long *diag_ptr)
+{
+  if (VARIANT == 0)
+  {
+    for (uint32_t i = 0; i < n_sph; i++)
+    {
+      /* intersect_sphere :82-117 */
+      const double *g = geom + PT_GEOM_STRIDE * i;
+      V3 Lv = {g[0] - o.x, g[1] - o.y, g[2] - o.z};
+      double tca = v_dot(Lv, d);
+      double d2 = v_dot(Lv, Lv) - tca * tca;
+      double r2 = g[3];
+      if (!(tca < 0) && !(d2 > r2))
+      {
+        double thc = sqrt(r2 - d2);
+        double t0 = tca - thc, t1 = tca + thc;
+        if (t0 > t1)
+        {
+          double tmp = t0;
+          t0 = t1;
+          t1 = tmp;
+        }
+        if (t0 < 0)
+          t0 = t1;
+        if (t0 > kEps && t0 < min_t)
+        {
+          min_t = t0;
+          best = (int)i;
+        }
+      }
+    }
+    return;
+  }
+
+  for (uint32_t base = 0; base < n_sph; base += 64)
+  {
+    const uint32_t chunk = min(64u, n_sph - base);
+    /* ---- phase 1: conservative filter, all lanes on the same sphere ---- */
+    uint32_t cand_lo = 0, cand_hi = 0;
+    auto filter = [&](uint32_t k) -> bool {
+      const double *g = geom + PT_GEOM_STRIDE * (base + k);
+      const double lx = g[0] - o.x, ly = g[1] - o.y, lz = g[2] - o.z;
+      const double tca = __builtin_fma(lz, d.z, __builtin_fma(ly, d.y, lx * d.x));
+      const double ll = __builtin_fma(lz, lz, __builtin_fma(ly, ly, lx * lx));
+      const double d2 = __builtin_fma(-tca, tca, ll);
+      /* bitwise |: no short-circuit branch.  NaNs compare false and therefore stay
+       * candidates, as they pass both tests of the reference. */
+      return (bool)((int)(tca < g[5]) | (int)(d2 > g[4]));
+    };
+    const uint32_t n_lo = min(chunk, 32u);
+#pragma unroll 4
+    for (uint32_t k = 0; k < n_lo; k++)
+      cand_lo |= filter(k) ? 0u : (1u << k);
+#pragma unroll 4
+    for (uint32_t k = 32; k < chunk; k++)
+      cand_hi |= filter(k) ? 0u : (1u << (k - 32u));
+    /* ---- phase 2: exact intersect_sphere() on each lane's own candidates ---- */
+#ifdef PT_DIAG
+    {
+      const uint32_t mine = (uint32_t)(__popc(cand_lo) + __popc(cand_hi));
+      DIAG(2, wave_max_u32(mine)); /* wave-level phase-2 iterations */
+      uint32_t tot = mine;
+      for (int off = 32; off > 0; off >>= 1)
+        tot += (uint32_t)__shfl_xor((int)tot, off);
+      DIAG(3, tot);                /* lane-level candidates */
+    }
+#endif
+    while (cand_lo | cand_hi)
+    {
+      /* lowest set bit of the 64-bit mask, branch-free */
+      const bool in_lo = cand_lo != 0;
+      const uint32_t word = in_lo ? cand_lo : cand_hi;
+      const uint32_t k = (uint32_t)__builtin_ctz(word) + (in_lo ? 0u : 32u);
+      const uint32_t cleared = word & (word - 1u);
+      cand_lo = in_lo ? cleared : 0u;
+      cand_hi = in_lo ? cand_hi : cleared;
+      const uint32_t i = base + k;
+      const double *g = geom + PT_GEOM_STRIDE * i;
+      V3 Lv = {g[0] - o.x, g[1] - o.y, g[2] - o.z};
+      double tca = v_dot(Lv, d);
+      double d2 = v_dot(Lv, Lv) - tca * tca;
+      double r2 = g[3];
+      if (!(tca < 0) && !(d2 > r2))
+      {
+        DIAG(4, 1);
+        DIAG_LANES(5);
+        double thc = sqrt(r2 - d2);
+        /* t0 <= t1 always (thc >= 0 or NaN): the reference's swap (:95-100) is dead code */
+        double t0 = tca - thc, t1 = tca + thc;
+        if (t0 < 0)
+          t0 = t1;
+        if (t0 > kEps && t0 < min_t)
+        {
+          min_t = t0;
+          best = (int)i;
+        }
+      }
+    }
+  }
+}
+
+/* ---- scene as staged in LDS ------------------------------------------------------------ */
+
+struct SceneCtx
+{
+  const double *geom;     /* n_sph x PT_GEOM_STRIDE */
+  const double *mat;      /* (n_sph + n_meshes) x PT_MAT_STRIDE */
+  const double *tri;      /* n_tri x 9: LDS copy, or the HBM array when it does not fit */
+  const double *tri_normal;
+  const double *tri_tex;
+  const uint32_t *tri_object;
+  uint32_t n_sph, n_tri;
+  int max_depth;
+};
+
+__device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
+{
+  const PtSceneView &sc = L.scene;
+  const uint32_t n_sph = sc.n_spheres, n_mat = sc.n_spheres + sc.n_meshes, n_tri = sc.n_triangles;
+  const bool tris_in_lds = n_tri <= PT_MAX_LDS_TRIS;
+  double *geom = lds;
+  double *mat = geom + PT_GEOM_STRIDE * (size_t)n_sph;
+  double *tri = mat + PT_MAT_STRIDE * (size_t)n_mat;
+  for (uint32_t i = threadIdx.x; i < n_sph; i += PT_BLOCK)
+  {
+    const double *src = sc.sphere_geom + PT_GEOM_SRC_STRIDE * i; /* cx cy cz r2 |c| */
+    double *g = geom + PT_GEOM_STRIDE * i;
+    g[0] = src[0];
+    g[1] = src[1];
+    g[2] = src[2];
+    g[3] = src[3];
+    /* Phase-1 tolerances.  With u = 2^-53, |L| <= |c| + |o| <= reach := |c| + bound_R and
+     * |d| <= 1.0001:  |tca_fused - tca_ref| <= 6.2 u reach,  |d2_fused - d2_ref| <= 23 u reach^2
+     * (each dot product carries <= 3 roundings of terms bounded by |L||d|).  Both are
+     * widened 16x; a false candidate costs a little time, a false reject would be an error. */
+    const double reach = src[4] + L.bound_R;
+    g[4] = src[3] + (16.0 * 23.0 * 1.1102230246251565e-16) * reach * reach;
+    g[5] = -(16.0 * 6.2 * 1.1102230246251565e-16) * reach;
+  }
+  for (uint32_t k = threadIdx.x; k < PT_MAT_STRIDE * n_mat; k += PT_BLOCK)
+    mat[k] = sc.material[k];
+  if (tris_in_lds)
+    for (uint32_t k = threadIdx.x; k < 9 * n_tri; k += PT_BLOCK)
+      tri[k] = sc.tri_geom[k];
+  SceneCtx ctx;
+  ctx.geom = geom;
+  ctx.mat = mat;
+  ctx.tri = tris_in_lds ? tri : sc.tri_geom;
+  ctx.tri_normal = sc.tri_normal;
+  ctx.tri_tex = sc.tri_tex;
+  ctx.tri_object = sc.tri_object;
+  ctx.n_sph = n_sph;
+  ctx.n_tri = n_tri;
+  ctx.max_depth = L.max_depth;
+  return ctx;
+}
+
+/* ---- one sample's path state ------------------------------------------------------------ */
+
+struct Path
+{
+  V3 o, d;      /* current ray */
+  V3 T;         /* throughput */
+  V3 Ls;        /* radiance gathered so far */
+  uint64_t rng;
+  int depth;
+};
+
+struct CameraRegs
+{
+  V3 pos, horizontal, vertical, llc;
+  double w_minus_1, h_minus_1;
+};
+
+__device__ __forceinline__ CameraRegs load_camera(const PtLaunch &L)
+{
+  CameraRegs c;
+  c.pos = ld3(L.cam.pos);
+  c.horizontal = ld3(L.cam.horizontal);
+  c.vertical = ld3(L.cam.vertical);
+  c.llc = ld3(L.cam.llc);
+  c.w_minus_1 = (double)L.width - 1.0;
+  c.h_minus_1 = (double)L.height - 1.0;
+  return c;
+}
+
+/* raytracer.c:203-206 + get_camera_ray :375-384, stream re-seeded per (pixel, sample) */
+__device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uint64_t seed, uint32_t px,
+                                             uint32_t py, uint32_t pixel, uint32_t s)
+{
+  P.rng = rt_rng_seed(seed, pixel, s);
+  const double u = ((double)px + rnd(P.rng)) / cam.w_minus_1;
+  const double v = ((double)py + rnd(P.rng)) / cam.h_minus_1;
+  const V3 on_plane = v_add(cam.llc, v_add(v_scale(cam.horizontal, u), v_scale(cam.vertical, v)));
+  P.o = cam.pos;
+  P.d = v_normalize(v_sub(cam.pos, on_plane));
+  P.T = {1, 1, 1};
+  P.Ls = {0, 0, 0};
+  P.depth = 0;
+}
+
+/* ---- one trace_path() call (raytracer.c:482-554).  Returns true when the path ended; P.Ls
+ * then holds the finished sample's radiance. -------------------------------------------- */
+template <int VARIANT>
+__device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
+                                           unsigned long long *diag_ptr)
+{
+  V3 add = {kBg, kBg, kBg}; /* what this call contributes if the path ends here */
+  bool path_ends = true;
+  const V3 o = P.o, d = P.d;
+
+  if (P.depth <= S.max_depth)
+  {
+    n_casts++;
+    /* ---- intersect(): closest hit, strict <, index order (:393-464) ---- */
+    double min_t = 1.7976931348623157e308; /* DBL_MAX */
+    int best = -1;
+    scan_spheres<VARIANT>(S.geom, S.n_sph, o, d, min_t, best, diag_ptr);
+    double bary_u = 0, bary_v = 0;
+    for (uint32_t i = 0; i < S.n_tri; i++)
+    {
+      /* intersect_triangle :132-150 (Moeller-Trumbore, two-sided) */
+      const double *g = S.tri + 9 * (size_t)i;
+      V3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
+      V3 h = v_cross(d, e2);
+      double a = v_dot(e1, h);
+      if (!(a > -kEps && a < kEps))
+      {
+        double f = 1.0 / a;
+        V3 sv = v_sub(o, v0);
+        double u = f * v_dot(sv, h);
+        if (!(u < 0.0 || u > 1.0))
+        {
+          V3 q = v_cross(sv, e1);
+          double v = f * v_dot(d, q);
+          if (!(v < 0.0 || u + v > 1.0))
+          {
+            double t = f * v_dot(e2, q);
+            if (t > kEps && t < min_t)
+            {
+              min_t = t;
+              best = (int)(S.n_sph + i);
+              bary_u = u;
+              bary_v = v;
+            }
+          }
+        }
+      }
+    }
+
+    if (best >= 0)
+    {
+      DIAG(8, 1);
+      DIAG_LANES(9);
+      /* ---- the winner's hit record (:406-411 / :428-431) ---- */
+      V3 p = v_add(o, v_scale(d, min_t)); /* point_at :257 */
+      V3 n;
+      uint32_t slot;
+      double tex_u = 0, tex_v = 0;
+      const bool is_tri = (uint32_t)best >= S.n_sph;
+      if (!is_tri)
+      {
+        const double *g = S.geom + PT_GEOM_STRIDE * best;
+        n = v_normalize(v_sub(p, ld3(g)));
+        slot = (uint32_t)best;
+      }
+      else
+      {
+        const uint32_t ti = (uint32_t)best - S.n_sph;
+        n = ld3(S.tri_normal + 3 * (size_t)ti);
+        slot = S.tri_object[ti];
+      }
+      const double *m = S.mat + PT_MAT_STRIDE * slot;
+      const double prob = m[0];
+      V3 albedo = ld3(m + 1);
+      const V3 emission = ld3(m + 4);
+      const uint32_t flags = (uint32_t)__double_as_longlong(m[7]);
+
+      add = emission; /* a path that dies in the roulette returns emission (:502) */
+      /* russian roulette :497-502: the draw is always consumed */
+      if (rnd(P.rng) < prob)
+      {
+        path_ends = false;
+        if (flags & PT_FLAG_CHECKER)
+        {
+          if (!is_tri)
+          {
+            tex_u = atan2(n.x, n.z) / (2 * kPi) + 0.5; /* :410-411 */
+            tex_v = n.y * 0.5 + 0.5;
+          }
+          else
+          {
+            /* :154-167 barycentric blend of the texture coordinates */
+            const double *tx = S.tri_tex + 6 * (size_t)((uint32_t)best - S.n_sph);
+            double w0 = 1 - bary_u - bary_v;
+            tex_u = (tx[0] * w0 + tx[2] * bary_u) + tx[4] * bary_v;
+            tex_v = (tx[1] * w0 + tx[3] * bary_u) + tx[5] * bary_v;
+          }
+          /* checkered_texture :386-391, M = 100000 (:508) */
+          double on = (double)((fmod(tex_u * 100000.0, 1.0) > 0.5) ^ (fmod(tex_v * 100000.0, 1.0) < 0.5));
+          double c = 0.3 * (1 - on) + 0.7 * on;
+          albedo = v_scale(albedo, c);
+        }
+        V3 nd;
+        double weight = 1.0;
+        if (flags & PT_FLAG_MIRROR)
+        {
+          /* reflect :349-352; direction left un-normalised (:542) */
+          nd = v_sub(d, v_scale(n, 2 * v_dot(d, n)));
+        }
+        else
+        {
+          /* random_on_hemisphere :231-253: x, y, z drawn in that order */
+          V3 q;
+          double len2;
+          int tries = 0;
+          do
+          {
+            DIAG(10, 1);
+            DIAG_LANES(11);
+            q.x = rnd_pm1(P.rng);
+            q.y = rnd_pm1(P.rng);
+            q.z = rnd_pm1(P.rng);
+            len2 = v_dot(q, q);
+            /* reference: while (sqrt(len2) > 1).  With correctly rounded sqrt,
+             * sqrt(x) > 1  <=>  x > 1 + 2^-52 (x = 1 + 2^-52 still rounds to 1.0), so the
+             * square root is taken once, after the loop (tests/test_host.py checks the
+             * equivalence around the boundary). */
+          } while (len2 > 1.0000000000000002 && ++tries < 100);
+          const double len = sqrt(len2);
+          nd = v_scale(q, 1.0 / len);
+          if (v_dot(nd, n) < 0)
+            nd = v_scale(nd, -1);
+          weight = v_dot(nd, n); /* cos_theta :549 */
+        }
+        /* L = e + albedo (.) (L_next * cos)  ==>  forward form */
+        P.Ls = v_add(P.Ls, v_mul(P.T, emission));
+        P.T = v_mul(P.T, (flags & PT_FLAG_MIRROR) ? albedo : v_scale(albedo, weight));
+        P.o = p;
+        P.d = nd;
+        P.depth++;
+      }
+    }
+  }
+  if (path_ends)
+    P.Ls = v_add(P.Ls, v_mul(P.T, add));
+  return path_ends;
+}
+
+/* ---- epilogue shared by both kernels: coalesced tile store + counters ------------------- */
+
+__device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f, const uint8_t *out_b,
+                                           const unsigned long long *wg_stats, uint32_t tile, uint32_t n_prims)
+{
+  /* 192 floats = 768 contiguous bytes per tile */
+  if (threadIdx.x < PT_TILE_PIXELS * 3)
+    L.tiles_rgb[(size_t)blockIdx.x * (PT_TILE_PIXELS * 3) + threadIdx.x] = out_f[threadIdx.x];
+  if (L.tiles_rgb8 && threadIdx.x < PT_TILE_PIXELS * 3 / 4)
+    reinterpret_cast<uint32_t *>(L.tiles_rgb8)[(size_t)blockIdx.x * (PT_TILE_PIXELS * 3 / 4) + threadIdx.x] =
+        reinterpret_cast<const uint32_t *>(out_b)[threadIdx.x];
+  if (L.stats && threadIdx.x == 0)
+  {
+    const unsigned long long rays = wg_stats[0], casts = wg_stats[1];
+    atomicAdd(&L.stats[0], rays);
+    atomicAdd(&L.stats[1], casts);
+    atomicAdd(&L.stats[2], casts * (unsigned long long)n_prims);
+  }
+  if (L.stats && threadIdx.x == 64)
+  {
+    const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE;
+    const uint32_t cw = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
+    const uint32_t ch = min((uint32_t)PT_TILE, (uint32_t)L.height - ty0);
+    atomicAdd(&L.stats[3], (unsigned long long)cw * ch * (unsigned long long)L.samples);
+  }
+}
+
+/* ---- shipped kernel: pooled samples, fixed-point pixel sums ------------------------------ */
 
 extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles(const PtLaunch L)
 {
@@ -85,31 +527,137 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles(const PtL
   __shared__ float out_f[PT_TILE_PIXELS * 3];
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
+  __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3]; /* fixed-point radiance sums */
 
-  const PtSceneView &sc = L.scene;
-  const uint32_t n_sph = sc.n_spheres;
-  const uint32_t n_mat = sc.n_spheres + sc.n_meshes;
-  const uint32_t n_tri = sc.n_triangles;
-  const bool tris_in_lds = n_tri <= PT_MAX_LDS_TRIS;
+  const SceneCtx S = stage_scene(L, lds);
+  if (threadIdx.x < 2)
+    wg_stats[threadIdx.x] = 0;
+  if (threadIdx.x < PT_TILE_PIXELS * 3)
+    pix_sum[threadIdx.x] = 0;
+  __syncthreads();
 
-  double *geom = lds;                               /* n_sph x 4 */
-  double *mat = geom + 4 * (size_t)n_sph;           /* n_mat x 8 */
-  double *tri = mat + PT_MAT_STRIDE * (size_t)n_mat; /* n_tri x 9 when staged */
+  /* ---- this wave's pixels and job pool ---- */
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t tile = L.tile_first + blockIdx.x * L.tile_stride;
+  const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE + 2u * wave;
+  /* valid sub-rectangle of the wave's 8x2 strip (edge tiles of ragged images) */
+  const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
+  const uint32_t vrows = ty0 >= (uint32_t)L.height ? 0u : min(2u, (uint32_t)L.height - ty0);
+  const uint32_t n_valid = vcols * vrows;
+  const uint32_t spp = (uint32_t)L.samples;
+  const uint32_t pool = n_valid * spp; /* jobs: j -> pixel j % n_valid, sample j / n_valid */
+  const CameraRegs cam = load_camera(L);
 
-  /* ---- stage the scene in LDS (once per workgroup) ---- */
-  for (uint32_t k = threadIdx.x; k < 4 * n_sph; k += PT_BLOCK)
-    geom[k] = sc.sphere_geom[k];
-  for (uint32_t k = threadIdx.x; k < PT_MAT_STRIDE * n_mat; k += PT_BLOCK)
-    mat[k] = sc.material[k];
-  if (tris_in_lds)
-    for (uint32_t k = threadIdx.x; k < 9 * n_tri; k += PT_BLOCK)
-      tri[k] = sc.tri_geom[k];
+  Path P;
+  P.o = {0, 0, 0};
+  P.d = {0, 0, 1};
+  P.T = {1, 1, 1};
+  P.Ls = {0, 0, 0};
+  P.rng = 1;
+  P.depth = 0;
+  uint32_t n_rays = 0, n_casts = 0;
+  uint32_t next_job = 0;     /* wave-uniform */
+  uint32_t pix_slot = 0;     /* 0..63 inside the tile */
+  bool busy = false;
+  unsigned long long *diag_ptr = L.stats;
+  (void)diag_ptr;
+
+  for (;;)
+  {
+    /* ---- hand out jobs to idle lanes: wave-synchronous, deterministic ---- */
+    const unsigned long long idle = __ballot(!busy);
+    if (idle != 0 && next_job < pool)
+    {
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      const uint32_t job = next_job + rank;
+      if (!busy && job < pool)
+      {
+        DIAG(6, 1);
+        DIAG_LANES(7);
+        uint32_t idx, s;
+        if (n_valid == 16)
+        {
+          idx = job & 15u;
+          s = job >> 4;
+        }
+        else
+        {
+          s = job / n_valid;
+          idx = job - s * n_valid;
+        }
+        const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
+        const uint32_t col = idx - row * vcols;
+        const uint32_t px = tx0 + col, py = ty0 + row;
+        pix_slot = (2u * wave + row) * PT_TILE + col;
+        start_sample(P, cam, L.seed, px, py, py * (uint32_t)L.width + px, s);
+        busy = true;
+      }
+      next_job += (uint32_t)__popcll(idle);
+    }
+    if (__ballot(busy) == 0)
+      break; /* pool dry and every lane drained: the one exit, reached by all lanes together */
+
+    if (busy)
+    {
+      DIAG(0, 1);      /* wave-level loop iterations */
+      DIAG_LANES(1);   /* lanes alive in them */
+      n_rays++;
+      if (trace_step<1>(S, P, n_casts, diag_ptr))
+      {
+        /* sample done: add to the pixel's fixed-point sum (integer adds commute: the
+         * result does not depend on which lane finishes first) */
+        atomicAdd(&pix_sum[3 * pix_slot + 0], (unsigned long long)__double2ll_rn(P.Ls.x * L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 1], (unsigned long long)__double2ll_rn(P.Ls.y * L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 2], (unsigned long long)__double2ll_rn(P.Ls.z * L.acc_scale));
+        busy = false;
+      }
+    }
+  }
+
+  if (n_rays)
+  {
+    atomicAdd(&wg_stats[0], (unsigned long long)n_rays);
+    atomicAdd(&wg_stats[1], (unsigned long long)n_casts);
+  }
+  __syncthreads();
+
+  /* ---- per-pixel mean (:215) and tonemap (:218-220), one thread per pixel ---- */
+  if (threadIdx.x < PT_TILE_PIXELS)
+  {
+    const uint32_t t = threadIdx.x;
+    const bool inside = tx0 + (t & 7u) < (uint32_t)L.width &&
+                        (tile / L.tiles_x) * PT_TILE + (t >> 3) < (uint32_t)L.height;
+    const double inv_s = 1.0 / (double)spp;
+    V3 mean;
+    mean.x = ((double)(long long)pix_sum[3 * t + 0] * L.acc_inv_scale) * inv_s;
+    mean.y = ((double)(long long)pix_sum[3 * t + 1] * L.acc_inv_scale) * inv_s;
+    mean.z = ((double)(long long)pix_sum[3 * t + 2] * L.acc_inv_scale) * inv_s;
+    out_f[3 * t + 0] = inside ? (float)mean.x : 0.f;
+    out_f[3 * t + 1] = inside ? (float)mean.y : 0.f;
+    out_f[3 * t + 2] = inside ? (float)mean.z : 0.f;
+    out_b[3 * t + 0] = inside ? tonemap(mean.x) : 0;
+    out_b[3 * t + 1] = inside ? tonemap(mean.y) : 0;
+    out_b[3 * t + 2] = inside ? tonemap(mean.z) : 0;
+  }
+  __syncthreads();
+  store_tile(L, out_f, out_b, wg_stats, tile, S.n_sph + S.n_tri);
+}
+
+/* ---- plain kernel: static (pixel, slice) lanes, literal scan, fp64 sums ------------------
+ * Selected by RT_HIP_KERNEL_VARIANT=0.  Lane l of wave w: pixel (l >> 2) of the wave's 16,
+ * sample slice (l & 3): samples s = slice, slice + 4, ... */
+extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const PtLaunch L)
+{
+  extern __shared__ double lds[];
+  __shared__ float out_f[PT_TILE_PIXELS * 3];
+  __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
+  __shared__ unsigned long long wg_stats[2];
+
+  const SceneCtx S = stage_scene(L, lds);
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
   __syncthreads();
-  const double *tri_src = tris_in_lds ? tri : sc.tri_geom;
 
-  /* ---- which pixel / slice am I ---- */
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t pix_in_tile = wave * 16u + (lane >> 2);
   const uint32_t slice = lane & (PT_SLICES - 1);
@@ -118,213 +666,51 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles(const PtL
   const uint32_t py = (tile / L.tiles_x) * PT_TILE + (pix_in_tile >> 3);
   const bool inside = px < (uint32_t)L.width && py < (uint32_t)L.height;
   const uint32_t pixel = py * (uint32_t)L.width + px;
-  const uint32_t S = (uint32_t)L.samples;
+  const uint32_t spp = (uint32_t)L.samples;
+  const CameraRegs cam = load_camera(L);
 
-  const V3 cam_pos = ld3(L.cam.pos), cam_h = ld3(L.cam.horizontal);
-  const V3 cam_v = ld3(L.cam.vertical), cam_llc = ld3(L.cam.llc);
-  const double inv_w = (double)L.width - 1.0, inv_h = (double)L.height - 1.0; /* divisors */
-
-  V3 acc = {0, 0, 0};   /* sum of finished samples of this lane's slice */
-  V3 Ls = {0, 0, 0};    /* radiance of the sample in flight */
-  V3 T = {1, 1, 1};     /* its path throughput */
-  V3 o = {0, 0, 0}, d = {0, 0, 1};
-  uint64_t rng = 1;
-  int depth = 0;
+  V3 acc = {0, 0, 0}; /* sum of finished samples of this lane's slice */
+  Path P;
+  P.o = {0, 0, 0};
+  P.d = {0, 0, 1};
+  P.T = {1, 1, 1};
+  P.Ls = {0, 0, 0};
+  P.rng = 1;
+  P.depth = 0;
   uint32_t n_rays = 0, n_casts = 0;
-  uint32_t s = inside ? slice : S;
+  uint32_t s = inside ? slice : spp;
   bool fresh = true;
+  unsigned long long *diag_ptr = L.stats;
+  (void)diag_ptr;
 
-  while (s < S)
+  while (s < spp)
   {
+    DIAG(0, 1);
+    DIAG_LANES(1);
     if (fresh)
     {
-      /* raytracer.c:203-206 + get_camera_ray :375-384 */
-      rng = rt_rng_seed(L.seed, pixel, s);
-      double u = ((double)px + rnd(rng)) / inv_w;
-      double v = ((double)py + rnd(rng)) / inv_h;
-      V3 on_plane = v_add(cam_llc, v_add(v_scale(cam_h, u), v_scale(cam_v, v)));
-      o = cam_pos;
-      d = v_normalize(v_sub(cam_pos, on_plane));
-      T = {1, 1, 1};
-      Ls = {0, 0, 0};
-      depth = 0;
+      DIAG(6, 1);
+      DIAG_LANES(7);
+      start_sample(P, cam, L.seed, px, py, pixel, s);
       fresh = false;
     }
-
-    /* ---- one trace_path() call (raytracer.c:482) ---- */
     n_rays++;
-    bool path_ends = true;
-    V3 add = {kBg, kBg, kBg}; /* what this call contributes if the path ends here */
-
-    if (depth <= L.max_depth)
+    if (trace_step<0>(S, P, n_casts, diag_ptr))
     {
-      n_casts++;
-      /* ---- intersect(): closest hit, strict <, index order (:393-464) ---- */
-      double min_t = 1.7976931348623157e308; /* DBL_MAX */
-      int best = -1;
-      for (uint32_t i = 0; i < n_sph; i++)
-      {
-        /* intersect_sphere :82-117 */
-        const double *g = geom + 4 * i;
-        V3 Lv = {g[0] - o.x, g[1] - o.y, g[2] - o.z};
-        double tca = v_dot(Lv, d);
-        double d2 = v_dot(Lv, Lv) - tca * tca;
-        double r2 = g[3];
-        if (!(tca < 0) && !(d2 > r2))
-        {
-          double thc = sqrt(r2 - d2);
-          double t0 = tca - thc, t1 = tca + thc;
-          if (t0 > t1)
-          {
-            double tmp = t0;
-            t0 = t1;
-            t1 = tmp;
-          }
-          if (t0 < 0)
-            t0 = t1;
-          if (t0 > kEps && t0 < min_t)
-          {
-            min_t = t0;
-            best = (int)i;
-          }
-        }
-      }
-      double bary_u = 0, bary_v = 0;
-      for (uint32_t i = 0; i < n_tri; i++)
-      {
-        /* intersect_triangle :132-150 (Moeller-Trumbore, two-sided) */
-        const double *g = tri_src + 9 * (size_t)i;
-        V3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
-        V3 h = v_cross(d, e2);
-        double a = v_dot(e1, h);
-        if (!(a > -kEps && a < kEps))
-        {
-          double f = 1.0 / a;
-          V3 sv = v_sub(o, v0);
-          double u = f * v_dot(sv, h);
-          if (!(u < 0.0 || u > 1.0))
-          {
-            V3 q = v_cross(sv, e1);
-            double v = f * v_dot(d, q);
-            if (!(v < 0.0 || u + v > 1.0))
-            {
-              double t = f * v_dot(e2, q);
-              if (t > kEps && t < min_t)
-              {
-                min_t = t;
-                best = (int)(n_sph + i);
-                bary_u = u;
-                bary_v = v;
-              }
-            }
-          }
-        }
-      }
-
-      if (best >= 0)
-      {
-        /* ---- the winner's hit record (:406-411 / :428-431) ---- */
-        V3 p = v_add(o, v_scale(d, min_t)); /* point_at :257 */
-        V3 n;
-        uint32_t slot;
-        double tex_u = 0, tex_v = 0;
-        const bool is_tri = (uint32_t)best >= n_sph;
-        if (!is_tri)
-        {
-          const double *g = geom + 4 * best;
-          n = v_normalize(v_sub(p, ld3(g)));
-          slot = (uint32_t)best;
-        }
-        else
-        {
-          const uint32_t ti = (uint32_t)best - n_sph;
-          n = ld3(sc.tri_normal + 3 * (size_t)ti);
-          slot = sc.tri_object[ti];
-        }
-        const double *m = mat + PT_MAT_STRIDE * slot;
-        const double prob = m[0];
-        V3 albedo = ld3(m + 1);
-        const V3 emission = ld3(m + 4);
-        const uint32_t flags = (uint32_t)__double_as_longlong(m[7]);
-
-        add = emission; /* a path that dies in the roulette returns emission (:502) */
-        /* russian roulette :497-502: the draw is always consumed */
-        if (rnd(rng) < prob)
-        {
-          path_ends = false;
-          if (flags & PT_FLAG_CHECKER)
-          {
-            if (!is_tri)
-            {
-              tex_u = atan2(n.x, n.z) / (2 * kPi) + 0.5; /* :410-411 */
-              tex_v = n.y * 0.5 + 0.5;
-            }
-            else
-            {
-              /* :154-167 barycentric blend of the texture coordinates */
-              const double *tx = sc.tri_tex + 6 * (size_t)((uint32_t)best - n_sph);
-              double w0 = 1 - bary_u - bary_v;
-              tex_u = (tx[0] * w0 + tx[2] * bary_u) + tx[4] * bary_v;
-              tex_v = (tx[1] * w0 + tx[3] * bary_u) + tx[5] * bary_v;
-            }
-            /* checkered_texture :386-391, M = 100000 (:508) */
-            double on = (double)((fmod(tex_u * 100000.0, 1.0) > 0.5) ^ (fmod(tex_v * 100000.0, 1.0) < 0.5));
-            double c = 0.3 * (1 - on) + 0.7 * on;
-            albedo = v_scale(albedo, c);
-          }
-          V3 nd;
-          double weight = 1.0;
-          if (flags & PT_FLAG_MIRROR)
-          {
-            /* reflect :349-352; direction left un-normalised (:542) */
-            nd = v_sub(d, v_scale(n, 2 * v_dot(d, n)));
-          }
-          else
-          {
-            /* random_on_hemisphere :231-253: x, y, z drawn in that order */
-            V3 q;
-            double len;
-            int tries = 0;
-            do
-            {
-              q.x = rnd(rng) * 2.0 + -1.0;
-              q.y = rnd(rng) * 2.0 + -1.0;
-              q.z = rnd(rng) * 2.0 + -1.0;
-              len = sqrt(v_dot(q, q));
-            } while (len > 1 && ++tries < 100);
-            nd = v_scale(q, 1.0 / len);
-            if (v_dot(nd, n) < 0)
-              nd = v_scale(nd, -1);
-            weight = v_dot(nd, n); /* cos_theta :549 */
-          }
-          /* L = e + albedo (.) (L_next * cos)  ==>  forward form */
-          Ls = v_add(Ls, v_mul(T, emission));
-          T = v_mul(T, (flags & PT_FLAG_MIRROR) ? albedo : v_scale(albedo, weight));
-          o = p;
-          d = nd;
-          depth++;
-        }
-      }
-    }
-
-    if (path_ends)
-    {
-      Ls = v_add(Ls, v_mul(T, add));
-      acc = v_add(acc, Ls);
+      acc = v_add(acc, P.Ls);
       s += PT_SLICES;
       fresh = true;
     }
   }
 
-  /* ---- per-pixel mean: fixed-order reduction over the 4 slice lanes ---- */
+  /* per-pixel mean: fixed-order reduction over the 4 slice lanes */
   acc.x += __shfl_xor(acc.x, 1);
   acc.y += __shfl_xor(acc.y, 1);
   acc.z += __shfl_xor(acc.z, 1);
   acc.x += __shfl_xor(acc.x, 2);
   acc.y += __shfl_xor(acc.y, 2);
   acc.z += __shfl_xor(acc.z, 2);
-  const V3 mean = v_scale(acc, 1.0 / (double)S); /* :215 */
-
+  const V3 mean = v_scale(acc, 1.0 / (double)spp); /* :215 */
   if (slice == 0)
   {
     out_f[3 * pix_in_tile + 0] = inside ? (float)mean.x : 0.f;
@@ -340,27 +726,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles(const PtL
     atomicAdd(&wg_stats[1], (unsigned long long)n_casts);
   }
   __syncthreads();
-
-  /* ---- coalesced tile store: 192 floats = 768 contiguous bytes ---- */
-  if (threadIdx.x < PT_TILE_PIXELS * 3)
-    L.tiles_rgb[(size_t)blockIdx.x * (PT_TILE_PIXELS * 3) + threadIdx.x] = out_f[threadIdx.x];
-  if (L.tiles_rgb8 && threadIdx.x < PT_TILE_PIXELS * 3 / 4)
-    reinterpret_cast<uint32_t *>(L.tiles_rgb8)[(size_t)blockIdx.x * (PT_TILE_PIXELS * 3 / 4) + threadIdx.x] =
-        reinterpret_cast<const uint32_t *>(out_b)[threadIdx.x];
-  if (L.stats && threadIdx.x == 0)
-  {
-    const unsigned long long rays = wg_stats[0], casts = wg_stats[1];
-    atomicAdd(&L.stats[0], rays);
-    atomicAdd(&L.stats[1], casts);
-    atomicAdd(&L.stats[2], casts * (unsigned long long)(n_sph + n_tri));
-  }
-  if (L.stats && threadIdx.x == 64)
-  {
-    const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE;
-    const uint32_t cw = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
-    const uint32_t ch = min((uint32_t)PT_TILE, (uint32_t)L.height - ty0);
-    atomicAdd(&L.stats[3], (unsigned long long)cw * ch * S);
-  }
+  store_tile(L, out_f, out_b, wg_stats, tile, S.n_sph + S.n_tri);
 }
 
 /* Scatter compact tile-major buffers to row-major images: one thread per
@@ -401,25 +767,27 @@ extern "C" __global__ __launch_bounds__(256) void pt_untile(const float *tiles_r
 
 size_t pt_render_lds_bytes(const PtSceneView &sc)
 {
-  size_t doubles = 4 * (size_t)sc.n_spheres + PT_MAT_STRIDE * (size_t)(sc.n_spheres + sc.n_meshes);
+  size_t doubles = PT_GEOM_STRIDE * (size_t)sc.n_spheres + PT_MAT_STRIDE * (size_t)(sc.n_spheres + sc.n_meshes);
   if (sc.n_triangles <= PT_MAX_LDS_TRIS)
     doubles += 9 * (size_t)sc.n_triangles;
   return doubles * sizeof(double);
 }
 
-hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream)
+hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant)
 {
   const size_t lds_bytes = pt_render_lds_bytes(launch.scene);
-  static size_t lds_allowed = 0; /* raised once per process if a scene needs > 64 KiB */
-  if (lds_bytes > 64 * 1024 && lds_bytes > lds_allowed)
+  auto kernel = variant == 0 ? pt_render_tiles_v0 : pt_render_tiles;
+  static size_t lds_allowed[2] = {0, 0}; /* raised once per process if a scene needs > 64 KiB */
+  size_t &allowed = lds_allowed[variant == 0 ? 0 : 1];
+  if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pt_render_tiles),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;
-    lds_allowed = lds_bytes;
+    allowed = lds_bytes;
   }
-  hipLaunchKernelGGL(pt_render_tiles, dim3(launch.tile_count), dim3(PT_BLOCK), lds_bytes, stream, launch);
+  hipLaunchKernelGGL(kernel, dim3(launch.tile_count), dim3(PT_BLOCK), lds_bytes, stream, launch);
   return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -28,6 +29,8 @@ struct RtHipScene
   int device = 0;
   PtSceneView view{};
   void *blob = nullptr; /* one device allocation holding every array */
+  double reach = 0;     /* >= |p| for every point p on any primitive (bounds bounce origins) */
+  double max_emission = 0; /* max |emission component| over all materials */
 };
 
 namespace
@@ -83,6 +86,8 @@ H3 h_cross(H3 a, H3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a
 H3 h_scale(H3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
 H3 h3(const double *p) { return {p[0], p[1], p[2]}; }
 
+double max_abs3(const double *v) { return std::fmax(std::fabs(v[0]), std::fmax(std::fabs(v[1]), std::fabs(v[2]))); }
+
 void put_material(double *m, uint32_t flags, const double *color, const double *emission)
 {
   /* raytracer.c:497: prob = MAX(albedo.x, MAX(albedo.y, albedo.z)) */
@@ -100,6 +105,16 @@ void put_material(double *m, uint32_t flags, const double *color, const double *
   memcpy(&m[7], &bits, sizeof bits);
 }
 
+/* development switch: RT_HIP_KERNEL_VARIANT=0 selects the literal single-phase scan */
+int kernel_variant()
+{
+  static const int v = [] {
+    const char *e = getenv("RT_HIP_KERNEL_VARIANT");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return v;
+}
+
 uint32_t tiles_x_of(int width) { return ((uint32_t)width + PT_TILE - 1) / PT_TILE; }
 uint32_t tiles_y_of(int height) { return ((uint32_t)height + PT_TILE - 1) / PT_TILE; }
 
@@ -109,8 +124,8 @@ int check_params(const RtHipParams *p)
     return fail(RT_HIP_EINVAL, "params is NULL");
   if (p->width < 2 || p->height < 2)
     return fail(RT_HIP_EINVAL, "width and height must be >= 2 (the reference divides by width-1, height-1)");
-  if (p->samples < 1)
-    return fail(RT_HIP_EINVAL, "samples must be >= 1");
+  if (p->samples < 1 || p->samples > (1 << 26))
+    return fail(RT_HIP_EINVAL, "samples must be in [1, 2^26]");
   if (p->max_depth < 0 || p->max_depth > 1000000)
     return fail(RT_HIP_EINVAL, "max_depth out of range");
   if ((uint64_t)p->width * (uint64_t)p->height > 0xFFFFFFFFull)
@@ -171,22 +186,37 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   if (n_spheres + n_meshes > 0xFFFFFFu || n_tri > 0x7FFFFFFFu - n_spheres)
     return fail(RT_HIP_ELIMIT, "scene too large");
   const size_t n_mat = n_spheres + n_meshes;
-  if ((4 * n_spheres + PT_MAT_STRIDE * n_mat) * sizeof(double) > 150 * 1024)
+  if ((PT_GEOM_STRIDE * n_spheres + PT_MAT_STRIDE * n_mat) * sizeof(double) > 150 * 1024)
     return fail(RT_HIP_ELIMIT, "%zu spheres + %zu meshes do not fit the LDS staging area", n_spheres, n_meshes);
 
   /* ---- build the kernel layout on the host (pt_device.h) ---- */
-  std::vector<double> geom(4 * n_spheres), mat(PT_MAT_STRIDE * n_mat), tgeom(9 * n_tri), tnorm(3 * n_tri),
+  double reach = 0, max_emission = 0;
+  for (size_t i = 0; i < n_spheres; i++)
+    max_emission = std::fmax(max_emission, max_abs3(spheres[i].emission));
+  for (size_t m = 0; m < n_meshes; m++)
+    max_emission = std::fmax(max_emission, max_abs3(meshes[m].emission));
+  std::vector<double> geom(PT_GEOM_SRC_STRIDE * n_spheres), mat(PT_MAT_STRIDE * n_mat), tgeom(9 * n_tri), tnorm(3 * n_tri),
       ttex(6 * n_tri);
   std::vector<uint32_t> tobj(n_tri);
   for (size_t i = 0; i < n_spheres; i++)
   {
-    geom[4 * i + 0] = spheres[i].center[0];
-    geom[4 * i + 1] = spheres[i].center[1];
-    geom[4 * i + 2] = spheres[i].center[2];
-    geom[4 * i + 3] = spheres[i].radius * spheres[i].radius; /* raytracer.c:87 */
+    double *g = &geom[PT_GEOM_SRC_STRIDE * i];
+    g[0] = spheres[i].center[0];
+    g[1] = spheres[i].center[1];
+    g[2] = spheres[i].center[2];
+    g[3] = spheres[i].radius * spheres[i].radius; /* raytracer.c:87 */
+    /* |c|, rounded up: feeds the conservative phase-1 thresholds only, never a result */
+    g[4] = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) * (1.0 + 1e-12);
+    reach = std::fmax(reach, g[4] + std::fabs(spheres[i].radius));
     put_material(&mat[PT_MAT_STRIDE * i], spheres[i].flags, spheres[i].color, spheres[i].emission);
   }
   size_t t = 0;
+  for (size_t m = 0; m < n_meshes; m++)
+    for (size_t k = 0; k < 3 * meshes[m].num_triangles; k++)
+    {
+      const double *q = meshes[m].vertices[k].pos;
+      reach = std::fmax(reach, std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]));
+    }
   for (size_t m = 0; m < n_meshes; m++)
   {
     put_material(&mat[PT_MAT_STRIDE * (n_spheres + m)], meshes[m].flags, meshes[m].color, meshes[m].emission);
@@ -263,6 +293,8 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   sc->view.n_meshes = (uint32_t)n_meshes;
   sc->view.n_triangles = (uint32_t)n_tri;
   sc->view.any_checker = any_checker ? 1u : 0u;
+  sc->reach = reach;
+  sc->max_emission = max_emission;
   *out_scene = sc;
   return RT_HIP_OK;
 }
@@ -317,6 +349,28 @@ int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, cons
   L.samples = params->samples;
   L.max_depth = params->max_depth;
   L.seed = params->seed;
+  {
+    /* every ray origin is the camera position or a point on a primitive */
+    const double *c = camera->position;
+    const double cam = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    L.bound_R = std::fmax(scene->reach, cam) * 1.0001 + 1e-9;
+    if (!(L.bound_R < 1e150))
+      return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.bound_R);
+  }
+  {
+    /* Fixed-point scale of the per-pixel sums (pt_render_tiles): a sample's radiance is
+     * sum_k T_k (.) e_k with throughput T <= 1 (albedo/prob <= 1, cos <= 1) over at most
+     * max_depth + 2 events, so |L| <= (max_depth + 2) * max(BACKGROUND, max emission); the
+     * sum of `samples` of them must stay below 2^62. */
+    const double per_sample = ((double)params->max_depth + 2.0) * std::fmax(10.0 / 255.0, scene->max_emission);
+    const double bound = per_sample * (double)params->samples * 1.01;
+    if (!(bound > 0) || !(bound < 1e300))
+      return fail(RT_HIP_EINVAL, "emission magnitudes give no finite radiance bound (%g)", bound);
+    int e = 0;
+    (void)std::frexp(4611686018427387904.0 / bound, &e); /* 2^62 / bound = m * 2^e, m in [0.5, 1) */
+    L.acc_scale = std::ldexp(1.0, e - 1);
+    L.acc_inv_scale = std::ldexp(1.0, 1 - e);
+  }
   L.tile_first = params->tile_first;
   L.tile_stride = params->tile_stride;
   L.tile_count = params->tile_count;
@@ -329,7 +383,7 @@ int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, cons
   HIP_TRY(hipGetDevice(&prev));
   if (prev != scene->device)
     HIP_TRY(hipSetDevice(scene->device));
-  hipError_t e = pt_launch_render(L, static_cast<hipStream_t>(stream));
+  hipError_t e = pt_launch_render(L, static_cast<hipStream_t>(stream), kernel_variant());
   if (prev != scene->device)
     (void)hipSetDevice(prev);
   if (e != hipSuccess)

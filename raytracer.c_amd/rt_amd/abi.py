@@ -7,7 +7,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # raytracer.c_amd/
 REPO_ROOT = os.path.dirname(PKG_DIR)
-SHIM_PATH = os.path.join(PKG_DIR, "csrc", "librt_hip.so")
+SHIM_PATH = os.environ.get("RT_HIP_SHIM_PATH") or os.path.join(PKG_DIR, "csrc", "librt_hip.so")  # env: dev builds
 HOST_PATH = os.path.join(PKG_DIR, "host", "libraytracer_amd.so")
 
 M_DEFAULT, M_REFLECTION, M_REFRACTION, M_CHECKERED = 2, 4, 8, 16

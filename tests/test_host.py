@@ -216,3 +216,31 @@ def test_tile_partition_arithmetic():
                 seen += [f + k * s for k in range(c)]
                 assert c <= D.padded_count(w, h, world)
             assert sorted(seen) == list(range(total))
+
+
+def test_sqrt_threshold_equivalence():
+    """pt_kernel.hip takes the square root of the rejection loop (reference raytracer.c:240,
+    `while (vec3_length(p) > 1)`) out of the loop using  sqrt(x) > 1  <=>  x > 1 + 2^-52  for a
+    correctly rounded sqrt.  Checked around the boundary and on random values."""
+    import math
+    eps = 2.0 ** -52
+    thr = 1.0000000000000002
+    assert thr == 1.0 + eps
+    for k in range(-8, 64):
+        x = 1.0 + k * eps if k >= 0 else 1.0 + k * eps / 2
+        assert (math.sqrt(x) > 1.0) == (x > thr), (k, x)
+    rng = np.random.default_rng(5)
+    for x in np.concatenate([rng.uniform(0, 3, 20000), 1 + rng.uniform(-1e-12, 1e-12, 20000)]):
+        assert (math.sqrt(float(x)) > 1.0) == (float(x) > thr)
+
+
+def test_fused_range_mapping_is_exact():
+    """rnd_pm1(): fma(r, 2^-30, -1) equals random_range(-1, 1) = (r / 2^31) * (1 - -1) + -1
+    exactly, because r * 2^-30 - 1 is representable for every 31-bit r."""
+    from fractions import Fraction
+    rng = np.random.default_rng(6)
+    for r in list(rng.integers(0, 2**31, 5000)) + [0, 1, 2**30, 2**30 + 1, 2**31 - 1]:
+        r = int(r)
+        ref = (r / 2147483648.0) * (1.0 - -1.0) + -1.0
+        exact = Fraction(r, 2**30) - 1
+        assert Fraction(ref) == exact  # no rounding anywhere: any evaluation order agrees

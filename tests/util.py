@@ -29,9 +29,12 @@ def assert_parity(gpu_img, gpu_img8, gpu_stats, mean, rgb8, stats, what=""):
     assert g.shape == m.shape
     rms = channel_rms(g, m)
     assert (rms <= RMS_TOL).all(), f"{what}: per-channel RMS {rms} > {RMS_TOL}"
-    # the float32 store is the only rounding that should be visible
-    rel = np.abs(g - m) / np.maximum(np.abs(m), 1e-30)
-    assert rel.max() < 1e-6, f"{what}: max relative error {rel.max()}"
+    # much tighter than the north-star bar: only the float32 store (6e-8 relative) and the
+    # fixed-point pixel sums of pt_render_tiles (absolute resolution <= (depth+2) * max
+    # emission * spp * 2^-62, i.e. < 1e-13 on every configuration) may be visible
+    err = np.abs(g - m)
+    bad = err > 1e-6 * np.abs(m) + 1e-12
+    assert not bad.any(), f"{what}: {bad.sum()} values off, worst {err[bad].max()} at value {np.abs(m)[bad][err[bad].argmax()]}"
     if gpu_img8 is not None:
         d8 = np.abs(np.asarray(gpu_img8, dtype=np.int16).reshape(-1, 3) - np.asarray(rgb8, dtype=np.int16).reshape(-1, 3))
         assert d8.max() <= 1, f"{what}: tonemapped bytes differ by {d8.max()} LSB"

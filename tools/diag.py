@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Wave-level event counts of pt_render_tiles from the PT_DIAG build (make shim-diag).
+usage: RT_HIP_SHIM_PATH=raytracer.c_amd/csrc/librt_hip_diag.so python tools/diag.py [config] [spp]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "raytracer.c_amd"))
+import torch
+from rt_amd import gpu as G, scene as S
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+sc = S.build_scene(cfg, samples=spp)
+gs = G.GpuScene(sc)
+stats = torch.zeros(20, dtype=torch.int64, device="cuda")
+total = G.n_tiles(sc.width, sc.height)
+gs.render_tiles(1666943821, 0, 1, total, stats=stats)
+torch.cuda.synchronize()
+st = stats.cpu().tolist()
+rays, casts = st[0], st[1]
+d = st[4:]
+names = ["loop iters (wave)", "loop lanes", "phase2 iters (wave)", "phase2 cands (lane)", "sqrt blocks (wave)", "sqrt lanes",
+         "fresh blocks (wave)", "fresh lanes", "hit blocks (wave)", "hit lanes", "reject-loop iters (wave)", "reject-loop lanes"]
+for n, v in zip(names, d):
+    print(f"{n:28s} {v:15d}")
+it = d[0]
+print(f"rays {rays}  casts {casts}  rays/(64*iters) = lane occupancy of the loop: {rays / (64.0 * it):.3f}")
+print(f"phase-2 iterations per loop iteration: {d[2] / it:.2f}; candidates per ray: {d[3] / casts:.2f}; "
+      f"phase-2 lane occupancy {d[3] / (64.0 * d[2]):.3f}")
+print(f"sqrt blocks per loop iter {d[4] / it:.2f}, lanes/64 {d[5] / (64.0 * d[4]):.3f}")
+print(f"fresh per iter {d[6] / it:.3f} lanes/64 {d[7] / (64.0 * max(d[6], 1)):.3f}")
+print(f"hit per iter {d[8] / it:.3f} lanes/64 {d[9] / (64.0 * max(d[8], 1)):.3f}")
+print(f"reject iters per loop iter {d[10] / it:.2f} lanes/64 {d[11] / (64.0 * max(d[10], 1)):.3f}")
