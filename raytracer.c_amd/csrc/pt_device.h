@@ -31,7 +31,8 @@
 #define PT_SLICES 4         /* sample slices per pixel inside one wavefront */
 #define PT_BLOCK 256        /* 4 wavefronts: 64 pixels x 4 slices */
 #define PT_MAT_STRIDE 8     /* doubles per material record */
-#define PT_GEOM_STRIDE 6     /* LDS doubles per sphere: cx cy cz r2 r2_hi neg_tol */
+#define PT_GEOM_STRIDE 4     /* LDS doubles per sphere: cx cy cz r2 */
+#define PT_FILT_STRIDE 5     /* LDS f32x2 per sphere PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
 #define PT_GEOM_SRC_STRIDE 5 /* HBM doubles per sphere: cx cy cz r2 |c| */
 #define PT_MAX_LDS_SPHERES 1024
 #define PT_MAX_LDS_TRIS 1024 /* triangles staged in LDS in one piece */
@@ -63,7 +64,7 @@ struct PtLaunch
   PtCamera cam;
   int32_t width, height, samples, max_depth;
   uint64_t seed;
-  double bound_R; /* >= |o| of every ray origin: scene reach and camera distance, see scan_spheres */
+  double near_R;  /* the phase-1 filter's assumption |o| <= near_R (rays beyond it skip the filter) */
   double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
   float *tiles_rgb;

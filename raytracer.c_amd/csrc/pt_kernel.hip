@@ -126,82 +126,111 @@ constexpr double kPi = 3.14159265359; /* raytracer.h:22 */
  *   occupancy (measured: VALU busy 89 %, average 41 % of lanes active).
  *
  * VARIANT 1 (shipped): filter, then compact.
- *   Phase 1, wave-uniform over spheres: a CONSERVATIVE version of the two early
- *     rejects of intersect_sphere (tca < 0, d2 > r*r) in fused arithmetic (10 fp64
- *     ops instead of 15).  Fused and unfused results differ by a few ulp of |L|^2; the
- *     thresholds are widened by a rigorous bound on that difference (staged per sphere
- *     as neg_tol / r2_hi), so phase 1 never drops a sphere the reference accepts.  It
- *     only records, per lane, a bit mask of surviving spheres.
- *   Phase 2, per lane over its own set bits: the EXACT intersect_sphere() (reference
+ *   Phase 1, wave-uniform over spheres, two spheres per instruction: a CONSERVATIVE
+ *     version of the two early rejects of intersect_sphere (tca < 0, d2 > r*r) in packed
+ *     fp32 with fused multiply-adds (v_pk_fma_f32: 5 packed ops per sphere instead of 15
+ *     fp64 ops).  fp32 values differ from the reference's fp64 ones by a bounded amount;
+ *     the thresholds are widened by a rigorous bound on that difference (derivation at
+ *     stage_scene), so phase 1 NEVER drops a sphere the reference accepts -- it can only
+ *     let extra ones through.  It records, per lane, a bit mask of surviving spheres.
+ *     Rays that start farther out than the staging assumed (|o| > near_R) skip the filter
+ *     and keep every sphere.
+ *   Phase 2, per lane over its own set bits: the EXACT intersect_sphere() (fp64, reference
  *     operation order, no fusion) on that lane's next candidate, sphere data gathered
  *     from LDS by index.  Lanes test different spheres in the same instruction, so the
- *     sqrt block now runs at (mean / max candidates per lane) occupancy instead of
- *     (lanes passing sphere i) / 64.  Visiting candidates in increasing index order with
- *     strict < keeps the reference's first-index-wins tie rule.
+ *     sqrt block runs at (mean / max candidates per lane) occupancy instead of (lanes
+ *     passing sphere i) / 64.  Visiting candidates in increasing index order with strict <
+ *     keeps the reference's first-index-wins tie rule.
  *   Exactness: every accept/reject that reaches the result is made by phase 2's exact
- *   arithmetic; phase 1 can only add work, never change an outcome.
+ *   arithmetic; phase 1 can only add work, never change an outcome (PT_DIAG builds
+ *   re-check every dropped sphere with the exact test and count violations: zero).
  */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+/* intersect_sphere :82-117, exact.  Updates (min_t, best) with strict <. */
+__device__ __forceinline__ void exact_sphere(const double *g, uint32_t index, const V3 &o, const V3 &d,
+                                             double &min_t, int &best)
+{
+  V3 Lv = {g[0] - o.x, g[1] - o.y, g[2] - o.z};
+  double tca = v_dot(Lv, d);
+  double d2 = v_dot(Lv, Lv) - tca * tca;
+  double r2 = g[3];
+  if (!(tca < 0) && !(d2 > r2))
+  {
+    double thc = sqrt(r2 - d2);
+    /* t0 <= t1 always (thc >= 0 or NaN): the reference's swap (:95-100) is dead code */
+    double t0 = tca - thc, t1 = tca + thc;
+    if (t0 < 0)
+      t0 = t1;
+    if (t0 > kEps && t0 < min_t)
+    {
+      min_t = t0;
+      best = (int)index;
+    }
+  }
+}
+
 template <int VARIANT>
-__device__ __forceinline__ void scan_spheres(const double *geom, uint32_t n_sph, const V3 &o, const V3 &d,
-                                             double &min_t, int &best, unsigned long long *diag_ptr)
+__device__ __forceinline__ void scan_spheres(const double *geom, const f32x2 *filt, double near_R2,
+                                             uint32_t n_sph, const V3 &o, const V3 &d, double &min_t, int &best,
+                                             unsigned long long *diag_ptr)
 {
   if (VARIANT == 0)
   {
     for (uint32_t i = 0; i < n_sph; i++)
-    {
-      /* intersect_sphere :82-117 */
-      const double *g = geom + PT_GEOM_STRIDE * i;
-      V3 Lv = {g[0] - o.x, g[1] - o.y, g[2] - o.z};
-      double tca = v_dot(Lv, d);
-      double d2 = v_dot(Lv, Lv) - tca * tca;
-      double r2 = g[3];
-      if (!(tca < 0) && !(d2 > r2))
-      {
-        double thc = sqrt(r2 - d2);
-        double t0 = tca - thc, t1 = tca + thc;
-        if (t0 > t1)
-        {
-          double tmp = t0;
-          t0 = t1;
-          t1 = tmp;
-        }
-        if (t0 < 0)
-          t0 = t1;
-        if (t0 > kEps && t0 < min_t)
-        {
-          min_t = t0;
-          best = (int)i;
-        }
-      }
-    }
+      exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
     return;
   }
+
+  /* the ray in fp32 (round to nearest: relative error <= 2^-24, part of the bound) */
+  const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  const f32x2 dx = {(float)d.x, (float)d.x}, dy = {(float)d.y, (float)d.y}, dz = {(float)d.z, (float)d.z};
+  const bool far_origin = !(v_dot(o, o) <= near_R2); /* also true for NaN */
 
   for (uint32_t base = 0; base < n_sph; base += 64)
   {
     const uint32_t chunk = min(64u, n_sph - base);
-    /* ---- phase 1: conservative filter, all lanes on the same sphere ---- */
+    /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same sphere pair ---- */
     uint32_t cand_lo = 0, cand_hi = 0;
-    auto filter = [&](uint32_t k) -> bool {
-      const double *g = geom + PT_GEOM_STRIDE * (base + k);
-      const double lx = g[0] - o.x, ly = g[1] - o.y, lz = g[2] - o.z;
-      const double tca = __builtin_fma(lz, d.z, __builtin_fma(ly, d.y, lx * d.x));
-      const double ll = __builtin_fma(lz, lz, __builtin_fma(ly, ly, lx * lx));
-      const double d2 = __builtin_fma(-tca, tca, ll);
-      /* bitwise |: no short-circuit branch.  NaNs compare false and therefore stay
-       * candidates, as they pass both tests of the reference. */
-      return (bool)((int)(tca < g[5]) | (int)(d2 > g[4]));
+    auto filter_pair = [&](uint32_t pair, uint32_t &word, uint32_t shift) {
+      const f32x2 *g = filt + PT_FILT_STRIDE * ((base >> 1) + pair);
+      const f32x2 lx = g[0] - ox, ly = g[1] - oy, lz = g[2] - oz;
+      const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
+      const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, lx * lx));
+      const f32x2 d2 = __builtin_elementwise_fma(-tca, tca, ll);
+      /* bitwise |: no short-circuit branch.  NaNs compare false and stay candidates. */
+      const bool drop0 = (bool)((int)(tca.x < g[4].x) | (int)(d2.x > g[3].x));
+      const bool drop1 = (bool)((int)(tca.y < g[4].y) | (int)(d2.y > g[3].y));
+      word |= (drop0 ? 0u : (1u << shift)) | (drop1 ? 0u : (2u << shift));
     };
-    const uint32_t n_lo = min(chunk, 32u);
+    const uint32_t n_pairs = (chunk + 1u) >> 1;
+    const uint32_t pairs_lo = min(n_pairs, 16u);
 #pragma unroll 4
-    for (uint32_t k = 0; k < n_lo; k++)
-      cand_lo |= filter(k) ? 0u : (1u << k);
+    for (uint32_t p = 0; p < pairs_lo; p++)
+      filter_pair(p, cand_lo, 2u * p);
 #pragma unroll 4
-    for (uint32_t k = 32; k < chunk; k++)
-      cand_hi |= filter(k) ? 0u : (1u << (k - 32u));
-    /* ---- phase 2: exact intersect_sphere() on each lane's own candidates ---- */
+    for (uint32_t p = 16; p < n_pairs; p++)
+      filter_pair(p, cand_hi, 2u * (p - 16u));
+    /* spheres that exist in this chunk (an odd count leaves one padding slot) */
+    const uint32_t valid_lo = chunk >= 32u ? 0xFFFFFFFFu : ((1u << chunk) - 1u);
+    const uint32_t valid_hi = chunk >= 64u ? 0xFFFFFFFFu : (chunk > 32u ? ((1u << (chunk - 32u)) - 1u) : 0u);
+    cand_lo = far_origin ? valid_lo : (cand_lo & valid_lo);
+    cand_hi = far_origin ? valid_hi : (cand_hi & valid_hi);
 #ifdef PT_DIAG
     {
+      /* exactness check of the filter: any sphere it dropped that the exact test accepts? */
+      uint32_t violations = 0;
+      for (uint32_t k = 0; k < chunk; k++)
+      {
+        const bool kept = k < 32 ? ((cand_lo >> k) & 1u) : ((cand_hi >> (k - 32u)) & 1u);
+        double t_probe = 1.7976931348623157e308;
+        int b_probe = -1;
+        exact_sphere(geom + PT_GEOM_STRIDE * (base + k), base + k, o, d, t_probe, b_probe);
+        violations += (!kept && b_probe >= 0) ? 1u : 0u;
+      }
+      for (int off = 32; off > 0; off >>= 1)
+        violations += (uint32_t)__shfl_xor((int)violations, off);
+      DIAG(12, violations);
       const uint32_t mine = (uint32_t)(__popc(cand_lo) + __popc(cand_hi));
       DIAG(2, wave_max_u32(mine)); /* wave-level phase-2 iterations */
       uint32_t tot = mine;
@@ -210,6 +239,7 @@ __device__ __forceinline__ void scan_spheres(const double *geom, uint32_t n_sph,
       DIAG(3, tot);                /* lane-level candidates */
     }
 #endif
+    /* ---- phase 2: exact intersect_sphere() on each lane's own candidates ---- */
     while (cand_lo | cand_hi)
     {
       /* lowest set bit of the 64-bit mask, branch-free */
@@ -220,26 +250,7 @@ __device__ __forceinline__ void scan_spheres(const double *geom, uint32_t n_sph,
       cand_lo = in_lo ? cleared : 0u;
       cand_hi = in_lo ? cand_hi : cleared;
       const uint32_t i = base + k;
-      const double *g = geom + PT_GEOM_STRIDE * i;
-      V3 Lv = {g[0] - o.x, g[1] - o.y, g[2] - o.z};
-      double tca = v_dot(Lv, d);
-      double d2 = v_dot(Lv, Lv) - tca * tca;
-      double r2 = g[3];
-      if (!(tca < 0) && !(d2 > r2))
-      {
-        DIAG(4, 1);
-        DIAG_LANES(5);
-        double thc = sqrt(r2 - d2);
-        /* t0 <= t1 always (thc >= 0 or NaN): the reference's swap (:95-100) is dead code */
-        double t0 = tca - thc, t1 = tca + thc;
-        if (t0 < 0)
-          t0 = t1;
-        if (t0 > kEps && t0 < min_t)
-        {
-          min_t = t0;
-          best = (int)i;
-        }
-      }
+      exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
     }
   }
 }
@@ -248,7 +259,9 @@ __device__ __forceinline__ void scan_spheres(const double *geom, uint32_t n_sph,
 
 struct SceneCtx
 {
-  const double *geom;     /* n_sph x PT_GEOM_STRIDE */
+  const double *geom;     /* n_sph x PT_GEOM_STRIDE: cx cy cz r2 (fp64, exact tests and normals) */
+  const f32x2 *filt;      /* ceil(n_sph/2) x PT_FILT_STRIDE packed-fp32 pairs for the phase-1 filter */
+  double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
   const double *mat;      /* (n_sph + n_meshes) x PT_MAT_STRIDE */
   const double *tri;      /* n_tri x 9: LDS copy, or the HBM array when it does not fit */
   const double *tri_normal;
@@ -266,6 +279,8 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   double *geom = lds;
   double *mat = geom + PT_GEOM_STRIDE * (size_t)n_sph;
   double *tri = mat + PT_MAT_STRIDE * (size_t)n_mat;
+  const uint32_t n_pairs = (n_sph + 1u) >> 1;
+  f32x2 *filt = reinterpret_cast<f32x2 *>(tri + (tris_in_lds ? 9 * (size_t)n_tri : 0));
   for (uint32_t i = threadIdx.x; i < n_sph; i += PT_BLOCK)
   {
     const double *src = sc.sphere_geom + PT_GEOM_SRC_STRIDE * i; /* cx cy cz r2 |c| */
@@ -274,13 +289,36 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
     g[1] = src[1];
     g[2] = src[2];
     g[3] = src[3];
-    /* Phase-1 tolerances.  With u = 2^-53, |L| <= |c| + |o| <= reach := |c| + bound_R and
-     * |d| <= 1.0001:  |tca_fused - tca_ref| <= 6.2 u reach,  |d2_fused - d2_ref| <= 23 u reach^2
-     * (each dot product carries <= 3 roundings of terms bounded by |L||d|).  Both are
-     * widened 16x; a false candidate costs a little time, a false reject would be an error. */
-    const double reach = src[4] + L.bound_R;
-    g[4] = src[3] + (16.0 * 23.0 * 1.1102230246251565e-16) * reach * reach;
-    g[5] = -(16.0 * 6.2 * 1.1102230246251565e-16) * reach;
+  }
+  /* Phase-1 filter table, packed fp32, per sphere pair: cx cy cz r2_hi neg_tol.
+   * Bound (e = 2^-24, fp32 unit roundoff; a = |c| + |o| <= A := |c| + near_R; |d| <= 1.0001):
+   *   c, o, d are rounded to fp32 (relative e each), L = c - o adds one rounding, so
+   *   |L32 - L| <= 2.01 e a per component; each 3-term fused dot product adds <= 3 e of
+   *   its magnitude.  Hence  |tca32 - tca| <= 6.2 e A   and   |d2_32 - d2| <= 20.5 e A^2,
+   *   where tca, d2 are the real-number values; the reference's own fp64 rounding of them
+   *   (~1e-16 relative) is absorbed by the 1.5x slack below.
+   *   drop  <=>  tca32 < -(10 e A)  or  d2_32 > r^2 + 32 e A^2      (never a false drop)
+   * Thresholds are rounded away from the accept region when stored as fp32. */
+  for (uint32_t i = threadIdx.x; i < 2u * n_pairs; i += PT_BLOCK)
+  {
+    float *f = reinterpret_cast<float *>(filt + PT_FILT_STRIDE * (i >> 1)) + (i & 1u);
+    if (i < n_sph)
+    {
+      const double *src = sc.sphere_geom + PT_GEOM_SRC_STRIDE * i;
+      const double e = 5.9604644775390625e-08; /* 2^-24 */
+      const double A = src[4] + L.near_R;
+      f[0] = (float)src[0];
+      f[2] = (float)src[1];
+      f[4] = (float)src[2];
+      f[6] = (float)((src[3] + 32.0 * e * A * A) * (1.0 + 4.0 * e));
+      f[8] = -(float)((10.0 * e * A) * (1.0 + 4.0 * e));
+    }
+    else
+    { /* padding slot of an odd count: masked out by valid_lo / valid_hi */
+      f[0] = f[2] = f[4] = 0.f;
+      f[6] = -1.f;
+      f[8] = 0.f;
+    }
   }
   for (uint32_t k = threadIdx.x; k < PT_MAT_STRIDE * n_mat; k += PT_BLOCK)
     mat[k] = sc.material[k];
@@ -289,6 +327,8 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
       tri[k] = sc.tri_geom[k];
   SceneCtx ctx;
   ctx.geom = geom;
+  ctx.filt = filt;
+  ctx.near_R2 = L.near_R * L.near_R;
   ctx.mat = mat;
   ctx.tri = tris_in_lds ? tri : sc.tri_geom;
   ctx.tri_normal = sc.tri_normal;
@@ -360,7 +400,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
     /* ---- intersect(): closest hit, strict <, index order (:393-464) ---- */
     double min_t = 1.7976931348623157e308; /* DBL_MAX */
     int best = -1;
-    scan_spheres<VARIANT>(S.geom, S.n_sph, o, d, min_t, best, diag_ptr);
+    scan_spheres<VARIANT>(S.geom, S.filt, S.near_R2, S.n_sph, o, d, min_t, best, diag_ptr);
     double bary_u = 0, bary_v = 0;
     for (uint32_t i = 0; i < S.n_tri; i++)
     {
@@ -770,6 +810,7 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
   size_t doubles = PT_GEOM_STRIDE * (size_t)sc.n_spheres + PT_MAT_STRIDE * (size_t)(sc.n_spheres + sc.n_meshes);
   if (sc.n_triangles <= PT_MAX_LDS_TRIS)
     doubles += 9 * (size_t)sc.n_triangles;
+  doubles += PT_FILT_STRIDE * (size_t)((sc.n_spheres + 1) / 2); /* f32x2 = one double-sized slot */
   return doubles * sizeof(double);
 }
 

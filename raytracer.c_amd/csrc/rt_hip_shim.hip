@@ -29,7 +29,7 @@ struct RtHipScene
   int device = 0;
   PtSceneView view{};
   void *blob = nullptr; /* one device allocation holding every array */
-  double reach = 0;     /* >= |p| for every point p on any primitive (bounds bounce origins) */
+  double reach = 0;     /* >= |p| for every point p on a primitive of ordinary size (radius < 1000) */
   double max_emission = 0; /* max |emission component| over all materials */
 };
 
@@ -186,7 +186,7 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   if (n_spheres + n_meshes > 0xFFFFFFu || n_tri > 0x7FFFFFFFu - n_spheres)
     return fail(RT_HIP_ELIMIT, "scene too large");
   const size_t n_mat = n_spheres + n_meshes;
-  if ((PT_GEOM_STRIDE * n_spheres + PT_MAT_STRIDE * n_mat) * sizeof(double) > 150 * 1024)
+  if ((PT_GEOM_STRIDE * n_spheres + PT_FILT_STRIDE * ((n_spheres + 1) / 2) + PT_MAT_STRIDE * n_mat) * sizeof(double) > 150 * 1024)
     return fail(RT_HIP_ELIMIT, "%zu spheres + %zu meshes do not fit the LDS staging area", n_spheres, n_meshes);
 
   /* ---- build the kernel layout on the host (pt_device.h) ---- */
@@ -207,7 +207,8 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
     g[3] = spheres[i].radius * spheres[i].radius; /* raytracer.c:87 */
     /* |c|, rounded up: feeds the conservative phase-1 thresholds only, never a result */
     g[4] = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) * (1.0 + 1e-12);
-    reach = std::fmax(reach, g[4] + std::fabs(spheres[i].radius));
+    if (std::fabs(spheres[i].radius) < 1000.0) /* wall-sized spheres would only loosen the filter */
+      reach = std::fmax(reach, g[4] + std::fabs(spheres[i].radius));
     put_material(&mat[PT_MAT_STRIDE * i], spheres[i].flags, spheres[i].color, spheres[i].emission);
   }
   size_t t = 0;
@@ -350,12 +351,15 @@ int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, cons
   L.max_depth = params->max_depth;
   L.seed = params->seed;
   {
-    /* every ray origin is the camera position or a point on a primitive */
+    /* Ray origins are the camera or points on primitives.  The packed-fp32 filter of
+     * scan_spheres is built for origins within near_R; a ray starting farther out (e.g. on
+     * the far side of a radius-1e4 "wall" sphere) is still traced exactly, it just skips
+     * the filter.  near_R only trades filter tightness against that fallback. */
     const double *c = camera->position;
     const double cam = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-    L.bound_R = std::fmax(scene->reach, cam) * 1.0001 + 1e-9;
-    if (!(L.bound_R < 1e150))
-      return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.bound_R);
+    L.near_R = 1.5 * (cam + scene->reach) + 1.0;
+    if (!(L.near_R < 1e15))
+      return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.near_R);
   }
   {
     /* Fixed-point scale of the per-pixel sums (pt_render_tiles): a sample's radiance is

@@ -18,9 +18,10 @@ st = stats.cpu().tolist()
 rays, casts = st[0], st[1]
 d = st[4:]
 names = ["loop iters (wave)", "loop lanes", "phase2 iters (wave)", "phase2 cands (lane)", "sqrt blocks (wave)", "sqrt lanes",
-         "fresh blocks (wave)", "fresh lanes", "hit blocks (wave)", "hit lanes", "reject-loop iters (wave)", "reject-loop lanes"]
+         "fresh blocks (wave)", "fresh lanes", "hit blocks (wave)", "hit lanes", "reject-loop iters (wave)", "reject-loop lanes", "FILTER VIOLATIONS (must be 0)"]
 for n, v in zip(names, d):
     print(f"{n:28s} {v:15d}")
+assert d[12] == 0, 'the conservative filter dropped a sphere the exact test accepts'
 it = d[0]
 print(f"rays {rays}  casts {casts}  rays/(64*iters) = lane occupancy of the loop: {rays / (64.0 * it):.3f}")
 print(f"phase-2 iterations per loop iteration: {d[2] / it:.2f}; candidates per ray: {d[3] / casts:.2f}; "
