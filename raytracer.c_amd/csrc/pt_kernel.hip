@@ -561,7 +561,14 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 
 /* ---- shipped kernel: pooled samples, fixed-point pixel sums ------------------------------ */
 
-extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles(const PtLaunch L)
+/* PT_MIN_WAVES: waves per SIMD the register allocator must leave room for.  Measured on
+ * config 4 (ms per 1080p x 128 spp frame): 3 waves 56.2, 4: 49.8, 5: 48.0, 6: 47.2, 7: 48.1,
+ * 8: 54.1 -- the loop is VALU-issue bound and wants latency cover more than it minds the
+ * few spilled registers (232 B/lane of scratch at 6). */
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 6
+#endif
+extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void pt_render_tiles(const PtLaunch L)
 {
   extern __shared__ double lds[];
   __shared__ float out_f[PT_TILE_PIXELS * 3];

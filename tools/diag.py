@@ -26,7 +26,7 @@ it = d[0]
 print(f"rays {rays}  casts {casts}  rays/(64*iters) = lane occupancy of the loop: {rays / (64.0 * it):.3f}")
 print(f"phase-2 iterations per loop iteration: {d[2] / it:.2f}; candidates per ray: {d[3] / casts:.2f}; "
       f"phase-2 lane occupancy {d[3] / (64.0 * d[2]):.3f}")
-print(f"sqrt blocks per loop iter {d[4] / it:.2f}, lanes/64 {d[5] / (64.0 * d[4]):.3f}")
+
 print(f"fresh per iter {d[6] / it:.3f} lanes/64 {d[7] / (64.0 * max(d[6], 1)):.3f}")
 print(f"hit per iter {d[8] / it:.3f} lanes/64 {d[9] / (64.0 * max(d[8], 1)):.3f}")
 print(f"reject iters per loop iter {d[10] / it:.2f} lanes/64 {d[11] / (64.0 * max(d[10], 1)):.3f}")
