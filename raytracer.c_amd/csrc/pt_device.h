@@ -37,6 +37,8 @@
 #define PT_MAX_LDS_SPHERES 1024
 #define PT_MAX_LDS_TRIS 1024 /* triangles staged in LDS in one piece */
 
+#define PT_REFRACT_MAX_DEPTH 32 /* pending-ray stack of pt_render_tiles_refract holds max_depth + 2 */
+
 #define PT_FLAG_DIFFUSE 2u
 #define PT_FLAG_MIRROR 4u
 #define PT_FLAG_REFRACT 8u
@@ -51,6 +53,7 @@ struct PtSceneView
   const double *tri_tex;
   const uint32_t *tri_object;
   uint32_t n_spheres, n_meshes, n_triangles, any_checker;
+  uint32_t any_refract, reserved_;
 };
 
 struct PtCamera

@@ -351,6 +351,16 @@ struct Path
   int depth;
 };
 
+/* Deferred second child of an M_REFRACTION hit (raytracer.c:523-529 traces two children per
+ * hit, the "refracted" one completely first): depth-first order = a LIFO of pending rays.
+ * At most one entry is pushed per depth level, so max_depth + 1 slots suffice. */
+struct PendingRay
+{
+  V3 o, d, T;
+  int depth;
+};
+#define PT_REFRACT_STACK 34 /* supports max_depth <= 32 for scenes with M_REFRACTION */
+
 struct CameraRegs
 {
   V3 pos, horizontal, vertical, llc;
@@ -386,9 +396,9 @@ __device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uin
 
 /* ---- one trace_path() call (raytracer.c:482-554).  Returns true when the path ended; P.Ls
  * then holds the finished sample's radiance. -------------------------------------------- */
-template <int VARIANT>
+template <int VARIANT, bool REFRACT>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
-                                           unsigned long long *diag_ptr)
+                                           unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
 {
   V3 add = {kBg, kBg, kBg}; /* what this call contributes if the path ends here */
   bool path_ends = true;
@@ -488,7 +498,38 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         }
         V3 nd;
         double weight = 1.0;
-        if (flags & PT_FLAG_MIRROR)
+        bool split = false;
+        if (REFRACT && (flags & PT_FLAG_REFRACT))
+        {
+          /* :514-529.  fresnel = mix(pow(1 - facing, 3), 1, 0.1); refract() with the
+           * CLAMP_BETWEEN quirk (raytracer.h:30: cosi == 1 always) and iot = 1:
+           *   eta = 1, k = 1 - eta*eta*(1 - cosi*cosi) = 1, n' = -N,
+           *   refract(I) = I*eta + n'*(eta*cosi - sqrtf(k)) = I*1 + (-N)*0      (:354-373)
+           * i.e. child A goes back along the incoming ray; child B is the mirror direction.
+           * Both are normalised (:523, :526).  B waits on the stack with its share kr. */
+          const double facing = -v_dot(d, n);
+          const double fresnel = 1 * 0.1 + pow(1 - facing, 3.0) * (1 - 0.1);
+          const double kr = fresnel, kt = (1 - fresnel) * 1.0;
+          const V3 in = v_scale(d, -1);
+          const V3 nn = v_scale(n, -1);
+          const double coef = 1.0 * 1.0 - (double)sqrtf(1.0f);
+          const V3 refr = v_add(v_scale(in, 1.0), v_scale(nn, coef));
+          nd = v_normalize(refr);
+          const V3 refl = v_normalize(v_sub(v_scale(d, 1), v_scale(n, 2 * v_dot(v_scale(d, 1), n))));
+          const V3 base = v_mul(P.T, albedo);
+          if (stack_n < PT_REFRACT_STACK)
+          {
+            PendingRay &slot = stack[stack_n++];
+            slot.o = p;
+            slot.d = refl;
+            slot.T = v_scale(base, kr);
+            slot.depth = P.depth + 1;
+          }
+          P.Ls = v_add(P.Ls, v_mul(P.T, emission));
+          P.T = v_scale(base, kt);
+          split = true;
+        }
+        else if (flags & PT_FLAG_MIRROR)
         {
           /* reflect :349-352; direction left un-normalised (:542) */
           nd = v_sub(d, v_scale(n, 2 * v_dot(d, n)));
@@ -519,8 +560,11 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           weight = v_dot(nd, n); /* cos_theta :549 */
         }
         /* L = e + albedo (.) (L_next * cos)  ==>  forward form */
-        P.Ls = v_add(P.Ls, v_mul(P.T, emission));
-        P.T = v_mul(P.T, (flags & PT_FLAG_MIRROR) ? albedo : v_scale(albedo, weight));
+        if (!split)
+        {
+          P.Ls = v_add(P.Ls, v_mul(P.T, emission));
+          P.T = v_mul(P.T, (flags & PT_FLAG_MIRROR) ? albedo : v_scale(albedo, weight));
+        }
         P.o = p;
         P.d = nd;
         P.depth++;
@@ -528,7 +572,20 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
     }
   }
   if (path_ends)
+  {
     P.Ls = v_add(P.Ls, v_mul(P.T, add));
+    if (REFRACT && stack_n > 0)
+    {
+      /* this branch of the tree is done: resume the most recent pending child; the RNG
+       * stream simply continues, as it does across the reference's two recursive calls */
+      const PendingRay &slot = stack[--stack_n];
+      P.o = slot.o;
+      P.d = slot.d;
+      P.T = slot.T;
+      P.depth = slot.depth;
+      path_ends = false;
+    }
+  }
   return path_ends;
 }
 
@@ -568,7 +625,8 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 6
 #endif
-extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void pt_render_tiles(const PtLaunch L)
+template <bool REFRACT>
+__device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 {
   extern __shared__ double lds[];
   __shared__ float out_f[PT_TILE_PIXELS * 3];
@@ -606,6 +664,8 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void pt_render_t
   uint32_t next_job = 0;     /* wave-uniform */
   uint32_t pix_slot = 0;     /* 0..63 inside the tile */
   bool busy = false;
+  PendingRay stack[REFRACT ? PT_REFRACT_STACK : 1];
+  int stack_n = 0;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
 
@@ -649,7 +709,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void pt_render_t
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      if (trace_step<1>(S, P, n_casts, diag_ptr))
+      if (trace_step<1, REFRACT>(S, P, n_casts, diag_ptr, stack, stack_n))
       {
         /* sample done: add to the pixel's fixed-point sum (integer adds commute: the
          * result does not depend on which lane finishes first) */
@@ -690,6 +750,18 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void pt_render_t
   store_tile(L, out_f, out_b, wg_stats, tile, S.n_sph + S.n_tri);
 }
 
+extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void pt_render_tiles(const PtLaunch L)
+{
+  render_tiles_pooled<false>(L);
+}
+
+/* Same kernel for scenes with M_REFRACTION materials: carries the per-lane stack of pending
+ * second children (private memory; touched only at refractive hits). */
+extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_refract(const PtLaunch L)
+{
+  render_tiles_pooled<true>(L);
+}
+
 /* ---- plain kernel: static (pixel, slice) lanes, literal scan, fp64 sums ------------------
  * Selected by RT_HIP_KERNEL_VARIANT=0.  Lane l of wave w: pixel (l >> 2) of the wave's 16,
  * sample slice (l & 3): samples s = slice, slice + 4, ... */
@@ -727,6 +799,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
   uint32_t n_rays = 0, n_casts = 0;
   uint32_t s = inside ? slice : spp;
   bool fresh = true;
+  int no_stack = 0;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
 
@@ -742,7 +815,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
       fresh = false;
     }
     n_rays++;
-    if (trace_step<0>(S, P, n_casts, diag_ptr))
+    if (trace_step<0, false>(S, P, n_casts, diag_ptr, nullptr, no_stack))
     {
       acc = v_add(acc, P.Ls);
       s += PT_SLICES;
@@ -824,9 +897,10 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
 hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant)
 {
   const size_t lds_bytes = pt_render_lds_bytes(launch.scene);
-  auto kernel = variant == 0 ? pt_render_tiles_v0 : pt_render_tiles;
-  static size_t lds_allowed[2] = {0, 0}; /* raised once per process if a scene needs > 64 KiB */
-  size_t &allowed = lds_allowed[variant == 0 ? 0 : 1];
+  auto kernel = launch.scene.any_refract ? pt_render_tiles_refract
+                                         : (variant == 0 ? pt_render_tiles_v0 : pt_render_tiles);
+  static size_t lds_allowed[3] = {0, 0, 0}; /* raised once per process if a scene needs > 64 KiB */
+  size_t &allowed = lds_allowed[launch.scene.any_refract ? 2 : (variant == 0 ? 0 : 1)];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),

@@ -166,18 +166,15 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
     return fail(RT_HIP_ENODEV, "no HIP device %d (found %d)", device, usable_devices());
 
   size_t n_tri = 0;
-  bool any_checker = false;
+  bool any_checker = false, any_refract = false;
   for (size_t i = 0; i < n_spheres; i++)
   {
-    if (spheres[i].flags & PT_FLAG_REFRACT)
-      return fail(RT_HIP_ELIMIT, "sphere %zu is M_REFRACTION: the two-child refraction tree "
-                                 "(raytracer.c:514-529) is not implemented on the device yet", i);
+    any_refract |= (spheres[i].flags & PT_FLAG_REFRACT) != 0;
     any_checker |= (spheres[i].flags & PT_FLAG_CHECKER) != 0;
   }
   for (size_t m = 0; m < n_meshes; m++)
   {
-    if (meshes[m].flags & PT_FLAG_REFRACT)
-      return fail(RT_HIP_ELIMIT, "mesh %zu is M_REFRACTION: not implemented on the device yet", m);
+    any_refract |= (meshes[m].flags & PT_FLAG_REFRACT) != 0;
     if (meshes[m].num_triangles && !meshes[m].vertices)
       return fail(RT_HIP_EINVAL, "mesh %zu has triangles but no vertices", m);
     any_checker |= (meshes[m].flags & PT_FLAG_CHECKER) != 0;
@@ -294,6 +291,7 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   sc->view.n_meshes = (uint32_t)n_meshes;
   sc->view.n_triangles = (uint32_t)n_tri;
   sc->view.any_checker = any_checker ? 1u : 0u;
+  sc->view.any_refract = any_refract ? 1u : 0u;
   sc->reach = reach;
   sc->max_emission = max_emission;
   *out_scene = sc;
@@ -327,6 +325,10 @@ int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, cons
   int rc = check_params(params);
   if (rc)
     return rc;
+  if (scene->view.any_refract && params->max_depth > PT_REFRACT_MAX_DEPTH)
+    return fail(RT_HIP_ELIMIT, "scenes with M_REFRACTION materials support max_depth <= %d (two rays per "
+                               "refractive hit, raytracer.c:523-529; the pending-ray stack is fixed)",
+                PT_REFRACT_MAX_DEPTH);
   const uint32_t tx = tiles_x_of(params->width), ty = tiles_y_of(params->height);
   const uint64_t n_tiles = (uint64_t)tx * ty;
   if (params->tile_count == 0)

@@ -16,7 +16,7 @@ Files
                    refract / checker values, camera frames for 4 aspect ratios, camera
                    rays, the reference's own test.c vectors, RNG stream heads
   frames.npz       linear fp64 means + tonemapped bytes + ray/test counts:
-                   config 1 whole frame at 64x64; tiles of configs 1, 2, 4 at full size
+                   config 1 whole frame at 64x64; a 96x64 'glass' frame (refraction, checker); tiles of configs 1, 2, 4 at full size
   samples.npz      per-(pixel, sample) traces: radiance, rays, tests, draws
 """
 import os
@@ -33,7 +33,7 @@ os.environ.setdefault("OMP_NUM_THREADS", "1")
 
 import oracle_py  # noqa: E402
 from rt_amd import scene as S  # noqa: E402
-from util import tile_pixels  # noqa: E402
+from util import glass_scene, tile_pixels  # noqa: E402
 
 SEED = 1666943821
 
@@ -191,6 +191,11 @@ def frames():
     ref = oracle_py.RefOracle(sc.max_depth)
     mean, rgb8, st = ref.render_pixels(sc, SEED)
     out.update(c1_64_mean=mean, c1_64_rgb8=rgb8, c1_64_stats=np.array([st["rays"], st["tests"]]))
+    # every material branch incl. the two-child refraction tree and the checker texture
+    sc = glass_scene()
+    ref = oracle_py.RefOracle(sc.max_depth)
+    mean, rgb8, st = ref.render_pixels(sc, SEED)
+    out.update(glass_mean=mean, glass_rgb8=rgb8, glass_stats=np.array([st["rays"], st["tests"]]))
     # tiles at full size
     rng = np.random.default_rng(4)
     for cfg, ntiles, spp in [(1, 32, None), (2, 16, None), (4, 8, 64), (4, 8, 1024)]:

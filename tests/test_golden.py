@@ -116,3 +116,15 @@ def test_sample_traces(pt, samples, cfg):
         c, got = pt.trace_sample(sc, int(x), int(y), int(s), SEED)
         assert np.array_equal(c, rgb)
         assert [got["rays"], got["tests"], got["draws"]] == st.tolist()
+
+
+def test_glass_frame_refraction_and_checker(pt, frames):
+    """M_REFRACTION (two recursive children per hit, with the CLAMP_BETWEEN quirk) and
+    M_CHECKERED, as rendered by the compiled reference"""
+    from util import glass_scene
+    sc = glass_scene()
+    mean, rgb8, st = pt.render_pixels(sc, SEED)
+    assert np.array_equal(mean, frames["glass_mean"])
+    assert np.array_equal(rgb8, frames["glass_rgb8"])
+    assert [st["rays"], st["tests"]] == frames["glass_stats"].tolist()
+    assert st["rays"] > 1.5 * sc.width * sc.height * sc.samples

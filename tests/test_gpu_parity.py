@@ -215,3 +215,25 @@ def test_render_image_c_host_entry(gpu, pt):
     mean, rgb8, ost = pt.render_pixels(sc, SEED)
     assert_parity(img, img8, st, mean, rgb8, ost, what="rt_hip_render_image")
     assert secs > 0
+
+
+def test_golden_glass_frame(gpu):
+    """device refraction tree (pending-ray stack) + checker texture vs the compiled reference"""
+    from util import glass_scene
+    fr = np.load(GOLD + "/frames.npz", allow_pickle=False)
+    sc = glass_scene()
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(SEED)
+    ost = dict(rays=int(fr["glass_stats"][0]), tests=int(fr["glass_stats"][1]))
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, fr["glass_mean"], fr["glass_rgb8"], ost, what="glass")
+    gs.close()
+
+
+def test_refraction_depth_limit_is_reported(gpu):
+    from rt_amd import gpu as G
+    from util import glass_scene
+    sc = glass_scene(32, 32, 1, max_depth=40)
+    gs = gpu.GpuScene(sc)
+    with pytest.raises(G.ShimError, match="max_depth <= 32"):
+        gs.render_image(SEED)
+    gs.close()

@@ -57,3 +57,18 @@ def untile_numpy(tiles, width, height, first, stride, count, image):
         w = min(8, width - x0)
         image[y0:y0 + h, x0:x0 + w] = block[:h, :w]
     return image
+
+
+def glass_scene(width=96, height=64, samples=8, max_depth=5):
+    """a small scene exercising every material branch of trace_path(): diffuse, mirror, light,
+    M_REFRACTION (the reference's two-child 'glass', raytracer.c:514-529) and M_CHECKERED"""
+    from rt_amd import abi, scene as S
+    objs = [
+        dict(flags=abi.M_DEFAULT | abi.M_CHECKERED, radius=10000.0, center=(0, -10005.0, 0), color=(0.8, 0.8, 0.8)),
+        dict(flags=abi.M_DEFAULT, radius=4.0, center=(-11, -1, -2), color=(0.75, 0.25, 0.25)),
+        dict(flags=abi.M_REFRACTION, radius=5.0, center=(0, 0, 0), color=(0.95, 0.95, 0.95)),
+        dict(flags=abi.M_REFLECTION, radius=4.0, center=(11, -1, -3), color=(1, 1, 1)),
+        dict(flags=abi.M_REFRACTION | abi.M_CHECKERED, radius=2.5, center=(5, -2.5, 8), color=(0.6, 0.9, 0.7)),
+        dict(flags=abi.M_DEFAULT, radius=6.0, center=(-4, 18, 6), color=(1, 1, 1), emission=(5, 5, 5)),
+    ]
+    return S.custom_scene(objs, width, height, samples, max_depth, (0, 6, 38), (0, 0, 0))
