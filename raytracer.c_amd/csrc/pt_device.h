@@ -1,25 +1,29 @@
 /* pt_device.h -- device-side data layout shared by the kernels and the shim.
  *
- * HBM layout of a scene (RtHipScene), all fp64, built once by
- * rt_hip_scene_create() and read-only afterwards:
+ * HBM layout of a scene (RtHipScene), built once by rt_hip_scene_create() as one blob:
  *
- *   sphere_geom [n_spheres] x 5 doubles : cx, cy, cz, radius*radius, |c| (upper bound)
- *       what the scan of intersect() touches per test (32 B, one ds_read_b128
- *       pair once staged in LDS).  radius*radius is the product the reference
- *       forms per test (raytracer.c:87); forming it once is the same double.
- *   material    [n_spheres + n_meshes] x 8 doubles :
- *       prob, albedo_rr xyz, emission xyz, flags (as a double-sized slot)
+ *   entry_src  [n_spheres + n_triangles] x 6 f64 : cx, cy, cz, R2, |c|, Rb   (scan order)
+ *       sphere  : centre, radius*radius (the product raytracer.c:87 forms per test; forming
+ *                 it once is the same double), |centre|, 0
+ *       triangle: centre / squared radius / radius of a bounding sphere (filter only)
+ *       The first four doubles of the sphere records are what the exact test and the
+ *       normal use; they are staged in LDS per workgroup.
+ *   filt       [ceil(entries/2)] x 5 f32x2       : cx cy cz r2_hi neg_tol, two primitives per
+ *       f32x2 -- the packed-fp32 phase-1 filter table, rebuilt per launch (pt_build_filter)
+ *       because its thresholds depend on the camera distance; read with wave-uniform
+ *       indices, i.e. through scalar loads.
+ *   material   [n_spheres + n_meshes] x 8 f64    : prob, albedo_rr xyz, emission xyz, flags
  *       prob      = MAX(color) (raytracer.c:497)
- *       albedo_rr = color * (1/prob), the albedo after a survived Russian
- *                   roulette (:500); same operands, same two operations as the
- *                   reference performs per bounce, so the same doubles.
- *   tri_geom    [n_triangles] x 9 doubles : v0, edge1 = v1-v0, edge2 = v2-v0
+ *       albedo_rr = color * (1/prob), the albedo after a survived Russian roulette (:500);
+ *                   same operands, same two operations as the reference performs per
+ *                   bounce, so the same doubles.
+ *   tri_geom   [n_triangles] x 9 f64 : v0, edge1 = v1-v0, edge2 = v2-v0
  *       (raytracer.c:132-133 forms the edges per test; precomputed = same).
- *   tri_normal  [n_triangles] x 3 doubles : calculate_surface_normal(v0,v1,v2)
+ *   tri_normal [n_triangles] x 3 f64 : calculate_surface_normal(v0,v1,v2)
  *       (raytracer.c:42-45), read only for the winning triangle.
- *   tri_tex     [n_triangles] x 6 doubles : st0, st1, st2 (read only for a
- *       winning triangle of an M_CHECKERED mesh).
- *   tri_object  [n_triangles] uint32     : material slot of the owning mesh.
+ *   tri_tex    [n_triangles] x 6 f64 : st0, st1, st2 (read only for a winning triangle of an
+ *       M_CHECKERED mesh).
+ *   tri_object [n_triangles] u32     : material slot of the owning mesh.
  */
 #ifndef PT_DEVICE_H
 #define PT_DEVICE_H
@@ -31,11 +35,11 @@
 #define PT_SLICES 4         /* sample slices per pixel inside one wavefront */
 #define PT_BLOCK 256        /* 4 wavefronts: 64 pixels x 4 slices */
 #define PT_MAT_STRIDE 8     /* doubles per material record */
+#define PT_FILT_LDS_MAX 256  /* primitives up to which the filter table is also staged in LDS */
 #define PT_GEOM_STRIDE 4     /* LDS doubles per sphere: cx cy cz r2 */
-#define PT_FILT_STRIDE 5     /* LDS f32x2 per sphere PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
-#define PT_GEOM_SRC_STRIDE 5 /* HBM doubles per sphere: cx cy cz r2 |c| */
+#define PT_FILT_STRIDE 5     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
+#define PT_ENTRY_SRC_STRIDE 6 /* HBM doubles per primitive: cx cy cz R2 |c| Rb (bounding data, fp64) */
 #define PT_MAX_LDS_SPHERES 1024
-#define PT_MAX_LDS_TRIS 1024 /* triangles staged in LDS in one piece */
 
 #define PT_REFRACT_MAX_DEPTH 32 /* pending-ray stack of pt_render_tiles_refract holds max_depth + 2 */
 
@@ -46,7 +50,8 @@
 
 struct PtSceneView
 {
-  const double *sphere_geom;
+  const double *entry_src; /* n_spheres + n_triangles bounding records, scan order */
+  float *filt;             /* packed-fp32 filter table, rebuilt per launch by pt_build_filter */
   const double *material;
   const double *tri_geom;
   const double *tri_normal;

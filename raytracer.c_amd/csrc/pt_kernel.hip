@@ -170,62 +170,119 @@ __device__ __forceinline__ void exact_sphere(const double *g, uint32_t index, co
   }
 }
 
-template <int VARIANT>
-__device__ __forceinline__ void scan_spheres(const double *geom, const f32x2 *filt, double near_R2,
-                                             uint32_t n_sph, const V3 &o, const V3 &d, double &min_t, int &best,
-                                             unsigned long long *diag_ptr)
+/* intersect_triangle :132-150 (Moeller-Trumbore, two-sided), exact.  g = v0, e1, e2. */
+__device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, const V3 &o, const V3 &d,
+                                               double &min_t, int &best, double &bary_u, double &bary_v)
 {
-  if (VARIANT == 0)
+  V3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
+  V3 h = v_cross(d, e2);
+  double a = v_dot(e1, h);
+  if (!(a > -kEps && a < kEps))
   {
-    for (uint32_t i = 0; i < n_sph; i++)
-      exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
-    return;
+    double f = 1.0 / a;
+    V3 sv = v_sub(o, v0);
+    double u = f * v_dot(sv, h);
+    if (!(u < 0.0 || u > 1.0))
+    {
+      V3 q = v_cross(sv, e1);
+      double v = f * v_dot(d, q);
+      if (!(v < 0.0 || u + v > 1.0))
+      {
+        double t = f * v_dot(e2, q);
+        if (t > kEps && t < min_t)
+        {
+          min_t = t;
+          best = (int)index;
+          bary_u = u;
+          bary_v = v;
+        }
+      }
+    }
   }
+}
 
+struct SceneCtx;
+
+/* VARIANT 1 scan over ALL primitives.  The filter table has one entry per primitive in
+ * scan order (spheres, then triangles): a sphere is its own bound; a triangle is bounded by
+ * a sphere around its centroid (a ray that hits the triangle passes through that sphere,
+ * and the sphere's centre is at most its radius behind the origin, hence the entry's
+ * tca threshold -(R + tol)).  The table lives in HBM and is read with a wave-uniform index,
+ * i.e. by scalar loads through the constant cache into SGPRs: no LDS traffic, no VGPRs,
+ * and no size limit -- a 10k-triangle mesh streams through at 20 B per primitive. */
+template <bool TRIS>
+__device__ __forceinline__ void scan_filtered(const double *geom, const double *tri_geom,
+                                              const f32x2 *__restrict__ filt, double near_R2, uint32_t n_sph,
+                                              uint32_t n_entries, const V3 &o, const V3 &d, double &min_t,
+                                              int &best, double &bary_u, double &bary_v,
+                                              unsigned long long *diag_ptr)
+{
   /* the ray in fp32 (round to nearest: relative error <= 2^-24, part of the bound) */
   const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
   const f32x2 dx = {(float)d.x, (float)d.x}, dy = {(float)d.y, (float)d.y}, dz = {(float)d.z, (float)d.z};
   const bool far_origin = !(v_dot(o, o) <= near_R2); /* also true for NaN */
 
-  for (uint32_t base = 0; base < n_sph; base += 64)
+  for (uint32_t base = 0; base < n_entries; base += 64)
   {
-    const uint32_t chunk = min(64u, n_sph - base);
-    /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same sphere pair ---- */
+    const uint32_t chunk = min(64u, n_entries - base);
+    /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
     uint32_t cand_lo = 0, cand_hi = 0;
-    auto filter_pair = [&](uint32_t pair, uint32_t &word, uint32_t shift) {
-      const f32x2 *g = filt + PT_FILT_STRIDE * ((base >> 1) + pair);
-      const f32x2 lx = g[0] - ox, ly = g[1] - oy, lz = g[2] - oz;
+    struct PairRec
+    {
+      f32x2 cx, cy, cz, r2_hi, neg_tol;
+    };
+    auto load_pair = [&](uint32_t pair) -> PairRec {
+      const f32x2 *g = filt + PT_FILT_STRIDE * (size_t)((base >> 1) + pair);
+      return {g[0], g[1], g[2], g[3], g[4]};
+    };
+    auto filter_pair = [&](const PairRec &g, uint32_t &word, uint32_t shift) {
+      const f32x2 lx = g.cx - ox, ly = g.cy - oy, lz = g.cz - oz;
       const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
       const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, lx * lx));
       const f32x2 d2 = __builtin_elementwise_fma(-tca, tca, ll);
       /* bitwise |: no short-circuit branch.  NaNs compare false and stay candidates. */
-      const bool drop0 = (bool)((int)(tca.x < g[4].x) | (int)(d2.x > g[3].x));
-      const bool drop1 = (bool)((int)(tca.y < g[4].y) | (int)(d2.y > g[3].y));
+      const bool drop0 = (bool)((int)(tca.x < g.neg_tol.x) | (int)(d2.x > g.r2_hi.x));
+      const bool drop1 = (bool)((int)(tca.y < g.neg_tol.y) | (int)(d2.y > g.r2_hi.y));
       word |= (drop0 ? 0u : (1u << shift)) | (drop1 ? 0u : (2u << shift));
     };
     const uint32_t n_pairs = (chunk + 1u) >> 1;
+    /* software pipeline: the scalar loads of pair p+1 are in flight while pair p computes
+     * (the table is padded to a whole number of pairs, and one pair past the end) */
+    PairRec cur = load_pair(0);
     const uint32_t pairs_lo = min(n_pairs, 16u);
-#pragma unroll 4
+#pragma unroll 2
     for (uint32_t p = 0; p < pairs_lo; p++)
-      filter_pair(p, cand_lo, 2u * p);
-#pragma unroll 4
+    {
+      const PairRec nxt = load_pair(p + 1);
+      filter_pair(cur, cand_lo, 2u * p);
+      cur = nxt;
+    }
+#pragma unroll 2
     for (uint32_t p = 16; p < n_pairs; p++)
-      filter_pair(p, cand_hi, 2u * (p - 16u));
-    /* spheres that exist in this chunk (an odd count leaves one padding slot) */
+    {
+      const PairRec nxt = load_pair(p + 1);
+      filter_pair(cur, cand_hi, 2u * (p - 16u));
+      cur = nxt;
+    }
+    /* entries that exist in this chunk (an odd count leaves one padding slot) */
     const uint32_t valid_lo = chunk >= 32u ? 0xFFFFFFFFu : ((1u << chunk) - 1u);
     const uint32_t valid_hi = chunk >= 64u ? 0xFFFFFFFFu : (chunk > 32u ? ((1u << (chunk - 32u)) - 1u) : 0u);
     cand_lo = far_origin ? valid_lo : (cand_lo & valid_lo);
     cand_hi = far_origin ? valid_hi : (cand_hi & valid_hi);
 #ifdef PT_DIAG
     {
-      /* exactness check of the filter: any sphere it dropped that the exact test accepts? */
+      /* exactness check of the filter: any primitive it dropped that the exact test accepts? */
       uint32_t violations = 0;
       for (uint32_t k = 0; k < chunk; k++)
       {
         const bool kept = k < 32 ? ((cand_lo >> k) & 1u) : ((cand_hi >> (k - 32u)) & 1u);
-        double t_probe = 1.7976931348623157e308;
+        double t_probe = 1.7976931348623157e308, pu = 0, pv = 0;
         int b_probe = -1;
-        exact_sphere(geom + PT_GEOM_STRIDE * (base + k), base + k, o, d, t_probe, b_probe);
+        const uint32_t i = base + k;
+        if (!TRIS || i < n_sph)
+          exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, t_probe, b_probe);
+        else
+          exact_triangle(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, t_probe, b_probe, pu, pv);
         violations += (!kept && b_probe >= 0) ? 1u : 0u;
       }
       for (int off = 32; off > 0; off >>= 1)
@@ -239,7 +296,7 @@ __device__ __forceinline__ void scan_spheres(const double *geom, const f32x2 *fi
       DIAG(3, tot);                /* lane-level candidates */
     }
 #endif
-    /* ---- phase 2: exact intersect_sphere() on each lane's own candidates ---- */
+    /* ---- phase 2: the exact test on each lane's own candidates, in index order ---- */
     while (cand_lo | cand_hi)
     {
       /* lowest set bit of the 64-bit mask, branch-free */
@@ -250,7 +307,10 @@ __device__ __forceinline__ void scan_spheres(const double *geom, const f32x2 *fi
       cand_lo = in_lo ? cleared : 0u;
       cand_hi = in_lo ? cand_hi : cleared;
       const uint32_t i = base + k;
-      exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
+      if (!TRIS || i < n_sph)
+        exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
+      else
+        exact_triangle(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v);
     }
   }
 }
@@ -259,14 +319,15 @@ __device__ __forceinline__ void scan_spheres(const double *geom, const f32x2 *fi
 
 struct SceneCtx
 {
-  const double *geom;     /* n_sph x PT_GEOM_STRIDE: cx cy cz r2 (fp64, exact tests and normals) */
-  const f32x2 *filt;      /* ceil(n_sph/2) x PT_FILT_STRIDE packed-fp32 pairs for the phase-1 filter */
-  double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
-  const double *mat;      /* (n_sph + n_meshes) x PT_MAT_STRIDE */
-  const double *tri;      /* n_tri x 9: LDS copy, or the HBM array when it does not fit */
+  const double *geom;     /* LDS: n_sph x PT_GEOM_STRIDE: cx cy cz r2 (fp64, exact tests and normals) */
+  const double *mat;      /* LDS: (n_sph + n_meshes) x PT_MAT_STRIDE */
+  const double *tri;      /* HBM: n_tri x 9 (v0, e1, e2), gathered per lane in phase 2 */
   const double *tri_normal;
   const double *tri_tex;
   const uint32_t *tri_object;
+  const f32x2 *filt;      /* HBM: ceil(n_entries/2) x PT_FILT_STRIDE packed-fp32 filter pairs */
+  const f32x2 *filt_lds;  /* LDS copy of it when the scene is small (PT_FILT_LDS_MAX), else nullptr */
+  double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
   uint32_t n_sph, n_tri;
   int max_depth;
 };
@@ -274,68 +335,45 @@ struct SceneCtx
 __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
 {
   const PtSceneView &sc = L.scene;
-  const uint32_t n_sph = sc.n_spheres, n_mat = sc.n_spheres + sc.n_meshes, n_tri = sc.n_triangles;
-  const bool tris_in_lds = n_tri <= PT_MAX_LDS_TRIS;
+  const uint32_t n_sph = sc.n_spheres, n_mat = sc.n_spheres + sc.n_meshes;
   double *geom = lds;
   double *mat = geom + PT_GEOM_STRIDE * (size_t)n_sph;
-  double *tri = mat + PT_MAT_STRIDE * (size_t)n_mat;
-  const uint32_t n_pairs = (n_sph + 1u) >> 1;
-  f32x2 *filt = reinterpret_cast<f32x2 *>(tri + (tris_in_lds ? 9 * (size_t)n_tri : 0));
   for (uint32_t i = threadIdx.x; i < n_sph; i += PT_BLOCK)
   {
-    const double *src = sc.sphere_geom + PT_GEOM_SRC_STRIDE * i; /* cx cy cz r2 |c| */
+    const double *src = sc.entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz r2 |c| R */
     double *g = geom + PT_GEOM_STRIDE * i;
     g[0] = src[0];
     g[1] = src[1];
     g[2] = src[2];
     g[3] = src[3];
   }
-  /* Phase-1 filter table, packed fp32, per sphere pair: cx cy cz r2_hi neg_tol.
-   * Bound (e = 2^-24, fp32 unit roundoff; a = |c| + |o| <= A := |c| + near_R; |d| <= 1.0001):
-   *   c, o, d are rounded to fp32 (relative e each), L = c - o adds one rounding, so
-   *   |L32 - L| <= 2.01 e a per component; each 3-term fused dot product adds <= 3 e of
-   *   its magnitude.  Hence  |tca32 - tca| <= 6.2 e A   and   |d2_32 - d2| <= 20.5 e A^2,
-   *   where tca, d2 are the real-number values; the reference's own fp64 rounding of them
-   *   (~1e-16 relative) is absorbed by the 1.5x slack below.
-   *   drop  <=>  tca32 < -(10 e A)  or  d2_32 > r^2 + 32 e A^2      (never a false drop)
-   * Thresholds are rounded away from the accept region when stored as fp32. */
-  for (uint32_t i = threadIdx.x; i < 2u * n_pairs; i += PT_BLOCK)
-  {
-    float *f = reinterpret_cast<float *>(filt + PT_FILT_STRIDE * (i >> 1)) + (i & 1u);
-    if (i < n_sph)
-    {
-      const double *src = sc.sphere_geom + PT_GEOM_SRC_STRIDE * i;
-      const double e = 5.9604644775390625e-08; /* 2^-24 */
-      const double A = src[4] + L.near_R;
-      f[0] = (float)src[0];
-      f[2] = (float)src[1];
-      f[4] = (float)src[2];
-      f[6] = (float)((src[3] + 32.0 * e * A * A) * (1.0 + 4.0 * e));
-      f[8] = -(float)((10.0 * e * A) * (1.0 + 4.0 * e));
-    }
-    else
-    { /* padding slot of an odd count: masked out by valid_lo / valid_hi */
-      f[0] = f[2] = f[4] = 0.f;
-      f[6] = -1.f;
-      f[8] = 0.f;
-    }
-  }
   for (uint32_t k = threadIdx.x; k < PT_MAT_STRIDE * n_mat; k += PT_BLOCK)
     mat[k] = sc.material[k];
-  if (tris_in_lds)
-    for (uint32_t k = threadIdx.x; k < 9 * n_tri; k += PT_BLOCK)
-      tri[k] = sc.tri_geom[k];
+  /* Small scenes keep the filter table in LDS (measured 4 % faster than scalar loads on the
+   * 38-sphere room: ds_read is prefetched across pairs, s_load is not); large ones stream
+   * it through the constant cache. */
+  const uint32_t n_entries = n_sph + sc.n_triangles;
+  f32x2 *filt_lds = nullptr;
+  if (n_entries <= PT_FILT_LDS_MAX)
+  {
+    filt_lds = reinterpret_cast<f32x2 *>(mat + PT_MAT_STRIDE * (size_t)n_mat);
+    const uint32_t n_slots = PT_FILT_STRIDE * ((n_entries + 1u) / 2u + 1u); /* + the look-ahead pair */
+    const f32x2 *src = reinterpret_cast<const f32x2 *>(sc.filt);
+    for (uint32_t k = threadIdx.x; k < n_slots; k += PT_BLOCK)
+      filt_lds[k] = src[k];
+  }
   SceneCtx ctx;
   ctx.geom = geom;
-  ctx.filt = filt;
-  ctx.near_R2 = L.near_R * L.near_R;
   ctx.mat = mat;
-  ctx.tri = tris_in_lds ? tri : sc.tri_geom;
+  ctx.tri = sc.tri_geom;
   ctx.tri_normal = sc.tri_normal;
   ctx.tri_tex = sc.tri_tex;
   ctx.tri_object = sc.tri_object;
+  ctx.filt = reinterpret_cast<const f32x2 *>(sc.filt);
+  ctx.filt_lds = filt_lds;
+  ctx.near_R2 = L.near_R * L.near_R;
   ctx.n_sph = n_sph;
-  ctx.n_tri = n_tri;
+  ctx.n_tri = sc.n_triangles;
   ctx.max_depth = L.max_depth;
   return ctx;
 }
@@ -396,7 +434,9 @@ __device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uin
 
 /* ---- one trace_path() call (raytracer.c:482-554).  Returns true when the path ended; P.Ls
  * then holds the finished sample's radiance. -------------------------------------------- */
-template <int VARIANT, bool REFRACT>
+/* VARIANT: 0 literal scan / 1 filtered scan.  REFRACT: scene has M_REFRACTION materials.
+ * TRIS: scene has triangles.  FILT_LDS: the filter table is staged in LDS (small scenes). */
+template <int VARIANT, bool REFRACT, bool TRIS, bool FILT_LDS>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
                                            unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
 {
@@ -410,38 +450,18 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
     /* ---- intersect(): closest hit, strict <, index order (:393-464) ---- */
     double min_t = 1.7976931348623157e308; /* DBL_MAX */
     int best = -1;
-    scan_spheres<VARIANT>(S.geom, S.filt, S.near_R2, S.n_sph, o, d, min_t, best, diag_ptr);
     double bary_u = 0, bary_v = 0;
-    for (uint32_t i = 0; i < S.n_tri; i++)
+    if (VARIANT == 0)
     {
-      /* intersect_triangle :132-150 (Moeller-Trumbore, two-sided) */
-      const double *g = S.tri + 9 * (size_t)i;
-      V3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
-      V3 h = v_cross(d, e2);
-      double a = v_dot(e1, h);
-      if (!(a > -kEps && a < kEps))
-      {
-        double f = 1.0 / a;
-        V3 sv = v_sub(o, v0);
-        double u = f * v_dot(sv, h);
-        if (!(u < 0.0 || u > 1.0))
-        {
-          V3 q = v_cross(sv, e1);
-          double v = f * v_dot(d, q);
-          if (!(v < 0.0 || u + v > 1.0))
-          {
-            double t = f * v_dot(e2, q);
-            if (t > kEps && t < min_t)
-            {
-              min_t = t;
-              best = (int)(S.n_sph + i);
-              bary_u = u;
-              bary_v = v;
-            }
-          }
-        }
-      }
+      /* the literal scan: spheres, then triangles, every lane on the same primitive */
+      for (uint32_t i = 0; i < S.n_sph; i++)
+        exact_sphere(S.geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
+      for (uint32_t i = 0; i < S.n_tri; i++)
+        exact_triangle(S.tri + 9 * (size_t)i, S.n_sph + i, o, d, min_t, best, bary_u, bary_v);
     }
+    else
+      scan_filtered<TRIS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o,
+                          d, min_t, best, bary_u, bary_v, diag_ptr);
 
     if (best >= 0)
     {
@@ -625,7 +645,7 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 6
 #endif
-template <bool REFRACT>
+template <bool REFRACT, bool TRIS, bool FILT_LDS>
 __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 {
   extern __shared__ double lds[];
@@ -709,7 +729,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      if (trace_step<1, REFRACT>(S, P, n_casts, diag_ptr, stack, stack_n))
+      if (trace_step<1, REFRACT, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, stack, stack_n))
       {
         /* sample done: add to the pixel's fixed-point sum (integer adds commute: the
          * result does not depend on which lane finishes first) */
@@ -750,17 +770,22 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   store_tile(L, out_f, out_b, wg_stats, tile, S.n_sph + S.n_tri);
 }
 
-extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void pt_render_tiles(const PtLaunch L)
-{
-  render_tiles_pooled<false>(L);
-}
-
-/* Same kernel for scenes with M_REFRACTION materials: carries the per-lane stack of pending
- * second children (private memory; touched only at refractive hits). */
-extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_refract(const PtLaunch L)
-{
-  render_tiles_pooled<true>(L);
-}
+/* Kernel family: pt_render_tiles[_tri][_big][_refract].  The host picks by scene content
+ * (pt_launch_render): "_tri" = scene has triangles, "_big" = more than PT_FILT_LDS_MAX
+ * primitives (filter table streamed by scalar loads instead of LDS), "_refract" = scene has
+ * M_REFRACTION materials (per-lane stack of pending second children in private memory).
+ * pt_render_tiles itself is the headline configuration: spheres only, small scene. */
+#define PT_KERNEL(name, bounds, REFRACT, TRIS, FILT_LDS)                                     \
+  extern "C" __global__ bounds void name(const PtLaunch L) { render_tiles_pooled<REFRACT, TRIS, FILT_LDS>(L); }
+PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, true)
+PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
+PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, true, true)
+PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, true, false)
+PT_KERNEL(pt_render_tiles_refract, __launch_bounds__(PT_BLOCK), true, false, true)
+PT_KERNEL(pt_render_tiles_big_refract, __launch_bounds__(PT_BLOCK), true, false, false)
+PT_KERNEL(pt_render_tiles_tri_refract, __launch_bounds__(PT_BLOCK), true, true, true)
+PT_KERNEL(pt_render_tiles_tri_big_refract, __launch_bounds__(PT_BLOCK), true, true, false)
+#undef PT_KERNEL
 
 /* ---- plain kernel: static (pixel, slice) lanes, literal scan, fp64 sums ------------------
  * Selected by RT_HIP_KERNEL_VARIANT=0.  Lane l of wave w: pixel (l >> 2) of the wave's 16,
@@ -815,7 +840,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
       fresh = false;
     }
     n_rays++;
-    if (trace_step<0, false>(S, P, n_casts, diag_ptr, nullptr, no_stack))
+    if (trace_step<0, false, true, false>(S, P, n_casts, diag_ptr, nullptr, no_stack))
     {
       acc = v_add(acc, P.Ls);
       s += PT_SLICES;
@@ -847,6 +872,46 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
   }
   __syncthreads();
   store_tile(L, out_f, out_b, wg_stats, tile, S.n_sph + S.n_tri);
+}
+
+/* Builds the packed-fp32 phase-1 filter table for one launch (the thresholds depend on
+ * near_R, i.e. on the camera).  Per pair: cx cy cz r2_hi neg_tol, two primitives per f32x2.
+ * Bound (e = 2^-24, fp32 unit roundoff; a = |c| + |o| <= A := |c| + near_R; |d| <= 1.0001):
+ *   c, o, d are rounded to fp32 (relative e each), L = c - o adds one rounding, so
+ *   |L32 - L| <= 2.01 e a per component; each 3-term fused dot product adds <= 3 e of its
+ *   magnitude.  Hence  |tca32 - tca| <= 6.2 e A   and   |d2_32 - d2| <= 20.5 e A^2,  where tca,
+ *   d2 are the real-number values; the reference's own fp64 rounding of them (~1e-16
+ *   relative) is absorbed by the 1.5x slack:
+ *     drop  <=>  tca32 < -(Rb + 10 e A)   or   d2_32 > R2 + 32 e A^2       (never a false drop)
+ *   sphere: R2 = r*r, Rb = 0 (intersect_sphere rejects tca < 0, raytracer.c:84);
+ *   triangle: R2 = Rb^2 of its bounding sphere, Rb = that radius (the hit point is inside the
+ *   bounding sphere, so the centre is at most Rb behind the origin).
+ * Thresholds are rounded away from the accept region when stored as fp32. */
+extern "C" __global__ __launch_bounds__(256) void pt_build_filter(const double *entry_src, uint32_t n_entries,
+                                                                 double near_R, float *filt)
+{
+  const uint32_t n_slots = (n_entries + 1u) & ~1u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x)
+  {
+    float *f = filt + 2 * PT_FILT_STRIDE * (size_t)(i >> 1) + (i & 1u);
+    if (i < n_entries)
+    {
+      const double *src = entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz R2 |c| Rb */
+      const double e = 5.9604644775390625e-08;                          /* 2^-24 */
+      const double A = src[4] + near_R;
+      f[0] = (float)src[0];
+      f[2] = (float)src[1];
+      f[4] = (float)src[2];
+      f[6] = (float)((src[3] + 32.0 * e * A * A) * (1.0 + 4.0 * e));
+      f[8] = -(float)((src[5] + 10.0 * e * A) * (1.0 + 4.0 * e));
+    }
+    else
+    { /* padding slot of an odd count: masked out by valid_lo / valid_hi in the scan */
+      f[0] = f[2] = f[4] = 0.f;
+      f[6] = -1.f;
+      f[8] = 0.f;
+    }
+  }
 }
 
 /* Scatter compact tile-major buffers to row-major images: one thread per
@@ -888,19 +953,34 @@ extern "C" __global__ __launch_bounds__(256) void pt_untile(const float *tiles_r
 size_t pt_render_lds_bytes(const PtSceneView &sc)
 {
   size_t doubles = PT_GEOM_STRIDE * (size_t)sc.n_spheres + PT_MAT_STRIDE * (size_t)(sc.n_spheres + sc.n_meshes);
-  if (sc.n_triangles <= PT_MAX_LDS_TRIS)
-    doubles += 9 * (size_t)sc.n_triangles;
-  doubles += PT_FILT_STRIDE * (size_t)((sc.n_spheres + 1) / 2); /* f32x2 = one double-sized slot */
+  const size_t n_entries = (size_t)sc.n_spheres + sc.n_triangles;
+  if (n_entries <= PT_FILT_LDS_MAX)
+    doubles += PT_FILT_STRIDE * ((n_entries + 1) / 2 + 1); /* f32x2 = one double-sized slot */
   return doubles * sizeof(double);
 }
 
 hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant)
 {
   const size_t lds_bytes = pt_render_lds_bytes(launch.scene);
-  auto kernel = launch.scene.any_refract ? pt_render_tiles_refract
-                                         : (variant == 0 ? pt_render_tiles_v0 : pt_render_tiles);
-  static size_t lds_allowed[3] = {0, 0, 0}; /* raised once per process if a scene needs > 64 KiB */
-  size_t &allowed = lds_allowed[launch.scene.any_refract ? 2 : (variant == 0 ? 0 : 1)];
+  {
+    /* the filter table for this camera: a ~2 us kernel ahead of the render on the same stream */
+    const uint32_t n_entries = launch.scene.n_spheres + launch.scene.n_triangles;
+    const uint32_t blocks = n_entries ? min(1024u, (n_entries + 255u) / 256u) : 0u;
+    if (blocks)
+      hipLaunchKernelGGL(pt_build_filter, dim3(blocks), dim3(256), 0, stream, launch.scene.entry_src, n_entries,
+                         launch.near_R, launch.scene.filt);
+  }
+  const bool tris = launch.scene.n_triangles != 0;
+  const bool big = (size_t)launch.scene.n_spheres + launch.scene.n_triangles > PT_FILT_LDS_MAX;
+  const bool refr = launch.scene.any_refract != 0;
+  typedef void (*Kernel)(const PtLaunch);
+  static const Kernel family[8] = {pt_render_tiles,         pt_render_tiles_big,         pt_render_tiles_tri,
+                                   pt_render_tiles_tri_big, pt_render_tiles_refract,     pt_render_tiles_big_refract,
+                                   pt_render_tiles_tri_refract, pt_render_tiles_tri_big_refract};
+  const int which = (refr ? 4 : 0) + (tris ? 2 : 0) + (big ? 1 : 0);
+  const Kernel kernel = (variant == 0 && !refr) ? pt_render_tiles_v0 : family[which];
+  static size_t lds_allowed[9] = {0}; /* raised once per process if a scene needs > 64 KiB */
+  size_t &allowed = lds_allowed[(variant == 0 && !refr) ? 8 : which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),

@@ -183,8 +183,8 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   if (n_spheres + n_meshes > 0xFFFFFFu || n_tri > 0x7FFFFFFFu - n_spheres)
     return fail(RT_HIP_ELIMIT, "scene too large");
   const size_t n_mat = n_spheres + n_meshes;
-  if ((PT_GEOM_STRIDE * n_spheres + PT_FILT_STRIDE * ((n_spheres + 1) / 2) + PT_MAT_STRIDE * n_mat) * sizeof(double) > 150 * 1024)
-    return fail(RT_HIP_ELIMIT, "%zu spheres + %zu meshes do not fit the LDS staging area", n_spheres, n_meshes);
+  if ((PT_GEOM_STRIDE * n_spheres + PT_MAT_STRIDE * n_mat) * sizeof(double) > 24 * 1024)
+    return fail(RT_HIP_ELIMIT, "%zu spheres + %zu meshes exceed the 24 KiB LDS staging area (6 workgroups per CU)", n_spheres, n_meshes);
 
   /* ---- build the kernel layout on the host (pt_device.h) ---- */
   double reach = 0, max_emission = 0;
@@ -192,18 +192,19 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
     max_emission = std::fmax(max_emission, max_abs3(spheres[i].emission));
   for (size_t m = 0; m < n_meshes; m++)
     max_emission = std::fmax(max_emission, max_abs3(meshes[m].emission));
-  std::vector<double> geom(PT_GEOM_SRC_STRIDE * n_spheres), mat(PT_MAT_STRIDE * n_mat), tgeom(9 * n_tri), tnorm(3 * n_tri),
+  std::vector<double> geom(PT_ENTRY_SRC_STRIDE * (n_spheres + n_tri)), mat(PT_MAT_STRIDE * n_mat), tgeom(9 * n_tri), tnorm(3 * n_tri),
       ttex(6 * n_tri);
   std::vector<uint32_t> tobj(n_tri);
   for (size_t i = 0; i < n_spheres; i++)
   {
-    double *g = &geom[PT_GEOM_SRC_STRIDE * i];
+    double *g = &geom[PT_ENTRY_SRC_STRIDE * i];
     g[0] = spheres[i].center[0];
     g[1] = spheres[i].center[1];
     g[2] = spheres[i].center[2];
     g[3] = spheres[i].radius * spheres[i].radius; /* raytracer.c:87 */
     /* |c|, rounded up: feeds the conservative phase-1 thresholds only, never a result */
     g[4] = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) * (1.0 + 1e-12);
+    g[5] = 0.0; /* a sphere is rejected when its centre is behind the origin at all (raytracer.c:84) */
     if (std::fabs(spheres[i].radius) < 1000.0) /* wall-sized spheres would only loosen the filter */
       reach = std::fmax(reach, g[4] + std::fabs(spheres[i].radius));
     put_material(&mat[PT_MAT_STRIDE * i], spheres[i].flags, spheres[i].color, spheres[i].emission);
@@ -237,6 +238,23 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
         ttex[6 * t + 2 * j + 1] = v[j].tex[1];
       }
       tobj[t] = (uint32_t)(n_spheres + m);
+      /* phase-1 bound of the triangle: a sphere around the centroid through the farthest
+       * vertex, slightly enlarged; feeds the conservative filter only, never a result */
+      double *b = &geom[PT_ENTRY_SRC_STRIDE * (n_spheres + t)];
+      H3 cen = {(v0.x + v1.x + v2.x) / 3.0, (v0.y + v1.y + v2.y) / 3.0, (v0.z + v1.z + v2.z) / 3.0};
+      double rb2 = 0;
+      for (int j = 0; j < 3; j++)
+      {
+        H3 dv = h_sub(h3(v[j].pos), cen);
+        rb2 = std::fmax(rb2, h_dot(dv, dv));
+      }
+      const double rb = std::sqrt(rb2) * (1.0 + 1e-9) + 1e-300;
+      b[0] = cen.x;
+      b[1] = cen.y;
+      b[2] = cen.z;
+      b[3] = rb * rb;
+      b[4] = std::sqrt(h_dot(cen, cen)) * (1.0 + 1e-12);
+      b[5] = rb;
     }
   }
 
@@ -248,7 +266,10 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   const size_t off_tnorm = off_tgeom + pad(tgeom.size() * 8);
   const size_t off_ttex = off_tnorm + pad(tnorm.size() * 8);
   const size_t off_tobj = off_ttex + pad(ttex.size() * 8);
-  const size_t total = off_tobj + pad(tobj.size() * 4) + 256;
+  const size_t off_filt = off_tobj + pad(tobj.size() * 4);
+  /* + 1 pair: the scan's software pipeline reads one pair past the end */
+  const size_t filt_bytes = ((n_spheres + n_tri + 1) / 2 + 1) * (size_t)PT_FILT_STRIDE * 2 * sizeof(float);
+  const size_t total = off_filt + pad(filt_bytes) + 256;
 
   int prev = 0;
   HIP_TRY(hipGetDevice(&prev));
@@ -281,7 +302,8 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
     delete sc;
     return fail(RT_HIP_ERUNTIME, "scene upload: %s", hipGetErrorString(e));
   }
-  sc->view.sphere_geom = reinterpret_cast<const double *>(base + off_geom);
+  sc->view.entry_src = reinterpret_cast<const double *>(base + off_geom);
+  sc->view.filt = reinterpret_cast<float *>(base + off_filt);
   sc->view.material = reinterpret_cast<const double *>(base + off_mat);
   sc->view.tri_geom = reinterpret_cast<const double *>(base + off_tgeom);
   sc->view.tri_normal = reinterpret_cast<const double *>(base + off_tnorm);
