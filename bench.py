@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples/pixel (0 = the configuration's own)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--cpu-tiles", type=int, default=192, help="8x8 tiles of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-tiles", type=int, default=384, help="8x8 tiles of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch

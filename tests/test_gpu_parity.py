@@ -237,3 +237,41 @@ def test_refraction_depth_limit_is_reported(gpu):
     with pytest.raises(G.ShimError, match="max_depth <= 32"):
         gs.render_image(SEED)
     gs.close()
+
+
+def test_cli_host_writes_the_image(gpu, pt, tmp_path):
+    """the C command-line host (reference main.c flags -w -h -s -o) end to end: scene build,
+    init_camera, render() on the GPU, PNG out"""
+    import os
+    import struct
+    import subprocess
+    import zlib
+    from rt_amd import abi, scene as S
+    exe = os.path.join(abi.PKG_DIR, "host", "raytracer")
+    out = str(tmp_path / "cli.png")
+    r = subprocess.run([exe, "-w", "64", "-h", "40", "-s", "4", "-o", out, "-c", "1", "-d", "4"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "cast " in r.stdout and "rendering took" in r.stdout and "done." in r.stdout
+    data = open(out, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, dims = 8, b"", None
+    while pos < len(data):
+        (n,), typ = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        if typ == b"IHDR":
+            dims = struct.unpack(">II", body[:8])
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert dims == (64, 40)
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(40, 1 + 64 * 3)
+    img = raw[:, 1:].reshape(-1, 3)
+    sc = S.build_scene(1, 64, 40, 4)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert np.abs(img.astype(np.int16) - rgb8.astype(np.int16)).max() <= 1
+    rays = int([ln for ln in r.stdout.splitlines() if ln.startswith("cast ")][0].split()[1])
+    assert rays == ost["rays"]
+    # no arguments: usage + failure, like the reference (main.c:189-193)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "Usage:" in r.stderr
