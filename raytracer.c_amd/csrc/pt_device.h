@@ -73,6 +73,10 @@ struct PtLaunch
   int32_t width, height, samples, max_depth;
   uint64_t seed;
   double near_R;  /* the phase-1 filter's assumption |o| <= near_R (rays beyond it skip the filter) */
+  /* wave-uniform values formed on the host so they arrive in SGPRs (formed on the device
+   * they would occupy -- and spill -- vector registers): near_R^2, width-1, height-1 as the
+   * reference forms them, (double)options->width - 1.0 (raytracer.c:203-204) */
+  double near_R2, w_minus_1, h_minus_1;
   double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
   float *tiles_rgb;

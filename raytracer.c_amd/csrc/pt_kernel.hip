@@ -371,7 +371,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.tri_object = sc.tri_object;
   ctx.filt = reinterpret_cast<const f32x2 *>(sc.filt);
   ctx.filt_lds = filt_lds;
-  ctx.near_R2 = L.near_R * L.near_R;
+  ctx.near_R2 = L.near_R2;
   ctx.n_sph = n_sph;
   ctx.n_tri = sc.n_triangles;
   ctx.max_depth = L.max_depth;
@@ -412,8 +412,8 @@ __device__ __forceinline__ CameraRegs load_camera(const PtLaunch &L)
   c.horizontal = ld3(L.cam.horizontal);
   c.vertical = ld3(L.cam.vertical);
   c.llc = ld3(L.cam.llc);
-  c.w_minus_1 = (double)L.width - 1.0;
-  c.h_minus_1 = (double)L.height - 1.0;
+  c.w_minus_1 = L.w_minus_1;
+  c.h_minus_1 = L.h_minus_1;
   return c;
 }
 
@@ -435,8 +435,10 @@ __device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uin
 /* ---- one trace_path() call (raytracer.c:482-554).  Returns true when the path ended; P.Ls
  * then holds the finished sample's radiance. -------------------------------------------- */
 /* VARIANT: 0 literal scan / 1 filtered scan.  REFRACT: scene has M_REFRACTION materials.
+ * CHECKER: scene has M_CHECKERED materials (atan2 / fmod code; its polynomial constants
+ * would otherwise be hoisted into -- and spilled from -- registers of every scene).
  * TRIS: scene has triangles.  FILT_LDS: the filter table is staged in LDS (small scenes). */
-template <int VARIANT, bool REFRACT, bool TRIS, bool FILT_LDS>
+template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
                                            unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
 {
@@ -496,7 +498,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       if (rnd(P.rng) < prob)
       {
         path_ends = false;
-        if (flags & PT_FLAG_CHECKER)
+        if (CHECKER && (flags & PT_FLAG_CHECKER))
         {
           if (!is_tri)
           {
@@ -638,14 +640,17 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 
 /* ---- shipped kernel: pooled samples, fixed-point pixel sums ------------------------------ */
 
-/* PT_MIN_WAVES: waves per SIMD the register allocator must leave room for.  Measured on
- * config 4 (ms per 1080p x 128 spp frame): 3 waves 56.2, 4: 49.8, 5: 48.0, 6: 47.2, 7: 48.1,
- * 8: 54.1 -- the loop is VALU-issue bound and wants latency cover more than it minds the
- * few spilled registers (232 B/lane of scratch at 6). */
+/* PT_MIN_WAVES: waves per SIMD the register allocator must leave room for.  The loop is
+ * VALU-issue bound and wants latency cover: on config 4 (1080p x 128 spp) 3 waves/SIMD took
+ * 56.2 ms, 4: 49.8, 5: 48.0, 6: 47.2, 7: 48.1, 8: 54.1 when measured on revision c.  After the
+ * uniform values moved to SGPRs and the checker code out of this kernel, 5 waves fit in 94
+ * VGPRs with NO scratch (47.1 ms) and 6 waves need 56 B/lane of spills (46.7 ms, but 290 MB
+ * of spill write-back per frame against 31 MB of algorithmic output): 5 it is. */
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 6
+#define PT_MIN_WAVES 5
 #endif
-template <bool REFRACT, bool TRIS, bool FILT_LDS>
+/* FANCY = the scene has M_REFRACTION or M_CHECKERED materials */
+template <bool FANCY, bool TRIS, bool FILT_LDS>
 __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 {
   extern __shared__ double lds[];
@@ -684,7 +689,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   uint32_t next_job = 0;     /* wave-uniform */
   uint32_t pix_slot = 0;     /* 0..63 inside the tile */
   bool busy = false;
-  PendingRay stack[REFRACT ? PT_REFRACT_STACK : 1];
+  PendingRay stack[FANCY ? PT_REFRACT_STACK : 1];
   int stack_n = 0;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
@@ -729,7 +734,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      if (trace_step<1, REFRACT, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, stack, stack_n))
+      if (trace_step<1, FANCY, FANCY, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, stack, stack_n))
       {
         /* sample done: add to the pixel's fixed-point sum (integer adds commute: the
          * result does not depend on which lane finishes first) */
@@ -770,21 +775,22 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   store_tile(L, out_f, out_b, wg_stats, tile, S.n_sph + S.n_tri);
 }
 
-/* Kernel family: pt_render_tiles[_tri][_big][_refract].  The host picks by scene content
+/* Kernel family: pt_render_tiles[_tri][_big][_fancy].  The host picks by scene content
  * (pt_launch_render): "_tri" = scene has triangles, "_big" = more than PT_FILT_LDS_MAX
- * primitives (filter table streamed by scalar loads instead of LDS), "_refract" = scene has
- * M_REFRACTION materials (per-lane stack of pending second children in private memory).
- * pt_render_tiles itself is the headline configuration: spheres only, small scene. */
-#define PT_KERNEL(name, bounds, REFRACT, TRIS, FILT_LDS)                                     \
-  extern "C" __global__ bounds void name(const PtLaunch L) { render_tiles_pooled<REFRACT, TRIS, FILT_LDS>(L); }
+ * primitives (filter table streamed by scalar loads instead of LDS), "_fancy" = scene has
+ * M_REFRACTION materials (per-lane stack of pending second children in private memory) or
+ * M_CHECKERED ones (atan2 / fmod).  pt_render_tiles itself is the headline configuration:
+ * diffuse / mirror / emissive spheres, small scene. */
+#define PT_KERNEL(name, bounds, FANCY, TRIS, FILT_LDS)                                       \
+  extern "C" __global__ bounds void name(const PtLaunch L) { render_tiles_pooled<FANCY, TRIS, FILT_LDS>(L); }
 PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, true)
 PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
 PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, true, true)
 PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, true, false)
-PT_KERNEL(pt_render_tiles_refract, __launch_bounds__(PT_BLOCK), true, false, true)
-PT_KERNEL(pt_render_tiles_big_refract, __launch_bounds__(PT_BLOCK), true, false, false)
-PT_KERNEL(pt_render_tiles_tri_refract, __launch_bounds__(PT_BLOCK), true, true, true)
-PT_KERNEL(pt_render_tiles_tri_big_refract, __launch_bounds__(PT_BLOCK), true, true, false)
+PT_KERNEL(pt_render_tiles_fancy, __launch_bounds__(PT_BLOCK), true, false, true)
+PT_KERNEL(pt_render_tiles_big_fancy, __launch_bounds__(PT_BLOCK), true, false, false)
+PT_KERNEL(pt_render_tiles_tri_fancy, __launch_bounds__(PT_BLOCK), true, true, true)
+PT_KERNEL(pt_render_tiles_tri_big_fancy, __launch_bounds__(PT_BLOCK), true, true, false)
 #undef PT_KERNEL
 
 /* ---- plain kernel: static (pixel, slice) lanes, literal scan, fp64 sums ------------------
@@ -840,7 +846,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
       fresh = false;
     }
     n_rays++;
-    if (trace_step<0, false, true, false>(S, P, n_casts, diag_ptr, nullptr, no_stack))
+    if (trace_step<0, false, true, true, false>(S, P, n_casts, diag_ptr, nullptr, no_stack))
     {
       acc = v_add(acc, P.Ls);
       s += PT_SLICES;
@@ -972,15 +978,15 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }
   const bool tris = launch.scene.n_triangles != 0;
   const bool big = (size_t)launch.scene.n_spheres + launch.scene.n_triangles > PT_FILT_LDS_MAX;
-  const bool refr = launch.scene.any_refract != 0;
+  const bool refr = launch.scene.any_refract != 0 || launch.scene.any_checker != 0; /* "fancy" */
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[8] = {pt_render_tiles,         pt_render_tiles_big,         pt_render_tiles_tri,
-                                   pt_render_tiles_tri_big, pt_render_tiles_refract,     pt_render_tiles_big_refract,
-                                   pt_render_tiles_tri_refract, pt_render_tiles_tri_big_refract};
+  static const Kernel family[8] = {pt_render_tiles,         pt_render_tiles_big,       pt_render_tiles_tri,
+                                   pt_render_tiles_tri_big, pt_render_tiles_fancy,     pt_render_tiles_big_fancy,
+                                   pt_render_tiles_tri_fancy, pt_render_tiles_tri_big_fancy};
   const int which = (refr ? 4 : 0) + (tris ? 2 : 0) + (big ? 1 : 0);
-  const Kernel kernel = (variant == 0 && !refr) ? pt_render_tiles_v0 : family[which];
+  const Kernel kernel = (variant == 0 && !launch.scene.any_refract) ? pt_render_tiles_v0 : family[which];
   static size_t lds_allowed[9] = {0}; /* raised once per process if a scene needs > 64 KiB */
-  size_t &allowed = lds_allowed[(variant == 0 && !refr) ? 8 : which];
+  size_t &allowed = lds_allowed[(variant == 0 && !launch.scene.any_refract) ? 8 : which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),

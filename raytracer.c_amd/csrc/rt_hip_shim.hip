@@ -384,6 +384,9 @@ int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, cons
     L.near_R = 1.5 * (cam + scene->reach) + 1.0;
     if (!(L.near_R < 1e15))
       return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.near_R);
+    L.near_R2 = L.near_R * L.near_R;
+    L.w_minus_1 = (double)params->width - 1.0;
+    L.h_minus_1 = (double)params->height - 1.0;
   }
   {
     /* Fixed-point scale of the per-pixel sums (pt_render_tiles): a sample's radiance is
