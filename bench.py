@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples/pixel (0 = the configuration's own)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--chunks", type=int, default=0, help="sample chunks per tile (0 = rt_hip_suggest_chunks)")
+    ap.add_argument("--shard", type=str, default="", help="dev: render only rank R of a W-way partition, 'R/W', on this one GPU")
     ap.add_argument("--cpu-tiles", type=int, default=384, help="8x8 tiles of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -128,8 +130,16 @@ def main():
     W, H, spp, depth = sc.width, sc.height, sc.samples, sc.max_depth
     gs = G.GpuScene(sc, device=local_rank)            # scene resident in HBM from here on
     first, stride, count = D.rank_tiles(W, H, rank, world)
+    if args.shard:  # development aid: what one rank of a larger job would do
+        r_, w_ = [int(v) for v in args.shard.split("/")]
+        first, stride, count = D.rank_tiles(W, H, r_, w_)
     tiles, tiles8 = D.alloc_tile_buffers(W, H, world, dev)   # padded: ranks differ by at most one tile
     stats = torch.zeros(abi.NSTATS, dtype=torch.int64, device=dev)
+    # few tiles per GPU (large N): split every tile's samples over several workgroups so the
+    # last, partly filled round of the launch stays a small fraction of it (same image, bit for bit)
+    chunks = args.chunks or gs.suggest_chunks(count)
+    workspace = (torch.empty(abi.load_shim().rt_hip_chunk_workspace_bytes(max(count, 1)), dtype=torch.uint8, device=dev)
+                 if chunks > 1 else None)
     image = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
     image8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
     gathered = gathered8 = None
@@ -142,7 +152,7 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()                                    # same stream the shim launches on
-        gs.render_tiles(SEED, first, stride, count, tiles, tiles8, stats)
+        gs.render_tiles(SEED, first, stride, count, tiles, tiles8, stats, chunks=chunks, workspace=workspace)
         e1.record()
         if timed:
             kernel_events.append((e0, e1))
@@ -197,7 +207,8 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {W}x{H}, {spp} spp, "
                                    f"{sc.n_objects} spheres + {sc.n_triangles} triangles, depth {depth}",
                        "width": W, "height": H, "spp": spp, "max_depth": depth, "seed": SEED,
-                       "parallelism": f"tiles interleaved over {world} GPU(s), RCCL gather to rank 0"},
+                       "parallelism": f"tiles interleaved over {world} GPU(s), RCCL gather to rank 0",
+                       "sample_chunks_per_tile": chunks},
             "mpixel_samples_per_s": samples / elapsed * 1e-6,
             "rays_per_sample": rays / max(samples, 1),
             "ray_count_per_step": rays / steps, "ray_bounces_per_step": casts_per_step,

@@ -140,6 +140,18 @@ size_t rt_hip_scene_primitives(const RtHipScene *scene); /* spheres + triangles 
 int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
                         float *d_tiles_rgb, uint8_t *d_tiles_rgb8, uint64_t *d_stats, void *stream);
 
+/* The same render with every tile's samples split over `sample_chunks` workgroups (finer
+ * work units: matters when a GPU holds few tiles, e.g. 1/8 of a 1080p frame).  Partial sums
+ * are exact integers, so the image is bit-identical for every sample_chunks.  d_workspace:
+ * rt_hip_chunk_workspace_bytes(tile_count) bytes of device memory (may be NULL when
+ * sample_chunks == 1); it is cleared, filled and resolved on `stream`.
+ * rt_hip_suggest_chunks() returns a good value for the scene's device. */
+size_t rt_hip_chunk_workspace_bytes(uint32_t tile_count);
+uint32_t rt_hip_suggest_chunks(const RtHipScene *scene, uint32_t tile_count, int32_t samples);
+int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
+                                uint32_t sample_chunks, void *d_workspace, float *d_tiles_rgb,
+                                uint8_t *d_tiles_rgb8, uint64_t *d_stats, void *stream);
+
 /* Scatter a compact tile buffer into row-major images (either output may be
  * NULL together with its input). */
 int rt_hip_untile(const float *d_tiles_rgb, const uint8_t *d_tiles_rgb8, int32_t width, int32_t height,

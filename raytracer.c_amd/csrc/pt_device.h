@@ -79,6 +79,8 @@ struct PtLaunch
   double near_R2, w_minus_1, h_minus_1;
   double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
+  uint32_t sample_chunks, reserved_; /* workgroups per tile: each renders 1/sample_chunks of the samples */
+  unsigned long long *acc_ws;        /* tile_count x 192 fixed-point sums, used when sample_chunks > 1 */
   float *tiles_rgb;
   uint8_t *tiles_rgb8;
   unsigned long long *stats;

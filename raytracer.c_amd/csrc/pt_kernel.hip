@@ -613,14 +613,41 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
 
 /* ---- epilogue shared by both kernels: coalesced tile store + counters ------------------- */
 
+/* per-pixel mean (raytracer.c:215) and gamma-5 tonemap (:218-220) of one tile from its
+ * fixed-point sums; thread t < 64 handles pixel t */
+__device__ __forceinline__ void finish_pixels(const PtLaunch &L, const unsigned long long *sums, uint32_t tile,
+                                              float *out_f, uint8_t *out_b)
+{
+  if (threadIdx.x < PT_TILE_PIXELS)
+  {
+    const uint32_t t = threadIdx.x;
+    const bool inside = (tile % L.tiles_x) * PT_TILE + (t & 7u) < (uint32_t)L.width &&
+                        (tile / L.tiles_x) * PT_TILE + (t >> 3) < (uint32_t)L.height;
+    const double inv_s = 1.0 / (double)L.samples;
+    V3 mean;
+    mean.x = ((double)(long long)sums[3 * t + 0] * L.acc_inv_scale) * inv_s;
+    mean.y = ((double)(long long)sums[3 * t + 1] * L.acc_inv_scale) * inv_s;
+    mean.z = ((double)(long long)sums[3 * t + 2] * L.acc_inv_scale) * inv_s;
+    out_f[3 * t + 0] = inside ? (float)mean.x : 0.f;
+    out_f[3 * t + 1] = inside ? (float)mean.y : 0.f;
+    out_f[3 * t + 2] = inside ? (float)mean.z : 0.f;
+    out_b[3 * t + 0] = inside ? tonemap(mean.x) : 0;
+    out_b[3 * t + 1] = inside ? tonemap(mean.y) : 0;
+    out_b[3 * t + 2] = inside ? tonemap(mean.z) : 0;
+  }
+}
+
+/* slot = index of the tile in the compact output; with_pixels = false when this workgroup
+ * only contributed a sample chunk (pt_resolve_tiles writes the pixels then) */
 __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f, const uint8_t *out_b,
-                                           const unsigned long long *wg_stats, uint32_t tile, uint32_t n_prims)
+                                           const unsigned long long *wg_stats, uint32_t tile, uint32_t slot,
+                                           uint32_t n_prims, bool with_pixels, bool count_samples)
 {
   /* 192 floats = 768 contiguous bytes per tile */
-  if (threadIdx.x < PT_TILE_PIXELS * 3)
-    L.tiles_rgb[(size_t)blockIdx.x * (PT_TILE_PIXELS * 3) + threadIdx.x] = out_f[threadIdx.x];
-  if (L.tiles_rgb8 && threadIdx.x < PT_TILE_PIXELS * 3 / 4)
-    reinterpret_cast<uint32_t *>(L.tiles_rgb8)[(size_t)blockIdx.x * (PT_TILE_PIXELS * 3 / 4) + threadIdx.x] =
+  if (with_pixels && threadIdx.x < PT_TILE_PIXELS * 3)
+    L.tiles_rgb[(size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x] = out_f[threadIdx.x];
+  if (with_pixels && L.tiles_rgb8 && threadIdx.x < PT_TILE_PIXELS * 3 / 4)
+    reinterpret_cast<uint32_t *>(L.tiles_rgb8)[(size_t)slot * (PT_TILE_PIXELS * 3 / 4) + threadIdx.x] =
         reinterpret_cast<const uint32_t *>(out_b)[threadIdx.x];
   if (L.stats && threadIdx.x == 0)
   {
@@ -629,7 +656,7 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
     atomicAdd(&L.stats[1], casts);
     atomicAdd(&L.stats[2], casts * (unsigned long long)n_prims);
   }
-  if (L.stats && threadIdx.x == 64)
+  if (L.stats && count_samples && threadIdx.x == 64)
   {
     const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE;
     const uint32_t cw = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
@@ -668,14 +695,20 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 
   /* ---- this wave's pixels and job pool ---- */
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t tile = L.tile_first + blockIdx.x * L.tile_stride;
+  /* grid = tile_count x sample_chunks, chunk-major: consecutive workgroups are different
+   * tiles, so the chunks of an expensive tile are spread over the launch */
+  const uint32_t slot = blockIdx.x % L.tile_count, chunk = blockIdx.x / L.tile_count;
+  const uint32_t tile = L.tile_first + slot * L.tile_stride;
   const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE + 2u * wave;
   /* valid sub-rectangle of the wave's 8x2 strip (edge tiles of ragged images) */
   const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
   const uint32_t vrows = ty0 >= (uint32_t)L.height ? 0u : min(2u, (uint32_t)L.height - ty0);
   const uint32_t n_valid = vcols * vrows;
   const uint32_t spp = (uint32_t)L.samples;
-  const uint32_t pool = n_valid * spp; /* jobs: j -> pixel j % n_valid, sample j / n_valid */
+  /* this workgroup's share of the samples: [s_begin, s_end) of every pixel */
+  const uint32_t s_begin = (uint32_t)(((uint64_t)chunk * spp) / L.sample_chunks);
+  const uint32_t s_end = (uint32_t)(((uint64_t)(chunk + 1u) * spp) / L.sample_chunks);
+  const uint32_t pool = n_valid * (s_end - s_begin); /* jobs: j -> pixel j % n_valid, sample s_begin + j / n_valid */
   const CameraRegs cam = load_camera(L);
 
   Path P;
@@ -721,7 +754,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         const uint32_t col = idx - row * vcols;
         const uint32_t px = tx0 + col, py = ty0 + row;
         pix_slot = (2u * wave + row) * PT_TILE + col;
-        start_sample(P, cam, L.seed, px, py, py * (uint32_t)L.width + px, s);
+        start_sample(P, cam, L.seed, px, py, py * (uint32_t)L.width + px, s_begin + s);
         busy = true;
       }
       next_job += (uint32_t)__popcll(idle);
@@ -753,26 +786,20 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   }
   __syncthreads();
 
-  /* ---- per-pixel mean (:215) and tonemap (:218-220), one thread per pixel ---- */
-  if (threadIdx.x < PT_TILE_PIXELS)
+  if (L.sample_chunks == 1)
   {
-    const uint32_t t = threadIdx.x;
-    const bool inside = tx0 + (t & 7u) < (uint32_t)L.width &&
-                        (tile / L.tiles_x) * PT_TILE + (t >> 3) < (uint32_t)L.height;
-    const double inv_s = 1.0 / (double)spp;
-    V3 mean;
-    mean.x = ((double)(long long)pix_sum[3 * t + 0] * L.acc_inv_scale) * inv_s;
-    mean.y = ((double)(long long)pix_sum[3 * t + 1] * L.acc_inv_scale) * inv_s;
-    mean.z = ((double)(long long)pix_sum[3 * t + 2] * L.acc_inv_scale) * inv_s;
-    out_f[3 * t + 0] = inside ? (float)mean.x : 0.f;
-    out_f[3 * t + 1] = inside ? (float)mean.y : 0.f;
-    out_f[3 * t + 2] = inside ? (float)mean.z : 0.f;
-    out_b[3 * t + 0] = inside ? tonemap(mean.x) : 0;
-    out_b[3 * t + 1] = inside ? tonemap(mean.y) : 0;
-    out_b[3 * t + 2] = inside ? tonemap(mean.z) : 0;
+    finish_pixels(L, pix_sum, tile, out_f, out_b);
+    __syncthreads();
+    store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, true, true);
   }
-  __syncthreads();
-  store_tile(L, out_f, out_b, wg_stats, tile, S.n_sph + S.n_tri);
+  else
+  {
+    /* one of several sample chunks of this tile: add the partial sums to the tile's record in
+     * HBM (integer atomics: exact, order-independent); pt_resolve_tiles finishes the pixels */
+    if (threadIdx.x < PT_TILE_PIXELS * 3 && pix_sum[threadIdx.x] != 0)
+      atomicAdd(&L.acc_ws[(size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x], pix_sum[threadIdx.x]);
+    store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, false, chunk == 0);
+  }
 }
 
 /* Kernel family: pt_render_tiles[_tri][_big][_fancy].  The host picks by scene content
@@ -877,7 +904,23 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
     atomicAdd(&wg_stats[1], (unsigned long long)n_casts);
   }
   __syncthreads();
-  store_tile(L, out_f, out_b, wg_stats, tile, S.n_sph + S.n_tri);
+  store_tile(L, out_f, out_b, wg_stats, tile, blockIdx.x, S.n_sph + S.n_tri, true, true);
+}
+
+/* Second pass of a chunked render: per-tile fixed-point sums -> float3 + tonemapped bytes. */
+extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const PtLaunch L)
+{
+  __shared__ float out_f[PT_TILE_PIXELS * 3];
+  __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
+  const uint32_t slot = blockIdx.x;
+  const uint32_t tile = L.tile_first + slot * L.tile_stride;
+  finish_pixels(L, L.acc_ws + (size_t)slot * (PT_TILE_PIXELS * 3), tile, out_f, out_b);
+  __syncthreads();
+  if (threadIdx.x < PT_TILE_PIXELS * 3)
+    L.tiles_rgb[(size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x] = out_f[threadIdx.x];
+  if (L.tiles_rgb8 && threadIdx.x < PT_TILE_PIXELS * 3 / 4)
+    reinterpret_cast<uint32_t *>(L.tiles_rgb8)[(size_t)slot * (PT_TILE_PIXELS * 3 / 4) + threadIdx.x] =
+        reinterpret_cast<const uint32_t *>(out_b)[threadIdx.x];
 }
 
 /* Builds the packed-fp32 phase-1 filter table for one launch (the thresholds depend on
@@ -995,7 +1038,15 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
       return e;
     allowed = lds_bytes;
   }
-  hipLaunchKernelGGL(kernel, dim3(launch.tile_count), dim3(PT_BLOCK), lds_bytes, stream, launch);
+  if (launch.sample_chunks > 1)
+  {
+    hipError_t e = hipMemsetAsync(launch.acc_ws, 0, (size_t)launch.tile_count * PT_TILE_PIXELS * 3 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess)
+      return e;
+  }
+  hipLaunchKernelGGL(kernel, dim3(launch.tile_count * launch.sample_chunks), dim3(PT_BLOCK), lds_bytes, stream, launch);
+  if (launch.sample_chunks > 1)
+    hipLaunchKernelGGL(pt_resolve_tiles, dim3(launch.tile_count), dim3(PT_BLOCK), 0, stream, launch);
   return hipGetLastError();
 }
 

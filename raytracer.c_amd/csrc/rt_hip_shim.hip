@@ -339,11 +339,44 @@ size_t rt_hip_scene_primitives(const RtHipScene *scene)
   return scene ? (size_t)scene->view.n_spheres + scene->view.n_triangles : 0;
 }
 
+size_t rt_hip_chunk_workspace_bytes(uint32_t tile_count)
+{
+  return (size_t)tile_count * PT_TILE_PIXELS * 3 * sizeof(unsigned long long);
+}
+
+uint32_t rt_hip_suggest_chunks(const RtHipScene *scene, uint32_t tile_count, int32_t samples)
+{
+  if (!scene || tile_count == 0 || samples < 128)
+    return 1;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, scene->device) != hipSuccess)
+    return 1;
+  /* aim for >= 12 workgroups per resident slot (5 per CU), so the last, partly filled round
+   * of the launch is a small fraction of it; keep >= 64 samples per chunk */
+  const uint64_t want = 12ull * 5ull * (uint64_t)prop.multiProcessorCount;
+  uint64_t chunks = (want + tile_count - 1) / tile_count;
+  const uint64_t cap = (uint64_t)samples / 64;
+  if (chunks > cap) chunks = cap;
+  if (chunks > 16) chunks = 16;
+  return chunks < 1 ? 1u : (uint32_t)chunks;
+}
+
 int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
                         float *d_tiles_rgb, uint8_t *d_tiles_rgb8, uint64_t *d_stats, void *stream)
 {
+  return rt_hip_render_tiles_chunked(scene, camera, params, 1, nullptr, d_tiles_rgb, d_tiles_rgb8, d_stats, stream);
+}
+
+int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
+                                uint32_t sample_chunks, void *d_workspace, float *d_tiles_rgb,
+                                uint8_t *d_tiles_rgb8, uint64_t *d_stats, void *stream)
+{
   if (!scene || !camera || !d_tiles_rgb)
     return fail(RT_HIP_EINVAL, "scene, camera and d_tiles_rgb are required");
+  if (sample_chunks < 1 || (params && (int64_t)sample_chunks > params->samples))
+    return fail(RT_HIP_EINVAL, "sample_chunks must be in [1, samples]");
+  if (sample_chunks > 1 && !d_workspace)
+    return fail(RT_HIP_EINVAL, "sample_chunks > 1 needs a workspace of rt_hip_chunk_workspace_bytes(tile_count)");
   int rc = check_params(params);
   if (rc)
     return rc;
@@ -406,6 +439,10 @@ int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, cons
   L.tile_stride = params->tile_stride;
   L.tile_count = params->tile_count;
   L.tiles_x = tx;
+  L.sample_chunks = kernel_variant() == 0 && !scene->view.any_refract ? 1u : sample_chunks;
+  L.acc_ws = static_cast<unsigned long long *>(d_workspace);
+  if ((uint64_t)L.tile_count * L.sample_chunks > 0x7FFFFFFFull)
+    return fail(RT_HIP_EINVAL, "tile_count x sample_chunks exceeds the grid limit");
   L.tiles_rgb = d_tiles_rgb;
   L.tiles_rgb8 = d_tiles_rgb8;
   L.stats = reinterpret_cast<unsigned long long *>(d_stats);
@@ -475,6 +512,7 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
     float *tiles = nullptr;
     uint8_t *tiles8 = nullptr;
     uint64_t *stats = nullptr;
+    void *ws = nullptr;
     uint32_t count = 0;
   };
   std::vector<Dev> dev(G);
@@ -495,6 +533,7 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
       (void)hipFree(dev[g].tiles);
       (void)hipFree(dev[g].tiles8);
       (void)hipFree(dev[g].stats);
+      (void)hipFree(dev[g].ws);
       rt_hip_scene_destroy(dev[g].scene);
     }
     (void)hipSetDevice(0);
@@ -541,8 +580,11 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
     p.tile_first = (uint32_t)g;
     p.tile_stride = (uint32_t)G;
     p.tile_count = d.count;
+    const uint32_t chunks = rt_hip_suggest_chunks(d.scene, d.count, p.samples);
+    if (chunks > 1)
+      IMG_TRY(hipMalloc(&d.ws, rt_hip_chunk_workspace_bytes(d.count)));
     IMG_TRY(hipEventRecord(d.t0, d.stream));
-    rc = rt_hip_render_tiles(d.scene, camera, &p, d.tiles, d.tiles8, d.stats, d.stream);
+    rc = rt_hip_render_tiles_chunked(d.scene, camera, &p, chunks, d.ws, d.tiles, d.tiles8, d.stats, d.stream);
     if (rc)
     {
       cleanup();

@@ -56,10 +56,14 @@ class GpuScene:
         p.tile_first, p.tile_stride, p.tile_count = first, stride, count
         return p
 
+    def suggest_chunks(self, count, samples=None):
+        return int(self.shim.rt_hip_suggest_chunks(self.handle, count, samples or self.scene.samples))
+
     def render_tiles(self, seed, first, stride, count, tiles=None, tiles8=None, stats=None, samples=None,
-                     max_depth=None):
+                     max_depth=None, chunks=1, workspace=None):
         """Asynchronous on torch's current stream.  Returns (tiles f32 [count,64,3],
-        tiles8 u8 [count,64,3], stats i64 [4]); pass buffers to reuse them."""
+        tiles8 u8 [count,64,3], stats i64 [4]); pass buffers to reuse them.  chunks > 1 splits
+        every tile's samples over that many workgroups (same image, bit for bit)."""
         dev = torch.device("cuda", self.device)
         if tiles is None:
             tiles = torch.empty((max(count, 1), abi.TILE_PIXELS, 3), dtype=torch.float32, device=dev)
@@ -69,9 +73,14 @@ class GpuScene:
             stats = torch.zeros(abi.NSTATS, dtype=torch.int64, device=dev)
         p = self.params(seed, first, stride, count, samples, max_depth)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _check(self.shim.rt_hip_render_tiles(self.handle, C.byref(self.scene.camera), C.byref(p), tiles.data_ptr(),
-                                             tiles8.data_ptr(), stats.data_ptr(), C.c_void_p(stream)),
-               "rt_hip_render_tiles")
+        if chunks > 1 and workspace is None:
+            workspace = torch.empty(self.shim.rt_hip_chunk_workspace_bytes(max(count, 1)), dtype=torch.uint8, device=dev)
+        self._workspace = workspace  # keep alive until the stream has used it
+        _check(self.shim.rt_hip_render_tiles_chunked(self.handle, C.byref(self.scene.camera), C.byref(p), chunks,
+                                                     workspace.data_ptr() if workspace is not None else None,
+                                                     tiles.data_ptr(), tiles8.data_ptr(), stats.data_ptr(),
+                                                     C.c_void_p(stream)),
+               "rt_hip_render_tiles_chunked")
         return tiles, tiles8, stats
 
     def untile(self, tiles, tiles8, first, stride, count, image=None, image8=None):

@@ -275,3 +275,24 @@ def test_cli_host_writes_the_image(gpu, pt, tmp_path):
     # no arguments: usage + failure, like the reference (main.c:189-193)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode != 0 and "Usage:" in r.stderr
+
+
+def test_sample_chunks_are_bit_invariant(gpu, pt):
+    """splitting every tile's samples over several workgroups (finer work units for
+    multi-GPU shards) changes nothing: integer partial sums are exact"""
+    import torch
+    from rt_amd import scene as S
+    sc = S.build_scene(4, 96, 56, 22)  # 22 spp: chunks of unequal size
+    gs = gpu.GpuScene(sc)
+    total = gpu.n_tiles(sc.width, sc.height)
+    ref_t, ref_t8, ref_s = gs.render_tiles(SEED, 0, 1, total)
+    torch.cuda.synchronize()
+    for chunks in (2, 3, 7, 22):
+        t, t8, s = gs.render_tiles(SEED, 0, 1, total, chunks=chunks)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref_t) and torch.equal(t8, ref_t8), chunks
+        assert torch.equal(s, ref_s), (chunks, s.tolist(), ref_s.tolist())
+    assert gs.suggest_chunks(total, 22) == 1 and gs.suggest_chunks(100, 1024) > 1
+    with pytest.raises(gpu.ShimError):
+        gs.render_tiles(SEED, 0, 1, total, chunks=23)
+    gs.close()
