@@ -35,6 +35,18 @@ PEAK_FP64_TFLOPS = 39.3      # 256 CU x 4 SIMD x 16 fp64 lanes x 2.4 GHz, one op
 PEAK_HBM_GBS = 8000.0
 
 
+def measured_traffic(config, width, height, spp, world):
+    """HBM bytes per launch from the committed PMC passes (profiles/), when this run is the
+    profiled configuration; None otherwise (PMC counters cannot be collected from inside)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01e_traffic.json")))
+        if (rec["config"], rec["width"], rec["height"], rec["spp"], rec["n_gpus"]) == (config, width, height, spp, world):
+            return rec["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def flops_per_ray(n_spheres, n_triangles):
     """SURVEY.md section 8d counting convention (add/sub/mul/div/sqrt = 1, no FMA credit)."""
     return 17.0 * n_spheres + 40.0 * n_triangles + 120.0
@@ -215,13 +227,16 @@ def main():
             "intersection_tests_per_s": tests / elapsed,
             "roofline": {"bound": "valu_fp64", "kernel": "pt_render_tiles", "achieved": achieved_tflops,
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_TFLOPS,
-                         "traffic": None, "flops_per_ray_bounce": fr, "kernel_ms": kern_s * 1e3,
+                         "traffic": measured_traffic(args.config, W, H, spp, world), "flops_per_ray_bounce": fr,
+                         "kernel_ms": kern_s * 1e3,
                          "note": "branchy fp64 scalar-per-lane math: neither HBM nor MFMA binds it "
                                  "(BASELINE.md section 4); algorithmic flops, no FMA credit"},
             "roofline_hbm": {"bound": "hbm", "kernel": "pt_render_tiles",
                              "achieved": alg_bytes / kern_s * 1e-9 if kern_s > 0 else 0.0, "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": (alg_bytes / kern_s * 1e-9 / PEAK_HBM_GBS) if kern_s > 0 else 0.0,
-                             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes},
+                             "traffic": measured_traffic(args.config, W, H, spp, world),
+                             "traffic_source": "profiles/r01e_pmc_c4.txt (rocprofv3 --pmc, separate passes)",
+                             "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and args.cpu_tiles > 0:
             try:
