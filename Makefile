@@ -29,6 +29,9 @@ HOST_HDR := $(INC)/raytracer.h $(INC)/vector.h $(INC)/rt_hip.h $(INC)/rt_rng.h $
 
 all: shim host oracle
 
+# oracle/_ref/ref_main_dropin links against the host library: build that first
+oracle: host
+
 shim: $(SHIM)
 $(SHIM): $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC)/rt_hip.h $(INC)/rt_rng.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl

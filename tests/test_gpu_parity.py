@@ -296,3 +296,27 @@ def test_sample_chunks_are_bit_invariant(gpu, pt):
     with pytest.raises(gpu.ShimError):
         gs.render_tiles(SEED, 0, 1, total, chunks=23)
     gs.close()
+
+
+def test_reference_main_runs_on_the_gpu_through_the_boundary(gpu, pt, tmp_path):
+    """oracle/_ref/ref_main_dropin = the reference's main.c, unmodified, compiled against
+    include/raytracer.h and linked with libraytracer_amd.so (oracle/Makefile).  Its own scene
+    literal (main.c:256-397), its own init_camera()/render() calls and its own stb PNG writer,
+    with our GPU path behind render(): the image must be the oracle's for that scene."""
+    import os
+    import subprocess
+    from rt_amd import abi, scene as S
+    from util import decode_png_rgb8
+    exe = os.path.join(abi.REPO_ROOT, "oracle", "_ref", "ref_main_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_main_dropin not built (needs /root/reference at build time)")
+    out = str(tmp_path / "ref_main.png")
+    r = subprocess.run([exe, "-w", "96", "-h", "54", "-s", "8", "-o", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    img = decode_png_rgb8(out).reshape(-1, 3)
+    sc = S.build_scene(4, 96, 54, 8, max_depth=5)  # the library defaults: MAX_DEPTH 5, seed 1666943821
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert np.abs(img.astype(np.int16) - rgb8.astype(np.int16)).max() <= 1
+    rays = int([ln for ln in r.stdout.splitlines() if ln.startswith("cast ")][0].split()[1])
+    tests = int([ln for ln in r.stdout.splitlines() if ln.startswith("checked ")][0].split()[1])
+    assert (rays, tests) == (ost["rays"], ost["tests"])

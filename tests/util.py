@@ -72,3 +72,49 @@ def glass_scene(width=96, height=64, samples=8, max_depth=5):
         dict(flags=abi.M_DEFAULT, radius=6.0, center=(-4, 18, 6), color=(1, 1, 1), emission=(5, 5, 5)),
     ]
     return S.custom_scene(objs, width, height, samples, max_depth, (0, 6, 38), (0, 0, 0))
+
+
+def decode_png_rgb8(path):
+    """minimal PNG reader for 8-bit RGB, non-interlaced, all five filter types -> (h, w, 3) uint8"""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", None
+    while pos < len(data):
+        (n,), typ = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        if typ == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            assert (depth, ctype, interlace) == (8, 2, 0)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = zlib.decompress(idat)
+    stride, bpp = w * 3, 3
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        f = raw[y * (stride + 1)]
+        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=y * (stride + 1) + 1).astype(np.int32)
+        cur = np.zeros(stride, dtype=np.int32)
+        for i in range(stride):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if f == 0:
+                pred = 0
+            elif f == 1:
+                pred = a
+            elif f == 2:
+                pred = b
+            elif f == 3:
+                pred = (a + b) >> 1
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            cur[i] = (line[i] + pred) & 255
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, 3)
