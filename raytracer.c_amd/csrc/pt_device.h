@@ -24,6 +24,14 @@
  *   tri_tex    [n_triangles] x 6 f64 : st0, st1, st2 (read only for a winning triangle of an
  *       M_CHECKERED mesh).
  *   tri_object [n_triangles] u32     : material slot of the owning mesh.
+ *   bvh_src    [n_bvh_nodes] x 8 f64 : for meshes beyond PT_FILT_LDS_MAX primitives, a bounding-
+ *       volume hierarchy over the triangles in depth-first order: box min xyz, box max xyz,
+ *       then {skip, first, count} packed as three u32 + pad in the last two doubles.  `skip` =
+ *       index of the next node when this subtree is left (stackless traversal); leaves have
+ *       count > 0 and reference bvh_tri[first .. first+count).
+ *   bvh_nodes  [n_bvh_nodes] x 8 u32/f32 : the per-launch fp32 copy, boxes widened by a bound
+ *       on the fp32 ray/box arithmetic (pt_build_filter), same {skip, first, count} tail.
+ *   bvh_tri    [n_triangles] u32     : triangle indices in leaf order.
  */
 #ifndef PT_DEVICE_H
 #define PT_DEVICE_H
@@ -36,6 +44,8 @@
 #define PT_BLOCK 256        /* 4 wavefronts: 64 pixels x 4 slices */
 #define PT_MAT_STRIDE 8     /* doubles per material record */
 #define PT_FILT_LDS_MAX 256  /* primitives up to which the filter table is also staged in LDS */
+#define PT_BVH_LEAF 4         /* max triangles per BVH leaf */
+#define PT_BVH_NODE_WORDS 8   /* 32-byte device node: 6 f32 box + skip + (first << 3 | count) */
 #define PT_GEOM_STRIDE 4     /* LDS doubles per sphere: cx cy cz r2 */
 #define PT_FILT_STRIDE 5     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
 #define PT_ENTRY_SRC_STRIDE 6 /* HBM doubles per primitive: cx cy cz R2 |c| Rb (bounding data, fp64) */
@@ -57,8 +67,11 @@ struct PtSceneView
   const double *tri_normal;
   const double *tri_tex;
   const uint32_t *tri_object;
+  const double *bvh_src;
+  float *bvh_nodes;
+  const uint32_t *bvh_tri;
   uint32_t n_spheres, n_meshes, n_triangles, any_checker;
-  uint32_t any_refract, reserved_;
+  uint32_t any_refract, n_bvh_nodes; /* n_bvh_nodes == 0: triangles go through the flat filter */
 };
 
 struct PtCamera

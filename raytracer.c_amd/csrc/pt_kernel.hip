@@ -170,7 +170,11 @@ __device__ __forceinline__ void exact_sphere(const double *g, uint32_t index, co
   }
 }
 
-/* intersect_triangle :132-150 (Moeller-Trumbore, two-sided), exact.  g = v0, e1, e2. */
+/* intersect_triangle :132-150 (Moeller-Trumbore, two-sided), exact.  g = v0, e1, e2.
+ * TIE = false: candidates arrive in increasing index order, strict < keeps the first (the
+ * reference's rule).  TIE = true: they arrive in hierarchy order, so an equal t from a LOWER
+ * index must still win: the result is then the linear scan's, whatever the visiting order. */
+template <bool TIE = false>
 __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, const V3 &o, const V3 &d,
                                                double &min_t, int &best, double &bary_u, double &bary_v)
 {
@@ -189,7 +193,7 @@ __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, 
       if (!(v < 0.0 || u + v > 1.0))
       {
         double t = f * v_dot(e2, q);
-        if (t > kEps && t < min_t)
+        if (t > kEps && (t < min_t || (TIE && t == min_t && (int)index < best)))
         {
           min_t = t;
           best = (int)index;
@@ -198,6 +202,61 @@ __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, 
         }
       }
     }
+  }
+}
+
+/* Stackless walk of the triangle hierarchy (pt_device.h: bvh_nodes).  Per lane: node i's
+ * widened fp32 box against the ray by the slab test, in fp32, made conservative --
+ *   boxes were widened at launch by 4 e (near_R + |b|) (covers rounding o to fp32 and the
+ *   subtraction b - o), and the slab distances are widened by 4 e |t| (covers rounding d,
+ *   the reciprocal and the product; e = 2^-24) --
+ * so a box that contains an exact hit closer than min_t is never skipped.  v_min/v_max
+ * ignore NaN (0 * inf on an axis-parallel ray touching a slab plane), which leaves the
+ * other, correct bound.  Leaves run the exact fp64 triangle test. */
+__device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, uint32_t n_nodes,
+                                             const uint32_t *__restrict__ tri_order, const double *tri_geom,
+                                             uint32_t n_sph, bool far_origin, const V3 &o, const V3 &d,
+                                             double &min_t, int &best, double &bary_u, double &bary_v,
+                                             unsigned long long *diag_ptr)
+{
+  const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  const float ix = 1.0f / (float)d.x, iy = 1.0f / (float)d.y, iz = 1.0f / (float)d.z;
+  const float widen = 4.0f * 5.9604644775390625e-08f;
+  uint32_t i = 0;
+  while (i < n_nodes)
+  {
+    DIAG(13, 1);
+    const float4 a = *reinterpret_cast<const float4 *>(nodes + PT_BVH_NODE_WORDS * (size_t)i);
+    const float4 b = *reinterpret_cast<const float4 *>(nodes + PT_BVH_NODE_WORDS * (size_t)i + 4);
+    const uint32_t skip = __float_as_uint(b.z), packed = __float_as_uint(b.w);
+    const float tx1 = (a.x - ox) * ix, tx2 = (a.w - ox) * ix;
+    const float ty1 = (a.y - oy) * iy, ty2 = (b.x - oy) * iy;
+    const float tz1 = (a.z - oz) * iz, tz2 = (b.y - oz) * iz;
+    float tnear = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+    float tfar = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+    tnear -= fabsf(tnear) * widen;
+    tfar += fabsf(tfar) * widen;
+    /* min_t rounded up to fp32; a node starting beyond the closest hit so far cannot matter */
+    const float tmax = __double2float_ru(min_t);
+    const bool hit = far_origin || (tfar >= tnear && tfar >= 0.0f && tnear <= tmax);
+    if (!hit)
+    {
+      i = skip;
+      continue;
+    }
+    const uint32_t count = packed & 7u;
+    if (count == 0)
+    {
+      i = i + 1;
+      continue;
+    }
+    const uint32_t first = packed >> 3;
+    for (uint32_t k = 0; k < count; k++)
+    {
+      const uint32_t t = tri_order[first + k];
+      exact_triangle<true>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v);
+    }
+    i = skip;
   }
 }
 
@@ -210,13 +269,17 @@ struct SceneCtx;
  * tca threshold -(R + tol)).  The table lives in HBM and is read with a wave-uniform index,
  * i.e. by scalar loads through the constant cache into SGPRs: no LDS traffic, no VGPRs,
  * and no size limit -- a 10k-triangle mesh streams through at 20 B per primitive. */
-template <bool TRIS>
+template <bool TRIS, bool BVH>
 __device__ __forceinline__ void scan_filtered(const double *geom, const double *tri_geom,
                                               const f32x2 *__restrict__ filt, double near_R2, uint32_t n_sph,
                                               uint32_t n_entries, const V3 &o, const V3 &d, double &min_t,
                                               int &best, double &bary_u, double &bary_v,
-                                              unsigned long long *diag_ptr)
+                                              unsigned long long *diag_ptr, const float *bvh_nodes = nullptr,
+                                              uint32_t n_bvh_nodes = 0, const uint32_t *bvh_tri = nullptr)
 {
+  /* with a hierarchy the flat filter covers the spheres only */
+  if (BVH)
+    n_entries = n_sph;
   /* the ray in fp32 (round to nearest: relative error <= 2^-24, part of the bound) */
   const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
   const f32x2 dx = {(float)d.x, (float)d.x}, dy = {(float)d.y, (float)d.y}, dz = {(float)d.z, (float)d.z};
@@ -279,7 +342,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
         double t_probe = 1.7976931348623157e308, pu = 0, pv = 0;
         int b_probe = -1;
         const uint32_t i = base + k;
-        if (!TRIS || i < n_sph)
+        if (!TRIS || BVH || i < n_sph)
           exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, t_probe, b_probe);
         else
           exact_triangle(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, t_probe, b_probe, pu, pv);
@@ -307,12 +370,15 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       cand_lo = in_lo ? cleared : 0u;
       cand_hi = in_lo ? cand_hi : cleared;
       const uint32_t i = base + k;
-      if (!TRIS || i < n_sph)
+      if (!TRIS || BVH || i < n_sph)
         exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
       else
         exact_triangle(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v);
     }
   }
+  if (BVH)
+    bvh_traverse(bvh_nodes, n_bvh_nodes, bvh_tri, tri_geom, n_sph, far_origin, o, d, min_t, best, bary_u, bary_v,
+                 diag_ptr);
 }
 
 /* ---- scene as staged in LDS ------------------------------------------------------------ */
@@ -327,6 +393,9 @@ struct SceneCtx
   const uint32_t *tri_object;
   const f32x2 *filt;      /* HBM: ceil(n_entries/2) x PT_FILT_STRIDE packed-fp32 filter pairs */
   const f32x2 *filt_lds;  /* LDS copy of it when the scene is small (PT_FILT_LDS_MAX), else nullptr */
+  const float *bvh_nodes; /* HBM: triangle hierarchy of large meshes (n_bvh_nodes may be 0) */
+  const uint32_t *bvh_tri;
+  uint32_t n_bvh_nodes;
   double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
   uint32_t n_sph, n_tri;
   int max_depth;
@@ -371,6 +440,9 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.tri_object = sc.tri_object;
   ctx.filt = reinterpret_cast<const f32x2 *>(sc.filt);
   ctx.filt_lds = filt_lds;
+  ctx.bvh_nodes = sc.bvh_nodes;
+  ctx.bvh_tri = sc.bvh_tri;
+  ctx.n_bvh_nodes = sc.n_bvh_nodes;
   ctx.near_R2 = L.near_R2;
   ctx.n_sph = n_sph;
   ctx.n_tri = sc.n_triangles;
@@ -462,8 +534,9 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         exact_triangle(S.tri + 9 * (size_t)i, S.n_sph + i, o, d, min_t, best, bary_u, bary_v);
     }
     else
-      scan_filtered<TRIS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o,
-                          d, min_t, best, bary_u, bary_v, diag_ptr);
+      scan_filtered<TRIS, TRIS && !FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
+                                             S.n_sph + S.n_tri, o, d, min_t, best, bary_u, bary_v, diag_ptr,
+                                             S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri);
 
     if (best >= 0)
     {
@@ -936,6 +1009,28 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const Pt
  *   triangle: R2 = Rb^2 of its bounding sphere, Rb = that radius (the hit point is inside the
  *   bounding sphere, so the centre is at most Rb behind the origin).
  * Thresholds are rounded away from the accept region when stored as fp32. */
+/* fp32 hierarchy nodes for one launch: boxes widened by 4 e (near_R + |b|) and rounded
+ * outward (see bvh_traverse); tail = skip link and (first << 3 | count). */
+extern "C" __global__ __launch_bounds__(256) void pt_build_bvh(const double *bvh_src, uint32_t n_nodes, double near_R,
+                                                              float *nodes)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x)
+  {
+    const double *src = bvh_src + 8 * (size_t)i;
+    float *dst = nodes + PT_BVH_NODE_WORDS * (size_t)i;
+    const double e = 5.9604644775390625e-08;
+    for (int k = 0; k < 3; k++)
+    {
+      const double lo = src[k], hi = src[3 + k];
+      dst[k] = __double2float_rd(lo - 4.0 * e * (near_R + fabs(lo)));
+      dst[3 + k] = __double2float_ru(hi + 4.0 * e * (near_R + fabs(hi)));
+    }
+    const uint32_t *tail = reinterpret_cast<const uint32_t *>(src + 6); /* skip, first, count */
+    dst[6] = __uint_as_float(tail[0]);
+    dst[7] = __uint_as_float((tail[1] << 3) | tail[2]);
+  }
+}
+
 extern "C" __global__ __launch_bounds__(256) void pt_build_filter(const double *entry_src, uint32_t n_entries,
                                                                  double near_R, float *filt)
 {
@@ -1013,11 +1108,15 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   const size_t lds_bytes = pt_render_lds_bytes(launch.scene);
   {
     /* the filter table for this camera: a ~2 us kernel ahead of the render on the same stream */
-    const uint32_t n_entries = launch.scene.n_spheres + launch.scene.n_triangles;
+    const uint32_t n_nodes = launch.scene.n_bvh_nodes;
+    const uint32_t n_entries = launch.scene.n_spheres + (n_nodes ? 0u : launch.scene.n_triangles);
     const uint32_t blocks = n_entries ? min(1024u, (n_entries + 255u) / 256u) : 0u;
     if (blocks)
       hipLaunchKernelGGL(pt_build_filter, dim3(blocks), dim3(256), 0, stream, launch.scene.entry_src, n_entries,
                          launch.near_R, launch.scene.filt);
+    if (n_nodes)
+      hipLaunchKernelGGL(pt_build_bvh, dim3(min(1024u, (n_nodes + 255u) / 256u)), dim3(256), 0, stream,
+                         launch.scene.bvh_src, n_nodes, launch.near_R, launch.scene.bvh_nodes);
   }
   const bool tris = launch.scene.n_triangles != 0;
   const bool big = (size_t)launch.scene.n_spheres + launch.scene.n_triangles > PT_FILT_LDS_MAX;

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -104,6 +105,78 @@ void put_material(double *m, uint32_t flags, const double *color, const double *
   uint64_t bits = flags;
   memcpy(&m[7], &bits, sizeof bits);
 }
+
+/* ---- bounding-volume hierarchy over triangles (meshes beyond PT_FILT_LDS_MAX primitives) ----
+ * Median split on the longest axis of the centroid bounds, leaves of <= PT_BVH_LEAF
+ * triangles, nodes emitted in depth-first order with a `skip` link, so the device walks the
+ * tree without a stack: hit -> next node, miss or leaf done -> node[skip].  The hierarchy only
+ * decides WHICH triangles get the exact test; the exact test and the (t, index) tie rule
+ * decide the result, so any valid hierarchy gives the linear scan's answer. */
+struct BvhBuild
+{
+  const double *tgeom;              /* n_tri x 9: v0, e1, e2 */
+  std::vector<uint32_t> order;      /* triangle indices, permuted in place */
+  std::vector<double> nodes;        /* 8 doubles per node */
+  std::vector<double> cen, lo, hi;  /* per triangle: centroid, box */
+
+  void tri_box(uint32_t t)
+  {
+    const double *g = tgeom + 9 * (size_t)t;
+    for (int k = 0; k < 3; k++)
+    {
+      const double a = g[k], b = g[k] + g[3 + k], c = g[k] + g[6 + k]; /* v0, v0+e1, v0+e2 */
+      /* v1 = v0 + e1 is re-rounded here; the slack is absorbed by the device-side margins,
+       * which are orders of magnitude larger than one ulp of a coordinate */
+      lo[3 * t + k] = std::fmin(a, std::fmin(b, c));
+      hi[3 * t + k] = std::fmax(a, std::fmax(b, c));
+      cen[3 * t + k] = (a + b + c) / 3.0;
+    }
+  }
+
+  uint32_t build(uint32_t begin, uint32_t end)
+  {
+    const uint32_t me = (uint32_t)(nodes.size() / 8);
+    nodes.resize(nodes.size() + 8);
+    double bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
+    double cl[3] = {1e300, 1e300, 1e300}, ch[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = begin; i < end; i++)
+      for (int k = 0; k < 3; k++)
+      {
+        const uint32_t t = order[i];
+        bl[k] = std::fmin(bl[k], lo[3 * t + k]);
+        bh[k] = std::fmax(bh[k], hi[3 * t + k]);
+        cl[k] = std::fmin(cl[k], cen[3 * t + k]);
+        ch[k] = std::fmax(ch[k], cen[3 * t + k]);
+      }
+    uint32_t first = 0, count = 0;
+    if (end - begin <= PT_BVH_LEAF)
+    {
+      first = begin;
+      count = end - begin;
+    }
+    else
+    {
+      int axis = 0;
+      if (ch[1] - cl[1] > ch[axis] - cl[axis]) axis = 1;
+      if (ch[2] - cl[2] > ch[axis] - cl[axis]) axis = 2;
+      const uint32_t mid = begin + (end - begin) / 2;
+      std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end,
+                       [&](uint32_t a, uint32_t b) { return cen[3 * a + axis] < cen[3 * b + axis]; });
+      build(begin, mid);
+      build(mid, end);
+    }
+    const uint32_t skip = (uint32_t)(nodes.size() / 8);
+    double *n = &nodes[8 * (size_t)me];
+    for (int k = 0; k < 3; k++)
+    {
+      n[k] = bl[k];
+      n[3 + k] = bh[k];
+    }
+    uint32_t tail[4] = {skip, first, count, 0};
+    memcpy(&n[6], tail, sizeof tail);
+    return me;
+  }
+};
 
 /* development switch: RT_HIP_KERNEL_VARIANT=0 selects the literal single-phase scan */
 int kernel_variant()
@@ -258,6 +331,24 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
     }
   }
 
+  /* ---- hierarchy over the triangles of large meshes ---- */
+  BvhBuild bvh;
+  if (n_spheres + n_tri > PT_FILT_LDS_MAX && n_tri > 0)
+  {
+    bvh.tgeom = tgeom.data();
+    bvh.order.resize(n_tri);
+    bvh.cen.resize(3 * n_tri);
+    bvh.lo.resize(3 * n_tri);
+    bvh.hi.resize(3 * n_tri);
+    for (uint32_t k = 0; k < (uint32_t)n_tri; k++)
+    {
+      bvh.order[k] = k;
+      bvh.tri_box(k);
+    }
+    bvh.build(0, (uint32_t)n_tri);
+  }
+  const size_t n_bvh_nodes = bvh.nodes.size() / 8;
+
   /* ---- one device blob ---- */
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t off_geom = 0;
@@ -269,7 +360,10 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   const size_t off_filt = off_tobj + pad(tobj.size() * 4);
   /* + 1 pair: the scan's software pipeline reads one pair past the end */
   const size_t filt_bytes = ((n_spheres + n_tri + 1) / 2 + 1) * (size_t)PT_FILT_STRIDE * 2 * sizeof(float);
-  const size_t total = off_filt + pad(filt_bytes) + 256;
+  const size_t off_bvh_src = off_filt + pad(filt_bytes);
+  const size_t off_bvh_nodes = off_bvh_src + pad(bvh.nodes.size() * 8);
+  const size_t off_bvh_tri = off_bvh_nodes + pad(n_bvh_nodes * PT_BVH_NODE_WORDS * 4);
+  const size_t total = off_bvh_tri + pad(bvh.order.size() * 4) + 256;
 
   int prev = 0;
   HIP_TRY(hipGetDevice(&prev));
@@ -295,6 +389,8 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   if (e == hipSuccess) e = up(off_tnorm, tnorm.data(), tnorm.size() * 8);
   if (e == hipSuccess) e = up(off_ttex, ttex.data(), ttex.size() * 8);
   if (e == hipSuccess) e = up(off_tobj, tobj.data(), tobj.size() * 4);
+  if (e == hipSuccess) e = up(off_bvh_src, bvh.nodes.data(), bvh.nodes.size() * 8);
+  if (e == hipSuccess) e = up(off_bvh_tri, bvh.order.data(), bvh.order.size() * 4);
   (void)hipSetDevice(prev);
   if (e != hipSuccess)
   {
@@ -304,6 +400,10 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   }
   sc->view.entry_src = reinterpret_cast<const double *>(base + off_geom);
   sc->view.filt = reinterpret_cast<float *>(base + off_filt);
+  sc->view.bvh_src = reinterpret_cast<const double *>(base + off_bvh_src);
+  sc->view.bvh_nodes = reinterpret_cast<float *>(base + off_bvh_nodes);
+  sc->view.bvh_tri = reinterpret_cast<const uint32_t *>(base + off_bvh_tri);
+  sc->view.n_bvh_nodes = (uint32_t)n_bvh_nodes;
   sc->view.material = reinterpret_cast<const double *>(base + off_mat);
   sc->view.tri_geom = reinterpret_cast<const double *>(base + off_tgeom);
   sc->view.tri_normal = reinterpret_cast<const double *>(base + off_tnorm);

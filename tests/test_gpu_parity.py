@@ -320,3 +320,37 @@ def test_reference_main_runs_on_the_gpu_through_the_boundary(gpu, pt, tmp_path):
     rays = int([ln for ln in r.stdout.splitlines() if ln.startswith("cast ")][0].split()[1])
     tests = int([ln for ln in r.stdout.splitlines() if ln.startswith("checked ")][0].split()[1])
     assert (rays, tests) == (ost["rays"], ost["tests"])
+
+
+def test_config5_mesh_hierarchy_reduced(gpu, pt):
+    """BASELINE configs[4] scene (room + 10,240-triangle mesh) at reduced size: the triangles
+    go through the bounding-volume hierarchy on the device; the oracle scans them linearly.
+    Equal counters = every ray found the same closest primitive (incl. the tie rule)."""
+    from rt_amd import scene as S
+    sc = S.build_scene(5, 64, 36, 3)
+    st = _full(gpu, pt, sc)
+    assert st["tests"] == st["casts"] * (8 + 10240)
+    sc.free()
+
+
+def test_mesh_hierarchy_with_duplicate_triangles(gpu, pt):
+    """exact ties: every triangle of a mesh duplicated (same t from two indices) -- the lower
+    index must win under hierarchy order exactly as under the reference's linear order"""
+    import math
+    from rt_amd import abi, scene as S
+    tris = []
+    n = 12
+    for i in range(n):
+        for j in range(n):
+            x0, x1 = -12 + 2 * i, -10 + 2 * i
+            z0, z1 = -12 + 2 * j, -10 + 2 * j
+            y = 1.0 + 0.5 * math.sin(i) * math.cos(j)
+            a, b, c, d = (x0, y, z0), (x1, y, z0), (x1, y + 0.3, z1), (x0, y + 0.3, z1)
+            tris += [[a, c, b], [a, d, c]]
+    meshes = [dict(flags=abi.M_DEFAULT, color=(0.7, 0.6, 0.5), triangles=tris + tris),          # duplicated
+              dict(flags=abi.M_REFLECTION, color=(1, 1, 1), triangles=[[(-30, -3, -30), (30, -3, 30), (30, -3, -30)],
+                                                                          [(-30, -3, -30), (-30, -3, 30), (30, -3, 30)]])]
+    objs = [dict(flags=abi.M_DEFAULT, radius=5.0, center=(0, 14, 0), color=(1, 1, 1), emission=(6, 6, 6))]
+    sc = S.custom_scene(objs, 72, 40, 4, 6, (10, 14, 30), (0, 0, 0), meshes=meshes)
+    assert sc.n_triangles == 4 * n * n + 2 > 256
+    _full(gpu, pt, sc)
