@@ -41,12 +41,22 @@ RT_RNG_FN uint64_t rt_mix64(uint64_t z)
   return z;
 }
 
+/* The key is hashed in two steps so that the per-pixel half can be formed once per pixel. */
+RT_RNG_FN uint64_t rt_rng_pixel_key(uint64_t seed, uint32_t pixel)
+{
+  return rt_mix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)pixel + 1u));
+}
+
+RT_RNG_FN uint64_t rt_rng_sample_state(uint64_t pixel_key, uint32_t sample)
+{
+  const uint64_t h = rt_mix64(pixel_key + 0xD1B54A32D192ED03ull * ((uint64_t)sample + 1u));
+  return h ? h : 0x9E3779B97F4A7C15ull; /* xorshift state must be non-zero */
+}
+
 /* State for sample `sample` of pixel `pixel` under global seed `seed`. */
 RT_RNG_FN uint64_t rt_rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample)
 {
-  uint64_t h = rt_mix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)pixel + 1u));
-  h = rt_mix64(h + 0xD1B54A32D192ED03ull * ((uint64_t)sample + 1u));
-  return h ? h : 0x9E3779B97F4A7C15ull; /* xorshift state must be non-zero */
+  return rt_rng_sample_state(rt_rng_pixel_key(seed, pixel), sample);
 }
 
 /* Next rand()-compatible draw: 31 uniform bits. */

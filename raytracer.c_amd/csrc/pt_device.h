@@ -90,6 +90,7 @@ struct PtLaunch
    * they would occupy -- and spill -- vector registers): near_R^2, width-1, height-1 as the
    * reference forms them, (double)options->width - 1.0 (raytracer.c:203-204) */
   double near_R2, w_minus_1, h_minus_1;
+  double inv_w_minus_1, inv_h_minus_1; /* RN(1/(W-1)), RN(1/(H-1)) for div_small_int */
   double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
   uint32_t sample_chunks, reserved_; /* workgroups per tile: each renders 1/sample_chunks of the samples */

@@ -474,7 +474,7 @@ struct PendingRay
 struct CameraRegs
 {
   V3 pos, horizontal, vertical, llc;
-  double w_minus_1, h_minus_1;
+  double w_minus_1, h_minus_1, inv_w_minus_1, inv_h_minus_1;
 };
 
 __device__ __forceinline__ CameraRegs load_camera(const PtLaunch &L)
@@ -486,16 +486,35 @@ __device__ __forceinline__ CameraRegs load_camera(const PtLaunch &L)
   c.llc = ld3(L.cam.llc);
   c.w_minus_1 = L.w_minus_1;
   c.h_minus_1 = L.h_minus_1;
+  c.inv_w_minus_1 = L.inv_w_minus_1;
+  c.inv_h_minus_1 = L.inv_h_minus_1;
   return c;
 }
 
-/* raytracer.c:203-206 + get_camera_ray :375-384, stream re-seeded per (pixel, sample) */
-__device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uint64_t seed, uint32_t px,
-                                             uint32_t py, uint32_t pixel, uint32_t s)
+/* a / b, correctly rounded, for a >= 0 and an INTEGER 1 <= b < 2^20, given y = RN(1/b)
+ * (formed on the host): q0 = RN(a y); r = a - b q0 (exact: a multiple of ulp(q0) below
+ * 2.01 b ulp(q0), so it fits 53 bits); q = RN(q0 + r y).
+ *   |q0 - a/b| <= 2.01 2^-53 a/b, and q0 + r y = a/b + (r/b) eta with |eta| <= 2^-53, i.e. the
+ *   final rounding sees a/b perturbed by <= 2.01 2^-106 a/b.  A quotient by an odd integer
+ *   b is never a rounding midpoint, and its distance from one is >= ulp(q) / (2 b) >= 2^-74
+ *   relative -- 2^32 times the perturbation -- so RN(q0 + r y) = RN(a/b).  (Even b = 2^k b':
+ *   scale by 2^-k first, exact.)  3 instructions instead of the ~14 of an fp64 division
+ *   (tests/test_host.py checks the identity with exact rational arithmetic). */
+__device__ __forceinline__ double div_small_int(double a, double b, double y)
 {
-  P.rng = rt_rng_seed(seed, pixel, s);
-  const double u = ((double)px + rnd(P.rng)) / cam.w_minus_1;
-  const double v = ((double)py + rnd(P.rng)) / cam.h_minus_1;
+  const double q0 = a * y;
+  const double r = __builtin_fma(-q0, b, a);
+  return __builtin_fma(r, y, q0);
+}
+
+/* raytracer.c:203-206 + get_camera_ray :375-384, stream re-seeded per (pixel, sample) */
+__device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uint64_t pixel_key, uint32_t px,
+                                             uint32_t py, uint32_t s)
+{
+  P.rng = rt_rng_sample_state(pixel_key, s);
+  /* (x + rnd) / (W - 1): exactly the reference's quotient, see div_small_int */
+  const double u = div_small_int((double)px + rnd(P.rng), cam.w_minus_1, cam.inv_w_minus_1);
+  const double v = div_small_int((double)py + rnd(P.rng), cam.h_minus_1, cam.inv_h_minus_1);
   const V3 on_plane = v_add(cam.llc, v_add(v_scale(cam.horizontal, u), v_scale(cam.vertical, v)));
   P.o = cam.pos;
   P.d = v_normalize(v_sub(cam.pos, on_plane));
@@ -758,12 +777,19 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
   __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3]; /* fixed-point radiance sums */
+  __shared__ unsigned long long pix_key[PT_TILE_PIXELS];     /* per-pixel half of the RNG key */
 
   const SceneCtx S = stage_scene(L, lds);
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
   if (threadIdx.x < PT_TILE_PIXELS * 3)
     pix_sum[threadIdx.x] = 0;
+  if (threadIdx.x < PT_TILE_PIXELS)
+  {
+    const uint32_t t0 = L.tile_first + (blockIdx.x % L.tile_count) * L.tile_stride;
+    const uint32_t kx = (t0 % L.tiles_x) * PT_TILE + (threadIdx.x & 7u), ky = (t0 / L.tiles_x) * PT_TILE + (threadIdx.x >> 3);
+    pix_key[threadIdx.x] = rt_rng_pixel_key(L.seed, ky * (uint32_t)L.width + kx);
+  }
   __syncthreads();
 
   /* ---- this wave's pixels and job pool ---- */
@@ -827,7 +853,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         const uint32_t col = idx - row * vcols;
         const uint32_t px = tx0 + col, py = ty0 + row;
         pix_slot = (2u * wave + row) * PT_TILE + col;
-        start_sample(P, cam, L.seed, px, py, py * (uint32_t)L.width + px, s_begin + s);
+        start_sample(P, cam, pix_key[pix_slot], px, py, s_begin + s);
         busy = true;
       }
       next_job += (uint32_t)__popcll(idle);
@@ -942,7 +968,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
     {
       DIAG(6, 1);
       DIAG_LANES(7);
-      start_sample(P, cam, L.seed, px, py, pixel, s);
+      start_sample(P, cam, rt_rng_pixel_key(L.seed, pixel), px, py, s);
       fresh = false;
     }
     n_rays++;

@@ -203,6 +203,8 @@ int check_params(const RtHipParams *p)
     return fail(RT_HIP_EINVAL, "max_depth out of range");
   if ((uint64_t)p->width * (uint64_t)p->height > 0xFFFFFFFFull)
     return fail(RT_HIP_EINVAL, "image has more than 2^32 pixels");
+  if (p->width > (1 << 20) || p->height > (1 << 20))
+    return fail(RT_HIP_EINVAL, "width and height must not exceed 2^20 (the kernel's exact-quotient shortcut)");
   return RT_HIP_OK;
 }
 
@@ -520,6 +522,8 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     L.near_R2 = L.near_R * L.near_R;
     L.w_minus_1 = (double)params->width - 1.0;
     L.h_minus_1 = (double)params->height - 1.0;
+    L.inv_w_minus_1 = 1.0 / L.w_minus_1; /* IEEE division on the host: correctly rounded */
+    L.inv_h_minus_1 = 1.0 / L.h_minus_1;
   }
   {
     /* Fixed-point scale of the per-pixel sums (pt_render_tiles): a sample's radiance is

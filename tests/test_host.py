@@ -244,3 +244,27 @@ def test_fused_range_mapping_is_exact():
         ref = (r / 2147483648.0) * (1.0 - -1.0) + -1.0
         exact = Fraction(r, 2**30) - 1
         assert Fraction(ref) == exact  # no rounding anywhere: any evaluation order agrees
+
+
+def test_division_by_small_integer_shortcut_is_exact():
+    """div_small_int() in pt_kernel.hip: q0 = RN(a*y), r = fma(-q0, b, a), q = fma(r, y, q0) with
+    y = RN(1/b) equals RN(a/b) for the numerators (x + r/2^31) and divisors (W-1, H-1) of
+    raytracer.c:203-204.  Emulated here with exact rationals (float(Fraction) rounds correctly)."""
+    from fractions import Fraction as Fr
+    rng = np.random.default_rng(9)
+
+    def fma(x, y, z):
+        return float(Fr(x) * Fr(y) + Fr(z))
+
+    divisors = [1, 2, 3, 7, 255, 599, 799, 1079, 1919, 2159, 3839, 4095, 65535, (1 << 20) - 1, (1 << 20)]
+    for b in divisors:
+        bf = float(b)
+        y = 1.0 / bf
+        xs = list(rng.integers(0, b + 1, 300)) + [0, 1, b - 1, b]
+        for x in xs:
+            for k in [0, 1, 2**31 - 1, 2**30, int(rng.integers(0, 2**31)), int(rng.integers(0, 2**31))]:
+                a = float(x) + k / 2147483648.0
+                q0 = a * y
+                r = fma(-q0, bf, a)
+                q = fma(r, y, q0)
+                assert q == a / bf, (a, b)
