@@ -269,7 +269,24 @@ struct SceneCtx;
  * tca threshold -(R + tol)).  The table lives in HBM and is read with a wave-uniform index,
  * i.e. by scalar loads through the constant cache into SGPRs: no LDS traffic, no VGPRs,
  * and no size limit -- a 10k-triangle mesh streams through at 20 B per primitive. */
-template <bool TRIS, bool BVH>
+/* word = 2 * word + keep, keep = !(tca < neg_tol) && !(d2 > r2_hi), in three VALU instructions:
+ * the two compares (NaN-aware: a NaN keeps the primitive, as it passes both reference tests),
+ * and an add-with-carry that shifts the result bit in.  The compiler's own sequence for
+ * `word |= keep << k` is compare, compare, move, select, or. */
+__device__ __forceinline__ uint32_t push_keep_bit(uint32_t word, float tca, float neg_tol, float d2, float r2_hi)
+{
+  unsigned long long tmp;
+  asm("v_cmp_nlt_f32 vcc, %2, %3\n\t"
+               "v_cmp_ngt_f32 %1, %4, %5\n\t"
+               "s_and_b64 vcc, vcc, %1\n\t"
+               "v_addc_co_u32 %0, vcc, %0, %0, vcc"
+               : "+v"(word), "=&s"(tmp)
+               : "v"(tca), "v"(neg_tol), "v"(d2), "v"(r2_hi)
+               : "vcc", "scc"); /* s_and_b64 also writes SCC */
+  return word;
+}
+
+template <bool TRIS, bool BVH, bool FILT_LDS>
 __device__ __forceinline__ void scan_filtered(const double *geom, const double *tri_geom,
                                               const f32x2 *__restrict__ filt, double near_R2, uint32_t n_sph,
                                               uint32_t n_entries, const V3 &o, const V3 &d, double &min_t,
@@ -303,29 +320,59 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
       const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, lx * lx));
       const f32x2 d2 = __builtin_elementwise_fma(-tca, tca, ll);
-      /* bitwise |: no short-circuit branch.  NaNs compare false and stay candidates. */
-      const bool drop0 = (bool)((int)(tca.x < g.neg_tol.x) | (int)(d2.x > g.r2_hi.x));
-      const bool drop1 = (bool)((int)(tca.y < g.neg_tol.y) | (int)(d2.y > g.r2_hi.y));
-      word |= (drop0 ? 0u : (1u << shift)) | (drop1 ? 0u : (2u << shift));
+      if (FILT_LDS)
+      { /* pairs arrive in DESCENDING order, so shifting bits in leaves bit k = primitive k */
+        word = push_keep_bit(word, tca.y, g.neg_tol.y, d2.y, g.r2_hi.y);
+        word = push_keep_bit(word, tca.x, g.neg_tol.x, d2.x, g.r2_hi.x);
+      }
+      else
+      {
+        /* bitwise |: no short-circuit branch.  NaNs compare false and stay candidates. */
+        const bool drop0 = (bool)((int)(tca.x < g.neg_tol.x) | (int)(d2.x > g.r2_hi.x));
+        const bool drop1 = (bool)((int)(tca.y < g.neg_tol.y) | (int)(d2.y > g.r2_hi.y));
+        word |= (drop0 ? 0u : (1u << shift)) | (drop1 ? 0u : (2u << shift));
+      }
     };
     const uint32_t n_pairs = (chunk + 1u) >> 1;
-    /* software pipeline: the scalar loads of pair p+1 are in flight while pair p computes
-     * (the table is padded to a whole number of pairs, and one pair past the end) */
-    PairRec cur = load_pair(0);
     const uint32_t pairs_lo = min(n_pairs, 16u);
-#pragma unroll 2
-    for (uint32_t p = 0; p < pairs_lo; p++)
+    if (FILT_LDS)
     {
-      const PairRec nxt = load_pair(p + 1);
-      filter_pair(cur, cand_lo, 2u * p);
-      cur = nxt;
+      /* descending pair order (see filter_pair); the LDS reads of the next pair are issued
+       * before the current one computes */
+      /* (unrolled by hand: inline asm is convergent, which rules out runtime unrolling) */
+      auto run_desc = [&](uint32_t top, uint32_t count, uint32_t &word) {
+        uint32_t q = 0;
+        for (; q + 2 <= count; q += 2)
+        {
+          const PairRec a = load_pair(top - q), b = load_pair(top - q - 1u);
+          filter_pair(a, word, 0);
+          filter_pair(b, word, 0);
+        }
+        for (; q < count; q++)
+          filter_pair(load_pair(top - q), word, 0);
+      };
+      run_desc(pairs_lo - 1u, pairs_lo, cand_lo);
+      run_desc(n_pairs - 1u, n_pairs - pairs_lo, cand_hi);
     }
-#pragma unroll 2
-    for (uint32_t p = 16; p < n_pairs; p++)
+    else
     {
-      const PairRec nxt = load_pair(p + 1);
-      filter_pair(cur, cand_hi, 2u * (p - 16u));
-      cur = nxt;
+      /* software pipeline: the scalar loads of pair p+1 are in flight while pair p computes
+       * (the table is padded to a whole number of pairs, and one pair past the end) */
+      PairRec cur = load_pair(0);
+#pragma unroll 2
+      for (uint32_t p = 0; p < pairs_lo; p++)
+      {
+        const PairRec nxt = load_pair(p + 1);
+        filter_pair(cur, cand_lo, 2u * p);
+        cur = nxt;
+      }
+#pragma unroll 2
+      for (uint32_t p = 16; p < n_pairs; p++)
+      {
+        const PairRec nxt = load_pair(p + 1);
+        filter_pair(cur, cand_hi, 2u * (p - 16u));
+        cur = nxt;
+      }
     }
     /* entries that exist in this chunk (an odd count leaves one padding slot) */
     const uint32_t valid_lo = chunk >= 32u ? 0xFFFFFFFFu : ((1u << chunk) - 1u);
@@ -553,7 +600,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         exact_triangle(S.tri + 9 * (size_t)i, S.n_sph + i, o, d, min_t, best, bary_u, bary_v);
     }
     else
-      scan_filtered<TRIS, TRIS && !FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
+      scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
                                              S.n_sph + S.n_tri, o, d, min_t, best, bary_u, bary_v, diag_ptr,
                                              S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri);
 
