@@ -105,6 +105,7 @@ struct PtLaunch
 /* host-side launchers, defined next to the kernels in pt_kernel.hip */
 size_t pt_render_lds_bytes(const PtSceneView &scene);
 hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant);
+hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream);
 hipError_t pt_launch_untile(const float *tiles_rgb, const uint8_t *tiles_rgb8, int width, int height,
                             uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count, float *image_rgb,
                             uint8_t *image_rgb8, hipStream_t stream);

@@ -147,6 +147,26 @@ constexpr double kPi = 3.14159265359; /* raytracer.h:22 */
  */
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+/* Correctly rounded sqrt for x == 0 or x >= 2^-767: hipcc's own fp64 expansion (v_rsq_f64 +
+ * two Goldschmidt steps + two residual corrections) minus its input/output scaling, which
+ * only acts below 2^-767.  Same instructions on the same values => the same result as
+ * sqrt(x) there.  In intersect_sphere x = r*r - d2 is zero or at least half an ulp of r*r, and
+ * rt_hip_scene_create rejects radii below 1e-100, so the precondition always holds. */
+__device__ __forceinline__ double sqrt_unscaled(double x)
+{
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d0 = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d0, h, g);
+  const double d1 = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d1, h, g);
+  return x == 0.0 ? x : g;
+}
+
 /* intersect_sphere :82-117, exact.  Updates (min_t, best) with strict <. */
 __device__ __forceinline__ void exact_sphere(const double *g, uint32_t index, const V3 &o, const V3 &d,
                                              double &min_t, int &best)
@@ -157,7 +177,7 @@ __device__ __forceinline__ void exact_sphere(const double *g, uint32_t index, co
   double r2 = g[3];
   if (!(tca < 0) && !(d2 > r2))
   {
-    double thc = sqrt(r2 - d2);
+    double thc = sqrt_unscaled(r2 - d2);
     /* t0 <= t1 always (thc >= 0 or NaN): the reference's swap (:95-100) is dead code */
     double t0 = tca - thc, t1 = tca + thc;
     if (t0 < 0)
@@ -617,7 +637,9 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       if (!is_tri)
       {
         const double *g = S.geom + PT_GEOM_STRIDE * best;
-        n = v_normalize(v_sub(p, ld3(g)));
+        /* |p - c|^2 ~ r*r >= 1e-200: inside sqrt_unscaled's domain */
+        const V3 pc = v_sub(p, ld3(g));
+        n = v_scale(pc, 1.0 / sqrt_unscaled(v_dot(pc, pc)));
         slot = (uint32_t)best;
       }
       else
@@ -714,7 +736,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
              * square root is taken once, after the loop (tests/test_host.py checks the
              * equivalence around the boundary). */
           } while (len2 > 1.0000000000000002 && ++tries < 100);
-          const double len = sqrt(len2);
+          /* len2 is 0 or >= 2^-60 (coordinates are multiples of 2^-30): sqrt_unscaled's domain */
+          const double len = sqrt_unscaled(len2);
           nd = v_scale(q, 1.0 / len);
           if (v_dot(nd, n) < 0)
             nd = v_scale(nd, -1);
@@ -1067,6 +1090,36 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const Pt
   if (L.tiles_rgb8 && threadIdx.x < PT_TILE_PIXELS * 3 / 4)
     reinterpret_cast<uint32_t *>(L.tiles_rgb8)[(size_t)slot * (PT_TILE_PIXELS * 3 / 4) + threadIdx.x] =
         reinterpret_cast<const uint32_t *>(out_b)[threadIdx.x];
+}
+
+/* Self-test hook (rt_hip_selftest_math): evaluates the kernel's exact-arithmetic shortcuts
+ * on caller data so a test can compare them bit for bit with the host's IEEE results.
+ * op 0: sqrt_unscaled(a[i]);  op 1: div_small_int(a[i], b[i], 1/b[i]);  op 2: the library
+ * sqrt(a[i]);  op 3: a[i] / b[i];  op 4: rnd_pm1-style fused r * 2^-30 - 1 with r = a[i]. */
+extern "C" __global__ __launch_bounds__(256) void pt_selftest_math(int op, const double *a, const double *b,
+                                                                  double *out, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+  {
+    double r = 0;
+    if (op == 0)
+      r = sqrt_unscaled(a[i]);
+    else if (op == 1)
+      r = div_small_int(a[i], b[i], 1.0 / b[i]);
+    else if (op == 2)
+      r = sqrt(a[i]);
+    else if (op == 3)
+      r = a[i] / b[i];
+    else if (op == 4)
+      r = __builtin_fma(a[i], 1.0 / 1073741824.0, -1.0);
+    out[i] = r;
+  }
+}
+
+hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream)
+{
+  hipLaunchKernelGGL(pt_selftest_math, dim3(256), dim3(256), 0, stream, op, a, b, out, n);
+  return hipGetLastError();
 }
 
 /* Builds the packed-fp32 phase-1 filter table for one launch (the thresholds depend on

@@ -246,6 +246,8 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   {
     any_refract |= (spheres[i].flags & PT_FLAG_REFRACT) != 0;
     any_checker |= (spheres[i].flags & PT_FLAG_CHECKER) != 0;
+    if (!(std::fabs(spheres[i].radius) >= 1e-100) || !(std::fabs(spheres[i].radius) <= 1e100))
+      return fail(RT_HIP_ELIMIT, "sphere %zu: |radius| %g outside [1e-100, 1e100]", i, spheres[i].radius);
   }
   for (size_t m = 0; m < n_meshes; m++)
   {
@@ -560,6 +562,30 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     (void)hipSetDevice(prev);
   if (e != hipSuccess)
     return fail(RT_HIP_ERUNTIME, "pt_render_tiles launch: %s", hipGetErrorString(e));
+  return RT_HIP_OK;
+}
+
+int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h_out, size_t n, int device)
+{
+  if (!h_a || !h_b || !h_out || op < 0 || op > 4)
+    return fail(RT_HIP_EINVAL, "bad self-test arguments");
+  if (device < 0 || device >= usable_devices())
+    return fail(RT_HIP_ENODEV, "no HIP device %d", device);
+  if (n == 0)
+    return RT_HIP_OK;
+  int prev = 0;
+  HIP_TRY(hipGetDevice(&prev));
+  HIP_TRY(hipSetDevice(device));
+  double *d = nullptr;
+  hipError_t e = hipMalloc(&d, 3 * n * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(d, h_a, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + n, h_b, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = pt_launch_selftest(op, d, d + n, d + 2 * n, n, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(h_out, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess)
+    return fail(RT_HIP_ERUNTIME, "self-test: %s", hipGetErrorString(e));
   return RT_HIP_OK;
 }
 

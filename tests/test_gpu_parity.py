@@ -354,3 +354,40 @@ def test_mesh_hierarchy_with_duplicate_triangles(gpu, pt):
     sc = S.custom_scene(objs, 72, 40, 4, 6, (10, 14, 30), (0, 0, 0), meshes=meshes)
     assert sc.n_triangles == 4 * n * n + 2 > 256
     _full(gpu, pt, sc)
+
+
+def test_device_math_shortcuts_are_bit_exact(gpu):
+    """the kernel's exact-arithmetic shortcuts, evaluated on the device, against IEEE results on
+    the host: sqrt without range scaling, division by a small integer through its reciprocal,
+    the library sqrt / division themselves (correct rounding is what parity rests on)"""
+    import ctypes as C
+    from rt_amd import abi
+    shim = abi.load_shim()
+    rng = np.random.default_rng(12)
+
+    def run(op, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.zeros_like(a)
+        rc = shim.rt_hip_selftest_math(op, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size, 0)
+        assert rc == 0, shim.rt_hip_last_error()
+        return out
+
+    # sqrt: values shaped like r*r - d2 (cancellation leftovers), plain ranges, exact squares, zero
+    r2 = rng.uniform(0.5, 9, 200000) ** 2
+    x = np.concatenate([r2 - r2 * rng.uniform(0, 1, r2.size), 1e8 - rng.uniform(0, 1.2e6, 100000),
+                        10.0 ** rng.uniform(-200, 200, 100000), rng.integers(1, 1 << 26, 50000).astype(np.float64) ** 2,
+                        np.array([0.0, 1.0, 4.0, 2.0 ** -766, 2.0 ** -700, 1e-300 * 0 + 5e-217])])
+    x = np.abs(x)
+    one = np.ones_like(x)
+    want = np.sqrt(x)
+    assert np.array_equal(run(2, x, one), want), "library sqrt is not correctly rounded"
+    assert np.array_equal(run(0, x, one), want), "unscaled sqrt differs from IEEE sqrt"
+    # division by small integers (W-1, H-1) of numerators x + r / 2^31
+    b = rng.choice([1, 2, 3, 255, 599, 799, 1079, 1919, 2159, 3839, 65535, (1 << 20) - 1], size=400000).astype(np.float64)
+    a = np.floor(rng.uniform(0, 1, b.size) * (b + 1)) + rng.integers(0, 1 << 31, b.size) / 2147483648.0
+    assert np.array_equal(run(3, a, b), a / b), "IEEE division differs"
+    assert np.array_equal(run(1, a, b), a / b), "reciprocal shortcut differs from IEEE division"
+    # fused [-1, 1) mapping
+    r = rng.integers(0, 1 << 31, 200000).astype(np.float64)
+    assert np.array_equal(run(4, r, r), (r / 2147483648.0) * (1.0 - -1.0) + -1.0)
