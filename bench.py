@@ -39,7 +39,7 @@ def measured_traffic(config, width, height, spp, world):
     """HBM bytes per launch from the committed PMC passes (profiles/), when this run is the
     profiled configuration; None otherwise (PMC counters cannot be collected from inside)."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r01e_traffic.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_c4.json")))
         if (rec["config"], rec["width"], rec["height"], rec["spp"], rec["n_gpus"]) == (config, width, height, spp, world):
             return rec["traffic_bytes_per_launch"]
     except Exception:
@@ -235,7 +235,7 @@ def main():
                              "achieved": alg_bytes / kern_s * 1e-9 if kern_s > 0 else 0.0, "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": (alg_bytes / kern_s * 1e-9 / PEAK_HBM_GBS) if kern_s > 0 else 0.0,
                              "traffic": measured_traffic(args.config, W, H, spp, world),
-                             "traffic_source": "profiles/r01e_pmc_c4.txt (rocprofv3 --pmc, separate passes)",
+                             "traffic_source": "profiles/traffic_c4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                              "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and args.cpu_tiles > 0:
