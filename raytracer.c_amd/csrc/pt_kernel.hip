@@ -838,8 +838,10 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 5
 #endif
-/* FANCY = the scene has M_REFRACTION or M_CHECKERED materials */
-template <bool FANCY, bool TRIS, bool FILT_LDS>
+/* Pooled kernel body.  Not for scenes with M_REFRACTION: there the throughput is not bounded
+ * by 1 (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes
+ * negative), so no fixed-point scale can be fixed in advance; those scenes use the static body. */
+template <bool CHECKER, bool TRIS, bool FILT_LDS>
 __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 {
   extern __shared__ double lds[];
@@ -891,8 +893,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   uint32_t next_job = 0;     /* wave-uniform */
   uint32_t pix_slot = 0;     /* 0..63 inside the tile */
   bool busy = false;
-  PendingRay stack[FANCY ? PT_REFRACT_STACK : 1];
-  int stack_n = 0;
+  int stack_n = 0; /* no pending-ray stack in this body */
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
 
@@ -936,7 +937,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      if (trace_step<1, FANCY, FANCY, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, stack, stack_n))
+      if (trace_step<1, false, CHECKER, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, nullptr, stack_n))
       {
         /* sample done: add to the pixel's fixed-point sum (integer adds commute: the
          * result does not depend on which lane finishes first) */
@@ -971,28 +972,33 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   }
 }
 
-/* Kernel family: pt_render_tiles[_tri][_big][_fancy].  The host picks by scene content
+/* Kernel family pt_render_tiles[_tri][_big][_chk|_refr], picked by scene content
  * (pt_launch_render): "_tri" = scene has triangles, "_big" = more than PT_FILT_LDS_MAX
- * primitives (filter table streamed by scalar loads instead of LDS), "_fancy" = scene has
- * M_REFRACTION materials (per-lane stack of pending second children in private memory) or
- * M_CHECKERED ones (atan2 / fmod).  pt_render_tiles itself is the headline configuration:
- * diffuse / mirror / emissive spheres, small scene. */
-#define PT_KERNEL(name, bounds, FANCY, TRIS, FILT_LDS)                                       \
-  extern "C" __global__ bounds void name(const PtLaunch L) { render_tiles_pooled<FANCY, TRIS, FILT_LDS>(L); }
+ * primitives (filter table by scalar loads, triangles through the hierarchy), "_chk" = scene
+ * has M_CHECKERED materials (atan2 / fmod), "_refr" = scene has M_REFRACTION materials
+ * (static body + per-lane stack of pending second children; also covers M_CHECKERED).
+ * pt_render_tiles itself is the headline configuration: diffuse / mirror / emissive spheres,
+ * small scene. */
+#define PT_KERNEL(name, bounds, CHECKER, TRIS, FILT_LDS)                                     \
+  extern "C" __global__ bounds void name(const PtLaunch L) { render_tiles_pooled<CHECKER, TRIS, FILT_LDS>(L); }
 PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, true)
 PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
 PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, true, true)
 PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, true, false)
-PT_KERNEL(pt_render_tiles_fancy, __launch_bounds__(PT_BLOCK), true, false, true)
-PT_KERNEL(pt_render_tiles_big_fancy, __launch_bounds__(PT_BLOCK), true, false, false)
-PT_KERNEL(pt_render_tiles_tri_fancy, __launch_bounds__(PT_BLOCK), true, true, true)
-PT_KERNEL(pt_render_tiles_tri_big_fancy, __launch_bounds__(PT_BLOCK), true, true, false)
+PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK), true, false, true)
+PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK), true, false, false)
+PT_KERNEL(pt_render_tiles_tri_chk, __launch_bounds__(PT_BLOCK), true, true, true)
+PT_KERNEL(pt_render_tiles_tri_big_chk, __launch_bounds__(PT_BLOCK), true, true, false)
 #undef PT_KERNEL
 
-/* ---- plain kernel: static (pixel, slice) lanes, literal scan, fp64 sums ------------------
- * Selected by RT_HIP_KERNEL_VARIANT=0.  Lane l of wave w: pixel (l >> 2) of the wave's 16,
- * sample slice (l & 3): samples s = slice, slice + 4, ... */
-extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const PtLaunch L)
+/* ---- static body: lane = (pixel, sample slice), fp64 partial sums ------------------------
+ * Lane l of wave w: pixel (l >> 2) of the wave's 16, sample slice (l & 3): samples s = slice,
+ * slice + 4, ...; the four slice sums of a pixel are combined by xor-shuffles in a fixed
+ * order.  Floating-point sums have no range limit, which is what scenes with M_REFRACTION
+ * need (see render_tiles_pooled); VARIANT 0 of it is the plain reference kernel
+ * (RT_HIP_KERNEL_VARIANT=0). */
+template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS>
+__device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
 {
   extern __shared__ double lds[];
   __shared__ float out_f[PT_TILE_PIXELS * 3];
@@ -1026,7 +1032,8 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
   uint32_t n_rays = 0, n_casts = 0;
   uint32_t s = inside ? slice : spp;
   bool fresh = true;
-  int no_stack = 0;
+  PendingRay stack[REFRACT ? PT_REFRACT_STACK : 1];
+  int stack_n = 0;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
 
@@ -1042,7 +1049,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
       fresh = false;
     }
     n_rays++;
-    if (trace_step<0, false, true, true, false>(S, P, n_casts, diag_ptr, nullptr, no_stack))
+    if (trace_step<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, stack, stack_n))
     {
       acc = v_add(acc, P.Ls);
       s += PT_SLICES;
@@ -1075,6 +1082,18 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_v0(const 
   __syncthreads();
   store_tile(L, out_f, out_b, wg_stats, tile, blockIdx.x, S.n_sph + S.n_tri, true, true);
 }
+
+#define PT_KERNEL_STATIC(name, VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS)                    \
+  extern "C" __global__ __launch_bounds__(PT_BLOCK) void name(const PtLaunch L)             \
+  {                                                                                         \
+    render_tiles_static<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS>(L);                      \
+  }
+PT_KERNEL_STATIC(pt_render_tiles_v0, 0, false, true, true, false)
+PT_KERNEL_STATIC(pt_render_tiles_refr, 1, true, true, false, true)
+PT_KERNEL_STATIC(pt_render_tiles_big_refr, 1, true, true, false, false)
+PT_KERNEL_STATIC(pt_render_tiles_tri_refr, 1, true, true, true, true)
+PT_KERNEL_STATIC(pt_render_tiles_tri_big_refr, 1, true, true, true, false)
+#undef PT_KERNEL_STATIC
 
 /* Second pass of a chunked render: per-tile fixed-point sums -> float3 + tonemapped bytes. */
 extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const PtLaunch L)
@@ -1246,15 +1265,16 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }
   const bool tris = launch.scene.n_triangles != 0;
   const bool big = (size_t)launch.scene.n_spheres + launch.scene.n_triangles > PT_FILT_LDS_MAX;
-  const bool refr = launch.scene.any_refract != 0 || launch.scene.any_checker != 0; /* "fancy" */
+  const bool refr = launch.scene.any_refract != 0, chk = launch.scene.any_checker != 0;
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[8] = {pt_render_tiles,         pt_render_tiles_big,       pt_render_tiles_tri,
-                                   pt_render_tiles_tri_big, pt_render_tiles_fancy,     pt_render_tiles_big_fancy,
-                                   pt_render_tiles_tri_fancy, pt_render_tiles_tri_big_fancy};
-  const int which = (refr ? 4 : 0) + (tris ? 2 : 0) + (big ? 1 : 0);
-  const Kernel kernel = (variant == 0 && !launch.scene.any_refract) ? pt_render_tiles_v0 : family[which];
-  static size_t lds_allowed[9] = {0}; /* raised once per process if a scene needs > 64 KiB */
-  size_t &allowed = lds_allowed[(variant == 0 && !launch.scene.any_refract) ? 8 : which];
+  static const Kernel family[12] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
+                                    pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
+                                    pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr};
+  const int which = (refr ? 8 : (chk ? 4 : 0)) + (tris ? 2 : 0) + (big ? 1 : 0);
+  const bool plain = variant == 0 && !refr;
+  const Kernel kernel = plain ? pt_render_tiles_v0 : family[which];
+  static size_t lds_allowed[13] = {0}; /* raised once per process if a scene needs > 64 KiB */
+  size_t &allowed = lds_allowed[plain ? 12 : which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),

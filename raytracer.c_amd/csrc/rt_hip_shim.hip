@@ -89,6 +89,16 @@ H3 h3(const double *p) { return {p[0], p[1], p[2]}; }
 
 double max_abs3(const double *v) { return std::fmax(std::fabs(v[0]), std::fmax(std::fabs(v[1]), std::fabs(v[2]))); }
 
+/* The pooled kernels' fixed-point sums rest on throughput <= 1, i.e. on albedo / MAX(albedo)
+ * in [0, 1]: colours must be finite and non-negative; emission finite. */
+bool material_ok(const double *color, const double *emission)
+{
+  for (int k = 0; k < 3; k++)
+    if (!(color[k] >= 0.0) || !(color[k] <= 1e100) || !(std::fabs(emission[k]) <= 1e100))
+      return false;
+  return true;
+}
+
 void put_material(double *m, uint32_t flags, const double *color, const double *emission)
 {
   /* raytracer.c:497: prob = MAX(albedo.x, MAX(albedo.y, albedo.z)) */
@@ -246,12 +256,16 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   {
     any_refract |= (spheres[i].flags & PT_FLAG_REFRACT) != 0;
     any_checker |= (spheres[i].flags & PT_FLAG_CHECKER) != 0;
+    if (!material_ok(spheres[i].color, spheres[i].emission))
+      return fail(RT_HIP_EINVAL, "sphere %zu: colour must be finite and >= 0, emission finite", i);
     if (!(std::fabs(spheres[i].radius) >= 1e-100) || !(std::fabs(spheres[i].radius) <= 1e100))
       return fail(RT_HIP_ELIMIT, "sphere %zu: |radius| %g outside [1e-100, 1e100]", i, spheres[i].radius);
   }
   for (size_t m = 0; m < n_meshes; m++)
   {
     any_refract |= (meshes[m].flags & PT_FLAG_REFRACT) != 0;
+    if (!material_ok(meshes[m].color, meshes[m].emission))
+      return fail(RT_HIP_EINVAL, "mesh %zu: colour must be finite and >= 0, emission finite", m);
     if (meshes[m].num_triangles && !meshes[m].vertices)
       return fail(RT_HIP_EINVAL, "mesh %zu has triangles but no vertices", m);
     any_checker |= (meshes[m].flags & PT_FLAG_CHECKER) != 0;
@@ -545,7 +559,8 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   L.tile_stride = params->tile_stride;
   L.tile_count = params->tile_count;
   L.tiles_x = tx;
-  L.sample_chunks = kernel_variant() == 0 && !scene->view.any_refract ? 1u : sample_chunks;
+  /* the static kernels (plain reference variant; scenes with M_REFRACTION) do not split samples */
+  L.sample_chunks = (kernel_variant() == 0 || scene->view.any_refract) ? 1u : sample_chunks;
   L.acc_ws = static_cast<unsigned long long *>(d_workspace);
   if ((uint64_t)L.tile_count * L.sample_chunks > 0x7FFFFFFFull)
     return fail(RT_HIP_EINVAL, "tile_count x sample_chunks exceeds the grid limit");

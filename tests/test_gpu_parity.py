@@ -391,3 +391,63 @@ def test_device_math_shortcuts_are_bit_exact(gpu):
     # fused [-1, 1) mapping
     r = rng.integers(0, 1 << 31, 200000).astype(np.float64)
     assert np.array_equal(run(4, r, r), (r / 2147483648.0) * (1.0 - -1.0) + -1.0)
+
+
+def _random_scene(seed, with_mesh, n_tris):
+    """a deliberately nasty random scene: overlapping / nested / touching spheres, radii from
+    1e-3 to 1e4, every material flag, HDR emission, camera possibly inside a sphere, optional
+    triangle soup with degenerate and duplicated triangles"""
+    from rt_amd import abi, scene as S
+    rng = np.random.default_rng(1000 + seed)
+    flags = [abi.M_DEFAULT, abi.M_REFLECTION, abi.M_REFRACTION, abi.M_DEFAULT | abi.M_CHECKERED,
+             abi.M_REFLECTION | abi.M_CHECKERED]
+    objs = []
+    for k in range(int(rng.integers(1, 70))):
+        r = float(10.0 ** rng.uniform(-3, 1.3)) if rng.uniform() < 0.9 else float(10.0 ** rng.uniform(2, 4))
+        c = rng.uniform(-12, 12, 3)
+        if r > 50:  # a "wall": push it away so that it bounds rather than swallows the scene
+            axis = int(rng.integers(0, 3))
+            c[axis] = np.sign(c[axis] or 1.0) * (r + rng.uniform(5, 30))
+        if k and rng.uniform() < 0.15:  # touching / nested with the previous one
+            c = np.array(objs[-1]["center"]) + rng.normal(size=3) * objs[-1]["radius"] * rng.choice([0.2, 1.0, 2.0])
+        col = rng.uniform(0.05, 1.0, 3) if rng.uniform() < 0.8 else np.array([1.0, 1.0, 1.0])
+        emi = rng.uniform(0, 1, 3) * float(10.0 ** rng.uniform(-1, 3)) if rng.uniform() < 0.25 else np.zeros(3)
+        objs.append(dict(flags=int(rng.choice(flags)), radius=r, center=tuple(c), color=tuple(col), emission=tuple(emi)))
+    meshes = []
+    if with_mesh:
+        tris = []
+        for _ in range(n_tris):
+            base = rng.uniform(-10, 10, 3)
+            a, b, c = base, base + rng.normal(size=3) * 2, base + rng.normal(size=3) * 2
+            kind = rng.uniform()
+            if kind < 0.05:
+                c = a + (b - a) * 0.5           # degenerate: zero area
+            tri = [tuple(a) + tuple(rng.uniform(0, 1, 2)), tuple(b) + tuple(rng.uniform(0, 1, 2)),
+                   tuple(c) + tuple(rng.uniform(0, 1, 2))]
+            tris.append(tri)
+            if kind > 0.9:
+                tris.append(tri)                # exact duplicate: index tie
+        half = len(tris) // 2
+        meshes = [dict(flags=int(rng.choice(flags)), color=tuple(rng.uniform(0.2, 1, 3)), triangles=tris[:half]),
+                  dict(flags=abi.M_DEFAULT, color=tuple(rng.uniform(0.2, 1, 3)),
+                       emission=tuple(rng.uniform(0, 2, 3)), triangles=tris[half:])]
+    cam = rng.uniform(-25, 25, 3)
+    if rng.uniform() < 0.2 and objs:
+        cam = np.array(objs[0]["center"]) + 0.3 * objs[0]["radius"]  # inside the first sphere
+    if rng.uniform() < 0.15:
+        cam = cam * 40.0                                              # far outside: exercises near_R
+    w, h = int(rng.integers(9, 40)), int(rng.integers(9, 30))
+    depth = int(rng.integers(0, 7))
+    return S.custom_scene(objs, w, h, int(rng.integers(1, 7)), depth, tuple(cam), tuple(rng.uniform(-3, 3, 3)),
+                          meshes=meshes)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_sphere_scenes(gpu, pt, seed):
+    _full(gpu, pt, _random_scene(seed, False, 0))
+
+
+@pytest.mark.parametrize("seed,n_tris", [(s, n) for s, n in zip(range(16, 28), [3, 10, 40, 120, 250, 300, 400, 700, 1000, 60, 500, 2000])])
+def test_fuzz_mesh_scenes(gpu, pt, seed, n_tris):
+    """small meshes go through the flat filter, larger ones (> 256 primitives) through the hierarchy"""
+    _full(gpu, pt, _random_scene(seed, True, n_tris))
