@@ -65,6 +65,24 @@ int fail(int code, const char *fmt, ...)
       return fail(RT_HIP_ERUNTIME, "%s: %s", #expr, ncclGetErrorString(r_));                        \
   } while (0)
 
+/* selects a device for the current scope and puts the previous one back */
+struct DeviceScope
+{
+  int prev = -1;
+  hipError_t status;
+  explicit DeviceScope(int device)
+  {
+    status = hipGetDevice(&prev);
+    if (status == hipSuccess && prev != device)
+      status = hipSetDevice(device);
+  }
+  ~DeviceScope()
+  {
+    if (prev >= 0)
+      (void)hipSetDevice(prev);
+  }
+};
+
 int usable_devices()
 {
   int n = 0;
@@ -239,8 +257,64 @@ int rt_hip_device_info(int device, char *name, size_t name_cap, int *compute_uni
   return RT_HIP_OK;
 }
 
+} /* extern "C" */
+
+namespace
+{
+int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes,
+                      int device, RtHipScene **out_scene);
+int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes,
+                      const RtHipCamera *camera, const RtHipParams *params, int n_devices, float *h_image_rgb,
+                      uint8_t *h_image_rgb8, uint64_t *h_stats, double *kernel_seconds);
+} // namespace
+
+extern "C" {
+
+/* C++ exceptions (std::bad_alloc from the staging vectors) must not cross the C boundary */
 int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
                         size_t n_meshes, int device, RtHipScene **out_scene)
+{
+  try
+  {
+    return scene_create_impl(spheres, n_spheres, meshes, n_meshes, device, out_scene);
+  }
+  catch (const std::bad_alloc &)
+  {
+    return fail(RT_HIP_ENOMEM, "host allocation failed while staging the scene");
+  }
+  catch (...)
+  {
+    return fail(RT_HIP_ERUNTIME, "unexpected C++ exception in rt_hip_scene_create");
+  }
+}
+
+int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
+                        size_t n_meshes, const RtHipCamera *camera, const RtHipParams *params,
+                        int n_devices, float *h_image_rgb, uint8_t *h_image_rgb8, uint64_t *h_stats,
+                        double *kernel_seconds)
+{
+  try
+  {
+    return render_image_impl(spheres, n_spheres, meshes, n_meshes, camera, params, n_devices, h_image_rgb,
+                             h_image_rgb8, h_stats, kernel_seconds);
+  }
+  catch (const std::bad_alloc &)
+  {
+    return fail(RT_HIP_ENOMEM, "host allocation failed in rt_hip_render_image");
+  }
+  catch (...)
+  {
+    return fail(RT_HIP_ERUNTIME, "unexpected C++ exception in rt_hip_render_image");
+  }
+}
+
+} /* extern "C" */
+
+namespace
+{
+
+int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes,
+                      int device, RtHipScene **out_scene)
 {
   if (!out_scene)
     return fail(RT_HIP_EINVAL, "out_scene is NULL");
@@ -383,9 +457,8 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   const size_t off_bvh_tri = off_bvh_nodes + pad(n_bvh_nodes * PT_BVH_NODE_WORDS * 4);
   const size_t total = off_bvh_tri + pad(bvh.order.size() * 4) + 256;
 
-  int prev = 0;
-  HIP_TRY(hipGetDevice(&prev));
-  HIP_TRY(hipSetDevice(device));
+  DeviceScope scope(device);
+  HIP_TRY(scope.status);
   RtHipScene *sc = new (std::nothrow) RtHipScene;
   if (!sc)
     return fail(RT_HIP_ENOMEM, "host allocation failed");
@@ -394,7 +467,6 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   if (e != hipSuccess)
   {
     delete sc;
-    (void)hipSetDevice(prev);
     return fail(RT_HIP_ENOMEM, "hipMalloc(%zu): %s", total, hipGetErrorString(e));
   }
   char *base = static_cast<char *>(sc->blob);
@@ -409,7 +481,6 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   if (e == hipSuccess) e = up(off_tobj, tobj.data(), tobj.size() * 4);
   if (e == hipSuccess) e = up(off_bvh_src, bvh.nodes.data(), bvh.nodes.size() * 8);
   if (e == hipSuccess) e = up(off_bvh_tri, bvh.order.data(), bvh.order.size() * 4);
-  (void)hipSetDevice(prev);
   if (e != hipSuccess)
   {
     (void)hipFree(sc->blob);
@@ -438,15 +509,18 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   return RT_HIP_OK;
 }
 
+} // namespace
+
+extern "C" {
+
 void rt_hip_scene_destroy(RtHipScene *scene)
 {
   if (!scene)
     return;
-  int prev = 0;
-  (void)hipGetDevice(&prev);
-  (void)hipSetDevice(scene->device);
-  (void)hipFree(scene->blob);
-  (void)hipSetDevice(prev);
+  {
+    DeviceScope scope(scene->device);
+    (void)hipFree(scene->blob);
+  }
   delete scene;
 }
 
@@ -568,13 +642,9 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   L.tiles_rgb8 = d_tiles_rgb8;
   L.stats = reinterpret_cast<unsigned long long *>(d_stats);
 
-  int prev = 0;
-  HIP_TRY(hipGetDevice(&prev));
-  if (prev != scene->device)
-    HIP_TRY(hipSetDevice(scene->device));
+  DeviceScope scope(scene->device);
+  HIP_TRY(scope.status);
   hipError_t e = pt_launch_render(L, static_cast<hipStream_t>(stream), kernel_variant());
-  if (prev != scene->device)
-    (void)hipSetDevice(prev);
   if (e != hipSuccess)
     return fail(RT_HIP_ERUNTIME, "pt_render_tiles launch: %s", hipGetErrorString(e));
   return RT_HIP_OK;
@@ -588,9 +658,8 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
     return fail(RT_HIP_ENODEV, "no HIP device %d", device);
   if (n == 0)
     return RT_HIP_OK;
-  int prev = 0;
-  HIP_TRY(hipGetDevice(&prev));
-  HIP_TRY(hipSetDevice(device));
+  DeviceScope scope(device);
+  HIP_TRY(scope.status);
   double *d = nullptr;
   hipError_t e = hipMalloc(&d, 3 * n * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(d, h_a, n * sizeof(double), hipMemcpyHostToDevice);
@@ -598,7 +667,6 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
   if (e == hipSuccess) e = pt_launch_selftest(op, d, d + n, d + 2 * n, n, nullptr);
   if (e == hipSuccess) e = hipMemcpy(h_out, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
   (void)hipFree(d);
-  (void)hipSetDevice(prev);
   if (e != hipSuccess)
     return fail(RT_HIP_ERUNTIME, "self-test: %s", hipGetErrorString(e));
   return RT_HIP_OK;
@@ -629,10 +697,14 @@ int rt_hip_untile(const float *d_tiles_rgb, const uint8_t *d_tiles_rgb8, int32_t
  * device 0 with grouped ncclSend/ncclRecv (point-to-point over xGMI: a gather
  * to one root uses the root's 7 direct links concurrently, there is no ring),
  * scattered to the row-major image there, and copied to the host. */
-int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
-                        size_t n_meshes, const RtHipCamera *camera, const RtHipParams *params,
-                        int n_devices, float *h_image_rgb, uint8_t *h_image_rgb8, uint64_t *h_stats,
-                        double *kernel_seconds)
+} /* extern "C" */
+
+namespace
+{
+
+int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes,
+                      const RtHipCamera *camera, const RtHipParams *params, int n_devices, float *h_image_rgb,
+                      uint8_t *h_image_rgb8, uint64_t *h_stats, double *kernel_seconds)
 {
   int rc = check_params(params);
   if (rc)
@@ -829,4 +901,4 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
   return RT_HIP_OK;
 }
 
-} /* extern "C" */
+} // namespace
