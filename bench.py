@@ -105,6 +105,34 @@ def cpu_baseline(config, width, height, spp, depth, n_meshes, budget_tiles):
             "mpixel_samples_per_s": len(px) * spp / dt * 1e-6}
 
 
+def cpu_as_shipped():
+    """BASELINE.md CPU-A: the reference's render() exactly as shipped (libc rand(), its own
+    compile-time MAX_DEPTH 5, one OpenMP thread = its deterministic and fastest mode)
+    on its own scene at 320x180x16 -- context for readers of the reference, not the baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    from rt_amd import scene as S
+    if not oracle_py.ref_available(5):
+        return None
+    sc = S.build_scene(4, 320, 180, 16, max_depth=5)
+    ref = oracle_py.RefOracle(5)
+    devnull = os.open(os.devnull, os.O_WRONLY)       # render() prints a progress bar
+    saved = os.dup(1)
+    os.dup2(devnull, 1)
+    try:
+        t0 = time.perf_counter()
+        _, st = ref.render_as_shipped(sc, SEED, threads=1)
+        dt = time.perf_counter() - t0
+    finally:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)               # its printf buffer must drain into /dev/null, not after our JSON
+        os.dup2(saved, 1)
+        os.close(devnull)
+        os.close(saved)
+    return {"value": st["tests"] / sc.n_objects / dt, "unit": "ray-bounces/s", "cores": 1, "kind": "reference",
+            "sample": f"render() as shipped, 320x180, 16 spp, MAX_DEPTH 5, libc rand(), 1 thread, {dt:.1f} s"}
+
+
 # ---- main ------------------------------------------------------------------------------
 
 def main():
@@ -240,6 +268,8 @@ def main():
         }
         if world == 1 and args.cpu_tiles > 0:
             try:
+                if args.config == 4:
+                    out["cpu_as_shipped"] = cpu_as_shipped()
                 out["cpu_baseline"] = cpu_baseline(args.config, W, H, spp, depth, sc.n_meshes, args.cpu_tiles)
             except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "ray-bounces/s", "cores": 0, "kind": "reference",
