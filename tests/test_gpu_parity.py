@@ -451,3 +451,34 @@ def test_fuzz_sphere_scenes(gpu, pt, seed):
 def test_fuzz_mesh_scenes(gpu, pt, seed, n_tris):
     """small meshes go through the flat filter, larger ones (> 256 primitives) through the hierarchy"""
     _full(gpu, pt, _random_scene(seed, True, n_tris))
+
+
+def test_obj_file_through_render_ex(gpu, pt):
+    """load_obj() -> MeshObject -> render_ex() of the raytracer.h boundary (C host, meshes and
+    linear float output), against the oracle on the same mesh"""
+    import ctypes as C
+    from rt_amd import abi, scene as S
+    host = abi.load_host()
+    mesh = abi.TriangleMesh()
+    assert host.load_obj((GOLD + "/cube.obj").encode(), C.byref(mesh))
+    host.rt_mesh_flip_winding(C.byref(mesh))
+    for k in range(36):  # scale the unit cube up so it is visible
+        v = mesh.vertices[k]
+        v.pos = abi.Vec3(v.pos.x * 4, v.pos.y * 4 - 1, v.pos.z * 4)
+    sc = S.build_scene(1, 80, 48, 6)          # config 1's spheres + the cube
+    meshes = (abi.MeshObject * 1)()
+    meshes[0].flags = abi.M_REFLECTION
+    meshes[0].color = abi.Vec3(0.9, 0.8, 0.7)
+    meshes[0].emission = abi.Vec3(0, 0, 0)
+    meshes[0].mesh = mesh
+    sc.meshes, sc.n_meshes, sc.n_triangles = meshes, 1, 12
+    fb = np.zeros((sc.height, sc.width, 3), dtype=np.uint8)
+    lin = np.zeros((sc.height, sc.width, 3), dtype=np.float32)
+    opt = abi.Options()
+    opt.width, opt.height, opt.samples = sc.width, sc.height, sc.samples
+    host.rt_set_max_depth(sc.max_depth)
+    host.rt_set_seed(SEED)
+    host.render_ex(fb.ctypes.data, lin.ctypes.data, sc.objects, sc.n_objects, meshes, 1, C.byref(sc.camera), C.byref(opt))
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(lin, fb, None, mean, rgb8, None, what="render_ex + OBJ")
+    assert host.rt_last_ray_bounces() == ost["casts"] and host.rt_last_render_seconds() > 0
