@@ -211,6 +211,14 @@ void rt_set_devices(int n_devices);
 int rt_get_max_depth(void);
 uint64_t rt_get_seed(void);
 
+/* Cooperative cancellation (what the reference's SIGINT handler, main.c:37-48,422, is for):
+ * while a flag is registered, long renders poll it between slabs of tiles; when it becomes
+ * non-zero render()/render_ex() return early with the finished part of the image in the
+ * framebuffer (the rest stays as the caller initialised it / zero) and
+ * rt_last_render_cancelled() reports 1.  Set the flag from a signal handler. */
+void rt_set_cancel_flag(const volatile int *flag);
+int rt_last_render_cancelled(void);
+
 /* Kernel-only wall time of the last render()/render_ex(), seconds, and the
  * count of scene casts (rays that ran the intersection scan). */
 double rt_last_render_seconds(void);

@@ -53,6 +53,7 @@ enum
   RT_HIP_ENOMEM = -3,   /* host or device allocation failed */
   RT_HIP_ERUNTIME = -4, /* a HIP / RCCL runtime call failed */
   RT_HIP_ELIMIT = -5,   /* scene exceeds what the kernel supports */
+  RT_HIP_ECANCELLED = -6, /* rt_hip_render_image stopped early on the cancel flag; output is partial */
 };
 
 /* Layout-identical to the reference's Object (raytracer.h:104-111): 88 bytes. */
@@ -174,6 +175,12 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
  * h_image_rgb8 (w*h*3 bytes) may each be NULL.  h_stats: RT_HIP_NSTATS values,
  * overwritten.  kernel_seconds: device time of the render kernels (max over
  * devices), may be NULL.  params->tile_* are ignored. */
+/* Cooperative cancellation of rt_hip_render_image(): while a flag is registered, long frames
+ * are rendered in slabs and *flag is polled between them (set it from a signal handler).  On
+ * cancellation the finished tiles are still gathered and copied out, the rest of the image is
+ * zero, and the call returns RT_HIP_ECANCELLED.  NULL unregisters. */
+void rt_hip_set_cancel_flag(const volatile int *flag);
+
 int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
                         size_t n_meshes, const RtHipCamera *camera, const RtHipParams *params,
                         int n_devices, float *h_image_rgb, uint8_t *h_image_rgb8, uint64_t *h_stats,

@@ -38,6 +38,7 @@ namespace
 {
 
 thread_local char g_err[512] = "";
+const volatile int *g_cancel = nullptr; /* rt_hip_set_cancel_flag */
 
 int fail(int code, const char *fmt, ...)
 {
@@ -241,6 +242,8 @@ int check_params(const RtHipParams *p)
 extern "C" {
 
 const char *rt_hip_last_error(void) { return g_err; }
+
+void rt_hip_set_cancel_flag(const volatile int *flag) { g_cancel = flag; }
 
 int rt_hip_device_count(void) { return usable_devices(); }
 
@@ -793,21 +796,56 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     IMG_TRY(hipMalloc(&d.tiles8, slots * 192));
     IMG_TRY(hipMalloc(&d.stats, RT_HIP_NSTATS * sizeof(uint64_t)));
     IMG_TRY(hipMemsetAsync(d.stats, 0, RT_HIP_NSTATS * sizeof(uint64_t), d.stream));
-    RtHipParams p = *params;
-    p.tile_first = (uint32_t)g;
-    p.tile_stride = (uint32_t)G;
-    p.tile_count = d.count;
-    const uint32_t chunks = rt_hip_suggest_chunks(d.scene, d.count, p.samples);
-    if (chunks > 1)
-      IMG_TRY(hipMalloc(&d.ws, rt_hip_chunk_workspace_bytes(d.count)));
+    IMG_TRY(hipMemsetAsync(d.tiles, 0, slots * 192 * sizeof(float), d.stream));  /* unrendered tiles stay black, */
+    IMG_TRY(hipMemsetAsync(d.tiles8, 0, slots * 192, d.stream));                 /* like the reference's memset  */
     IMG_TRY(hipEventRecord(d.t0, d.stream));
-    rc = rt_hip_render_tiles_chunked(d.scene, camera, &p, chunks, d.ws, d.tiles, d.tiles8, d.stats, d.stream);
-    if (rc)
+  }
+  /* Long frames are rendered in slabs (contiguous runs of each device's tile list) so that a
+   * cancel request -- the CLI's SIGINT -- is honoured between slabs; what was finished is
+   * still gathered and returned (the reference dumps its partial framebuffer on SIGINT,
+   * main.c:37-48, from inside the signal handler; this does it from normal context). */
+  const double work = (double)W * H * (double)params->samples;
+  const uint32_t n_slabs = g_cancel ? (work > 4e9 ? 16u : (work > 2e8 ? 4u : 1u)) : 1u;
+  bool cancelled = false;
+  for (uint32_t slab = 0; slab < n_slabs && !cancelled; slab++)
+  {
+    for (int g = 0; g < G; g++)
     {
-      cleanup();
-      return rc;
+      Dev &d = dev[g];
+      const uint32_t k0 = (uint32_t)(((uint64_t)d.count * slab) / n_slabs);
+      const uint32_t k1 = (uint32_t)(((uint64_t)d.count * (slab + 1)) / n_slabs);
+      if (k1 == k0)
+        continue;
+      IMG_TRY(hipSetDevice(g));
+      RtHipParams p = *params;
+      p.tile_first = (uint32_t)g + k0 * (uint32_t)G;
+      p.tile_stride = (uint32_t)G;
+      p.tile_count = k1 - k0;
+      const uint32_t chunks = rt_hip_suggest_chunks(d.scene, p.tile_count, p.samples);
+      if (chunks > 1 && !d.ws)
+        IMG_TRY(hipMalloc(&d.ws, rt_hip_chunk_workspace_bytes(d.count)));
+      rc = rt_hip_render_tiles_chunked(d.scene, camera, &p, chunks, d.ws, d.tiles + (size_t)k0 * 192,
+                                       d.tiles8 + (size_t)k0 * 192, d.stats, d.stream);
+      if (rc)
+      {
+        cleanup();
+        return rc;
+      }
     }
-    IMG_TRY(hipEventRecord(d.t1, d.stream));
+    if (n_slabs > 1)
+    {
+      for (int g = 0; g < G; g++)
+      {
+        IMG_TRY(hipSetDevice(g));
+        IMG_TRY(hipStreamSynchronize(dev[g].stream));
+      }
+      cancelled = g_cancel && *g_cancel != 0;
+    }
+  }
+  for (int g = 0; g < G; g++)
+  {
+    IMG_TRY(hipSetDevice(g));
+    IMG_TRY(hipEventRecord(dev[g].t1, dev[g].stream));
   }
 
   /* ---- gather on device 0 ---- */
@@ -898,6 +936,8 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     *kernel_seconds = worst;
   cleanup();
 #undef IMG_TRY
+  if (cancelled)
+    return fail(RT_HIP_ECANCELLED, "render cancelled: the image holds the tiles finished so far");
   return RT_HIP_OK;
 }
 

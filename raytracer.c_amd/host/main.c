@@ -12,8 +12,8 @@
  * Timing is wall-clock (the reference's clock()/integer division, main.c:427-433,
  * reports summed CPU time truncated to seconds -- deliberately not reproduced).
  * SIGINT: the reference's handler writes and frees the live framebuffer from
- * signal context (main.c:37-48); here it only sets a flag and the partial
- * image is never read while the GPU owns it.
+ * signal context (main.c:37-48); here it only sets a flag that the renderer
+ * polls between slabs of tiles, and the partial image is written normally.
  */
 #define _POSIX_C_SOURCE 200809L
 #include <signal.h>
@@ -24,7 +24,7 @@
 
 int stbi_write_png(char const *filename, int w, int h, int comp, const void *data, int stride_in_bytes);
 
-static volatile sig_atomic_t interrupted = 0;
+static volatile int interrupted = 0; /* polled by the renderer between slabs of tiles */
 static void on_sigint(int sig)
 {
   (void)sig;
@@ -114,6 +114,7 @@ int main(int argc, char **argv)
     return EXIT_FAILURE;
   }
   signal(SIGINT, on_sigint);
+  rt_set_cancel_flag(&interrupted);
 
   Camera camera;
   vec3 pos = {info.cam_pos[0], info.cam_pos[1], info.cam_pos[2]};
@@ -138,18 +139,15 @@ int main(int argc, char **argv)
     printf("%.3e ray-bounces/s, %.2f Mpixel-samples/s\n", (double)rt_last_ray_bounces() / kernel_s,
            (double)a.options.width * a.options.height * a.options.samples / kernel_s * 1e-6);
   int status = EXIT_SUCCESS;
-  if (interrupted)
-    printf("interrupted: image not written\n");
-  else
-  {
-    printf("writing result to '%s'...\n", a.options.result);
+  if (rt_last_render_cancelled())
+    printf("interrupted: the image holds the tiles finished so far\n");
+  printf("writing result to '%s'...\n", a.options.result);
 #ifndef VALGRIND
-    if (stbi_write_png(a.options.result, a.options.width, a.options.height, 3, framebuffer, a.options.width * 3) == 0)
-      status = EXIT_FAILURE;
-    else
-      printf("done.\n");
+  if (stbi_write_png(a.options.result, a.options.width, a.options.height, 3, framebuffer, a.options.width * 3) == 0)
+    status = EXIT_FAILURE;
+  else
+    printf("done.\n");
 #endif
-  }
   rt_scene_free_meshes(meshes, info.n_meshes);
   free(meshes);
   free(scene);

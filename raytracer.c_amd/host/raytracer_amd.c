@@ -28,6 +28,7 @@ static int g_devices = 1;
 static uint64_t g_host_rng = 0;
 static double g_last_seconds = 0;
 static long long g_last_bounces = 0;
+static int g_last_cancelled = 0;
 
 _Static_assert(sizeof(Object) == sizeof(RtHipSphere), "Object must be passable as RtHipSphere");
 _Static_assert(offsetof(Object, radius) == offsetof(RtHipSphere, radius), "Object.radius");
@@ -49,6 +50,8 @@ void rt_set_seed(uint64_t seed)
 uint64_t rt_get_seed(void) { return g_seed; }
 void rt_set_devices(int n_devices) { g_devices = n_devices < 1 ? 1 : n_devices; }
 double rt_last_render_seconds(void) { return g_last_seconds; }
+void rt_set_cancel_flag(const volatile int *flag) { rt_hip_set_cancel_flag(flag); }
+int rt_last_render_cancelled(void) { return g_last_cancelled; }
 long long rt_last_ray_bounces(void) { return g_last_bounces; }
 
 /* ---- host-side RNG (reference raytracer.c:227-229) ------------------------------ */
@@ -219,7 +222,8 @@ void render_ex(uint8_t *framebuffer, float *linear_rgb, Object *objects, size_t 
   int rc = rt_hip_render_image((const RtHipSphere *)objects, n_objects, hm, n_meshes, (const RtHipCamera *)camera,
                                &p, g_devices, linear_rgb, framebuffer, stats, &seconds);
   free(hm);
-  if (rc != RT_HIP_OK)
+  g_last_cancelled = rc == RT_HIP_ECANCELLED;
+  if (rc != RT_HIP_OK && rc != RT_HIP_ECANCELLED)
   {
     fprintf(stderr, "render: GPU path failed (%d): %s\n", rc, rt_hip_last_error());
     exit(EXIT_FAILURE);

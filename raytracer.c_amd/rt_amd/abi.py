@@ -97,6 +97,7 @@ SHIM_SYMBOLS = {
     "rt_hip_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "rt_hip_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_hip_set_cancel_flag": (None, [C.c_void_p]),
     "rt_hip_render_image": (C.c_int, [C.POINTER(Object), C.c_size_t, C.POINTER(RtHipMesh), C.c_size_t,
                                       C.POINTER(Camera), C.POINTER(RtHipParams), C.c_int, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
@@ -123,6 +124,8 @@ HOST_SYMBOLS = {
     "rt_set_devices": (None, [C.c_int]),
     "rt_get_max_depth": (C.c_int, []),
     "rt_get_seed": (C.c_uint64, []),
+    "rt_set_cancel_flag": (None, [C.c_void_p]),
+    "rt_last_render_cancelled": (C.c_int, []),
     "rt_last_render_seconds": (C.c_double, []),
     "rt_last_ray_bounces": (C.c_longlong, []),
     "rt_scene_info": (C.c_int, [C.c_int, C.POINTER(RtSceneInfo)]),

@@ -482,3 +482,35 @@ def test_obj_file_through_render_ex(gpu, pt):
     mean, rgb8, ost = pt.render_pixels(sc, SEED)
     assert_parity(lin, fb, None, mean, rgb8, None, what="render_ex + OBJ")
     assert host.rt_last_ray_bounces() == ost["casts"] and host.rt_last_render_seconds() > 0
+
+
+def test_cancel_flag_returns_the_finished_part(gpu, pt):
+    """rt_set_cancel_flag(): with the flag already raised a long render stops after its first
+    slab; the finished tiles equal the full render's, the rest is zero"""
+    import ctypes as C
+    from rt_amd import abi, scene as S
+    host = abi.load_host()
+    sc = S.build_scene(4, 1920, 1080, 100)   # 2.07e8 pixel-samples: above the slab threshold
+    opt = abi.Options()
+    opt.width, opt.height, opt.samples = sc.width, sc.height, sc.samples
+    host.rt_set_max_depth(4)
+    host.rt_set_seed(SEED)
+    full = np.zeros((sc.height, sc.width, 3), dtype=np.uint8)
+    host.render(full.ctypes.data, sc.objects, sc.n_objects, C.byref(sc.camera), C.byref(opt))
+    assert host.rt_last_render_cancelled() == 0
+    flag = C.c_int(1)
+    host.rt_set_cancel_flag(C.byref(flag))
+    part = np.zeros_like(full)
+    host.render(part.ctypes.data, sc.objects, sc.n_objects, C.byref(sc.camera), C.byref(opt))
+    host.rt_set_cancel_flag(None)
+    assert host.rt_last_render_cancelled() == 1
+    done = part.reshape(-1, 3).any(axis=1)
+    frac = done.mean()
+    assert 0.15 < frac < 0.35, frac          # one slab of four
+    assert np.array_equal(part[part.any(axis=2)], full[part.any(axis=2)])
+    flag.value = 0
+    host.rt_set_cancel_flag(C.byref(flag))   # registered but never raised: complete image
+    again = np.zeros_like(full)
+    host.render(again.ctypes.data, sc.objects, sc.n_objects, C.byref(sc.camera), C.byref(opt))
+    host.rt_set_cancel_flag(None)
+    assert host.rt_last_render_cancelled() == 0 and np.array_equal(again, full)
