@@ -211,6 +211,14 @@ void rt_set_devices(int n_devices);
 int rt_get_max_depth(void);
 uint64_t rt_get_seed(void);
 
+/* Which integrator render() runs -- the reference chooses at compile time with the `#if 1`
+ * of raytracer.c:207-211: RT_TRACE_PATH (default) = trace_path (:482-554), RT_CAST_RAY =
+ * cast_ray (:556-641, Whitted-style: one point light, Phong, shadow rays, mirror and
+ * "refraction" children).  Other values are ignored. */
+enum { RT_TRACE_PATH = 0, RT_CAST_RAY = 1 };
+void rt_set_integrator(int integrator);
+int rt_get_integrator(void);
+
 /* Cooperative cancellation (what the reference's SIGINT handler, main.c:37-48,422, is for):
  * while a flag is registered, long renders poll it between slabs of tiles; when it becomes
  * non-zero render()/render_ex() return early with the finished part of the image in the

@@ -101,8 +101,20 @@ typedef struct
   int32_t max_depth;     /* the reference's compile-time MAX_DEPTH (raytracer.h:25) */
   uint64_t seed;         /* stream key, see rt_rng.h */
   uint32_t tile_first, tile_stride, tile_count;
-  uint32_t reserved;
+  uint32_t integrator;   /* RT_HIP_TRACE_PATH (0, the default) or RT_HIP_CAST_RAY */
 } RtHipParams;
+
+/* The two sides of the `#if 1` in the reference's render() (raytracer.c:207-211): the path
+ * tracer trace_path (:482-554), which is what the reference ships, and cast_ray (:556-641),
+ * the Whitted-style integrator it keeps compiled next to it (one fixed point light, Phong
+ * shading, shadow rays, mirror / "refraction" children; no random draws beyond the camera
+ * jitter).  With RT_HIP_CAST_RAY, RT_HIP_STAT_RAYS counts cast_ray calls (:558) and
+ * RT_HIP_STAT_CASTS counts scene scans, i.e. the primary and the shadow scan of every hit. */
+enum
+{
+  RT_HIP_TRACE_PATH = 0,
+  RT_HIP_CAST_RAY = 1
+};
 
 /* counters accumulated (+=) by a render call */
 enum
@@ -169,18 +181,18 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
 
 /* ---- convenience for C hosts: whole image, host buffers, synchronous ----------- */
 
-/* Renders width x height on n_devices GPUs of this process (tiles interleaved
- * over devices, tile buffers gathered onto device 0 with RCCL when
- * n_devices > 1), then copies to the host.  h_image_rgb (w*h*3 floats) and
- * h_image_rgb8 (w*h*3 bytes) may each be NULL.  h_stats: RT_HIP_NSTATS values,
- * overwritten.  kernel_seconds: device time of the render kernels (max over
- * devices), may be NULL.  params->tile_* are ignored. */
 /* Cooperative cancellation of rt_hip_render_image(): while a flag is registered, long frames
  * are rendered in slabs and *flag is polled between them (set it from a signal handler).  On
  * cancellation the finished tiles are still gathered and copied out, the rest of the image is
  * zero, and the call returns RT_HIP_ECANCELLED.  NULL unregisters. */
 void rt_hip_set_cancel_flag(const volatile int *flag);
 
+/* Renders width x height on n_devices GPUs of this process (tiles interleaved
+ * over devices, tile buffers gathered onto device 0 with RCCL when
+ * n_devices > 1), then copies to the host.  h_image_rgb (w*h*3 floats) and
+ * h_image_rgb8 (w*h*3 bytes) may each be NULL.  h_stats: RT_HIP_NSTATS values,
+ * overwritten.  kernel_seconds: device time of the render kernels (max over
+ * devices), may be NULL.  params->tile_* are ignored. */
 int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
                         size_t n_meshes, const RtHipCamera *camera, const RtHipParams *params,
                         int n_devices, float *h_image_rgb, uint8_t *h_image_rgb8, uint64_t *h_stats,

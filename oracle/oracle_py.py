@@ -19,6 +19,7 @@ from rt_amd import abi  # noqa: E402  (struct layouts only)
 
 PT_PATH = os.path.join(HERE, "libpt_oracle.so")
 REF_DEPTHS = (4, 5, 8, 16)
+INTEGRATORS = {"path": 0, "whitted": 1}  # render()'s `#if 1` (raytracer.c:207-211): trace_path / cast_ray
 
 
 def ref_path(depth):
@@ -116,24 +117,26 @@ class PtOracle(_Common):
             raise RuntimeError(f"{PT_PATH} missing: run `make oracle`")
         self.lib = C.CDLL(PT_PATH)
 
-    def render_pixels(self, scene, seed, pixels=None, spp=None, max_depth=None, want_rgb8=True):
-        """-> mean (npix,3) float64, rgb8 (npix,3) uint8, stats dict."""
+    def render_pixels(self, scene, seed, pixels=None, spp=None, max_depth=None, want_rgb8=True,
+                      integrator="path"):
+        """-> mean (npix,3) float64, rgb8 (npix,3) uint8, stats dict.
+        integrator: "path" = trace_path, "whitted" = cast_ray (raytracer.c:556-641)."""
         ptr, npix, keep = _pixels_arg(pixels, scene.width, scene.height)
         mean = np.zeros((npix, 3))
         rgb8 = np.zeros((npix, 3), dtype=np.uint8)
         stats = (C.c_longlong * 4)()
-        self.lib.pto_render_pixels(
-            scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
+        self.lib.pto_render_pixels_with(
+            C.c_int(INTEGRATORS[integrator]), scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
             C.byref(scene.camera), C.c_int(scene.width), C.c_int(scene.height),
             C.c_int(spp or scene.samples), C.c_int(scene.max_depth if max_depth is None else max_depth),
             C.c_uint64(seed), ptr, C.c_size_t(npix), _ptr(mean), _ptr(rgb8, C.c_uint8) if want_rgb8 else None, stats)
         return mean, rgb8, dict(rays=stats[0], tests=stats[1], casts=stats[2], draws=stats[3])
 
-    def trace_sample(self, scene, x, y, s, seed, max_depth=None):
+    def trace_sample(self, scene, x, y, s, seed, max_depth=None, integrator="path"):
         rgb = np.zeros(3)
         stats = (C.c_longlong * 4)()
-        self.lib.pto_trace_sample(
-            scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
+        self.lib.pto_trace_sample_with(
+            C.c_int(INTEGRATORS[integrator]), scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
             C.byref(scene.camera), C.c_int(scene.width), C.c_int(scene.height),
             C.c_int(scene.max_depth if max_depth is None else max_depth), C.c_uint32(x), C.c_uint32(y),
             C.c_uint32(s), C.c_uint64(seed), _ptr(rgb), stats)
@@ -164,8 +167,9 @@ class RefOracle(_Common):
         self.lib.ref_layout(out)
         return list(out)
 
-    def render_pixels(self, scene, seed, pixels=None, spp=None, want_rgb8=True):
+    def render_pixels(self, scene, seed, pixels=None, spp=None, want_rgb8=True, integrator="path"):
         assert scene.n_meshes == 0, "the compiled reference scans spheres only"
+        self.lib.ref_set_integrator(C.c_int(INTEGRATORS[integrator]))
         ptr, npix, keep = _pixels_arg(pixels, scene.width, scene.height)
         mean = np.zeros((npix, 3))
         rgb8 = np.zeros((npix, 3), dtype=np.uint8)
@@ -176,9 +180,10 @@ class RefOracle(_Common):
             _ptr(mean), _ptr(rgb8, C.c_uint8) if want_rgb8 else None, stats)
         return mean, rgb8, dict(rays=stats[0], tests=stats[1])
 
-    def trace_sample(self, scene, x, y, s, seed):
+    def trace_sample(self, scene, x, y, s, seed, integrator="path"):
         rgb = np.zeros(3)
         stats = (C.c_longlong * 3)()
+        self.lib.ref_set_integrator(C.c_int(INTEGRATORS[integrator]))
         self.lib.ref_trace_sample(
             scene.objects, C.c_size_t(scene.n_objects), C.byref(scene.camera), C.c_int(scene.width),
             C.c_int(scene.height), C.c_uint32(x), C.c_uint32(y), C.c_uint32(s), C.c_uint64(seed), _ptr(rgb), stats)

@@ -31,6 +31,7 @@ typedef struct
   const MeshObject *meshes;
   size_t n_meshes;
   int max_depth;
+  int whitted; /* 1: cast_ray (raytracer.c:556-641) instead of trace_path */
   uint64_t rng;
   long long rays, tests, casts, draws;
 } Ctx;
@@ -311,6 +312,78 @@ static vec3 trace(Ctx *c, const Ray *ray, int depth)
   return vec3_add(emission, vec3_mult(albedo, radiance));
 }
 
+/* raytracer.c:556-641: cast_ray, the Whitted integrator the reference keeps compiled behind
+ * the `#if 1` of render() (:207-211).  One fixed point light, Phong terms with the light's
+ * colour, a shadow ray without a distance limit, mirror and "refraction" children. */
+static vec3 whitted(Ctx *c, const Ray *ray, int depth)
+{
+  const vec3 background = {10 / 255.0, 10 / 255.0, 10 / 255.0};
+  const vec3 zero = {0 / 255.0, 0 / 255.0, 0 / 255.0};
+  Closest hit;
+  c->rays++;
+  if (depth > c->max_depth || !closest_hit(c, ray, &hit))
+    return background;
+
+  vec3 out_color = zero;
+  const vec3 light_pos = {2, 7, 2};
+  const vec3 light_color = {1, 1, 1};
+
+  Ray light_ray;
+  light_ray.origin = hit.point;
+  light_ray.direction = vec3_normalize(vec3_sub(light_pos, hit.point));
+  /* :571 intersect(.., NULL): anything in front of the point, at any distance, shadows it */
+  Closest blocker;
+  int in_shadow = closest_hit(c, &light_ray, &blocker);
+
+  vec3 object_color;
+  uint flags;
+  if (hit.is_mesh)
+  {
+    object_color = c->meshes[hit.index].color;
+    flags = c->meshes[hit.index].flags;
+  }
+  else
+  {
+    object_color = c->objs[hit.index].color;
+    flags = c->objs[hit.index].flags;
+  }
+  const double ka = 0.25, kd = 0.5, ks = 0.8, alpha = 10.0;
+  if (flags & M_CHECKERED)
+    object_color = checker(object_color, hit.u, hit.v, 10);
+
+  vec3 ambient = vec3_scalar_mult(light_color, ka);
+  vec3 diffuse = vec3_scalar_mult(light_color, kd * MAX(0.0, vec3_dot(hit.normal, light_ray.direction)));
+  vec3 reflected = reflect_dir(light_ray.direction, hit.normal);
+  vec3 view_dir = vec3_normalize(vec3_sub(hit.point, ray->origin));
+  vec3 specular = vec3_scalar_mult(light_color, ks * pow(MAX(vec3_dot(view_dir, reflected), 0.0), alpha));
+  vec3 surface = vec3_mult(
+      vec3_add(ambient, vec3_scalar_mult(vec3_add(specular, diffuse), in_shadow ? 0 : 1)), object_color);
+
+  vec3 reflection = zero, refraction = zero;
+  double kr = 0, kt = 0;
+  Ray next;
+  next.origin = hit.point;
+  if (flags & M_REFLECTION)
+  {
+    kr = 1.0;
+    next.direction = vec3_normalize(reflect_dir(ray->direction, hit.normal));
+    reflection = whitted(c, &next, depth + 1);
+  }
+  if (flags & M_REFRACTION)
+  {
+    double transparency = 0.5;
+    double facing = -vec3_dot(ray->direction, hit.normal);
+    double fresnel = mix(pow(1 - facing, 3), 1, 0.1);
+    kr = fresnel;
+    kt = (1 - fresnel) * transparency;
+    next.direction = vec3_normalize(refract_dir(ray->direction, hit.normal, 1.0));
+    refraction = whitted(c, &next, depth + 1);
+  }
+  out_color = vec3_add(out_color, surface);
+  out_color = vec3_add(out_color, vec3_add(vec3_scalar_mult(reflection, kr), vec3_scalar_mult(refraction, kt)));
+  return out_color;
+}
+
 /* raytracer.c:375-384 */
 static Ray camera_ray(const Camera *cam, double u, double v)
 {
@@ -330,7 +403,7 @@ static vec3 one_sample(Ctx *c, const Camera *cam, int w, int h, uint32_t x, uint
   double u = (double)(x + draw(c)) / ((double)w - 1.0);
   double v = (double)(y + draw(c)) / ((double)h - 1.0);
   Ray ray = camera_ray(cam, u, v);
-  return trace(c, &ray, 0);
+  return c->whitted ? whitted(c, &ray, 0) : trace(c, &ray, 0);
 }
 
 /* raytracer.c:218-220: gamma 5, clamp (NaN -> 1 through MIN), truncate */
@@ -356,13 +429,14 @@ static void ctx_stats(const Ctx *c, long long stats[4])
 
 /* ---- exported --------------------------------------------------------------- */
 
-void pto_render_pixels(const Object *objs, size_t n_objs, const MeshObject *meshes, size_t n_meshes,
-                       const Camera *cam, int w, int h, int spp, int max_depth, uint64_t seed,
-                       const uint32_t *pixels, size_t npix, double *out_mean, uint8_t *out_rgb8,
-                       long long stats[4])
+void pto_render_pixels_with(int integrator, const Object *objs, size_t n_objs, const MeshObject *meshes,
+                            size_t n_meshes, const Camera *cam, int w, int h, int spp, int max_depth,
+                            uint64_t seed, const uint32_t *pixels, size_t npix, double *out_mean,
+                            uint8_t *out_rgb8, long long stats[4])
 {
   Ctx c;
   ctx_init(&c, objs, n_objs, meshes, n_meshes, max_depth);
+  c.whitted = integrator == 1;
   for (size_t k = 0; k < npix; k++)
   {
     uint32_t p = pixels ? pixels[k] : (uint32_t)k;
@@ -387,17 +461,34 @@ void pto_render_pixels(const Object *objs, size_t n_objs, const MeshObject *mesh
   ctx_stats(&c, stats);
 }
 
-void pto_trace_sample(const Object *objs, size_t n_objs, const MeshObject *meshes, size_t n_meshes,
-                      const Camera *cam, int w, int h, int max_depth, uint32_t x, uint32_t y,
-                      uint32_t s, uint64_t seed, double out_rgb[3], long long stats[4])
+void pto_render_pixels(const Object *objs, size_t n_objs, const MeshObject *meshes, size_t n_meshes,
+                       const Camera *cam, int w, int h, int spp, int max_depth, uint64_t seed,
+                       const uint32_t *pixels, size_t npix, double *out_mean, uint8_t *out_rgb8,
+                       long long stats[4])
+{
+  pto_render_pixels_with(0, objs, n_objs, meshes, n_meshes, cam, w, h, spp, max_depth, seed, pixels, npix,
+                         out_mean, out_rgb8, stats);
+}
+
+void pto_trace_sample_with(int integrator, const Object *objs, size_t n_objs, const MeshObject *meshes,
+                           size_t n_meshes, const Camera *cam, int w, int h, int max_depth, uint32_t x,
+                           uint32_t y, uint32_t s, uint64_t seed, double out_rgb[3], long long stats[4])
 {
   Ctx c;
   ctx_init(&c, objs, n_objs, meshes, n_meshes, max_depth);
+  c.whitted = integrator == 1;
   vec3 r = one_sample(&c, cam, w, h, x, y, s, seed);
   out_rgb[0] = r.x;
   out_rgb[1] = r.y;
   out_rgb[2] = r.z;
   ctx_stats(&c, stats);
+}
+
+void pto_trace_sample(const Object *objs, size_t n_objs, const MeshObject *meshes, size_t n_meshes,
+                      const Camera *cam, int w, int h, int max_depth, uint32_t x, uint32_t y,
+                      uint32_t s, uint64_t seed, double out_rgb[3], long long stats[4])
+{
+  pto_trace_sample_with(0, objs, n_objs, meshes, n_meshes, cam, w, h, max_depth, x, y, s, seed, out_rgb, stats);
 }
 
 void pto_tonemap(const double *mean, size_t npix, uint8_t *out_rgb8)

@@ -26,6 +26,17 @@ void pto_trace_sample(const Object *objs, size_t n_objs, const MeshObject *meshe
                       const Camera *cam, int w, int h, int max_depth, uint32_t x, uint32_t y,
                       uint32_t s, uint64_t seed, double out_rgb[3], long long stats[4]);
 
+/* The same two with the integrator chosen: 0 = trace_path (raytracer.c:482-554, what render()
+ * calls as shipped), 1 = cast_ray (raytracer.c:556-641, the other side of render()'s `#if 1`).
+ * For cast_ray, "casts" counts both the primary and the shadow scan of every hit. */
+void pto_render_pixels_with(int integrator, const Object *objs, size_t n_objs, const MeshObject *meshes,
+                            size_t n_meshes, const Camera *cam, int w, int h, int spp, int max_depth,
+                            uint64_t seed, const uint32_t *pixels, size_t npix, double *out_mean,
+                            uint8_t *out_rgb8, long long stats[4]);
+void pto_trace_sample_with(int integrator, const Object *objs, size_t n_objs, const MeshObject *meshes,
+                           size_t n_meshes, const Camera *cam, int w, int h, int max_depth, uint32_t x,
+                           uint32_t y, uint32_t s, uint64_t seed, double out_rgb[3], long long stats[4]);
+
 void pto_init_camera(Camera *cam, const double pos[3], const double target[3], int w, int h);
 void pto_camera_ray(const Camera *cam, double u, double v, double out[6]);
 int pto_intersect_sphere(const double ray[6], const double center[3], double radius, double *t);

@@ -195,6 +195,12 @@ void ref_random_doubles(uint64_t seed, uint32_t pixel, uint32_t sample, int coun
 
 /* ---- one sample: raytracer.c:203-208 with the stream re-seeded ------------ */
 
+/* Which side of render()'s `#if 1` (raytracer.c:207-211) the harness takes: 0 = trace_path
+ * (as shipped), 1 = cast_ray, the Whitted integrator the reference keeps compiled but
+ * unreferenced (raytracer.c:556-641). */
+static int harness_integrator = 0;
+void ref_set_integrator(int which) { harness_integrator = which; }
+
 static vec3 harness_sample(Object *objs, size_t n, Camera *cam, int w, int h, uint32_t x,
                            uint32_t y, uint32_t s, uint64_t seed)
 {
@@ -202,6 +208,8 @@ static vec3 harness_sample(Object *objs, size_t n, Camera *cam, int w, int h, ui
   double u = (double)(x + random_double()) / ((double)w - 1.0);
   double v = (double)(y + random_double()) / ((double)h - 1.0);
   Ray ray = get_camera_ray(cam, u, v);
+  if (harness_integrator == 1)
+    return cast_ray(&ray, objs, n, 0);
   return trace_path(&ray, objs, n, 0);
 }
 

@@ -17,6 +17,8 @@
  *       albedo_rr = color * (1/prob), the albedo after a survived Russian roulette (:500);
  *                   same operands, same two operations as the reference performs per
  *                   bounce, so the same doubles.
+ *   color_raw  [n_spheres + n_meshes] x 3 f64    : the colours as given; cast_ray
+ *                   (raytracer.c:574) shades with them, trace_path never reads them.
  *   tri_geom   [n_triangles] x 9 f64 : v0, edge1 = v1-v0, edge2 = v2-v0
  *       (raytracer.c:132-133 forms the edges per test; precomputed = same).
  *   tri_normal [n_triangles] x 3 f64 : calculate_surface_normal(v0,v1,v2)
@@ -63,6 +65,7 @@ struct PtSceneView
   const double *entry_src; /* n_spheres + n_triangles bounding records, scan order */
   float *filt;             /* packed-fp32 filter table, rebuilt per launch by pt_build_filter */
   const double *material;
+  const double *color_raw;
   const double *tri_geom;
   const double *tri_normal;
   const double *tri_tex;
@@ -93,7 +96,8 @@ struct PtLaunch
   double inv_w_minus_1, inv_h_minus_1; /* RN(1/(W-1)), RN(1/(H-1)) for div_small_int */
   double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
-  uint32_t sample_chunks, reserved_; /* workgroups per tile: each renders 1/sample_chunks of the samples */
+  uint32_t sample_chunks; /* workgroups per tile: each renders 1/sample_chunks of the samples */
+  uint32_t integrator;    /* 0 trace_path (raytracer.c:482-554), 1 cast_ray (:556-641) */
   unsigned long long *acc_ws;        /* tile_count x 192 fixed-point sums, used when sample_chunks > 1 */
   float *tiles_rgb;
   uint8_t *tiles_rgb8;

@@ -454,6 +454,7 @@ struct SceneCtx
 {
   const double *geom;     /* LDS: n_sph x PT_GEOM_STRIDE: cx cy cz r2 (fp64, exact tests and normals) */
   const double *mat;      /* LDS: (n_sph + n_meshes) x PT_MAT_STRIDE */
+  const double *color_raw; /* HBM: (n_sph + n_meshes) x 3, the colours as given (cast_ray shades with them) */
   const double *tri;      /* HBM: n_tri x 9 (v0, e1, e2), gathered per lane in phase 2 */
   const double *tri_normal;
   const double *tri_tex;
@@ -501,6 +502,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   SceneCtx ctx;
   ctx.geom = geom;
   ctx.mat = mat;
+  ctx.color_raw = sc.color_raw;
   ctx.tri = sc.tri_geom;
   ctx.tri_normal = sc.tri_normal;
   ctx.tri_tex = sc.tri_tex;
@@ -773,6 +775,154 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
   return path_ends;
 }
 
+/* ---- one cast_ray() call (raytracer.c:556-641), the Whitted integrator on the other side of
+ * render()'s `#if 1` (:207-211).  Same contract as trace_step: returns true when the sample is
+ * finished.  One fixed point light (:567-568), Phong terms in the LIGHT's colour (1,1,1)
+ * times the object colour (:586-603), a shadow ray with no distance limit (:570-572:
+ * intersect(.., NULL) reports any hit in front of the point), a normalised mirror child
+ * (:609-615) and a "refracted" child that, with the CLAMP_BETWEEN quirk, goes straight on
+ * (:617-628).  Children are weighted by scalars, so the forward form carries a scalar weight
+ * in P.T; a hit with both M_REFLECTION and M_REFRACTION traces the mirror child first and
+ * parks the other on the pending-ray stack.  No random draws after the camera jitter. */
+template <bool TRIS, bool FILT_LDS>
+__device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
+                                             unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
+{
+  V3 add = {kBg, kBg, kBg}; /* depth limit or no hit: BACKGROUND (:561-564) */
+  bool path_ends = true;
+  const V3 o = P.o, d = P.d;
+
+  if (P.depth <= S.max_depth)
+  {
+    n_casts++;
+    double min_t = 1.7976931348623157e308;
+    int best = -1;
+    double bary_u = 0, bary_v = 0;
+    scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
+                                                     S.n_sph + S.n_tri, o, d, min_t, best, bary_u, bary_v, diag_ptr,
+                                                     S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri);
+    if (best >= 0)
+    {
+      const V3 p = v_add(o, v_scale(d, min_t));
+      V3 n;
+      uint32_t slot;
+      const bool is_tri = (uint32_t)best >= S.n_sph;
+      if (!is_tri)
+      {
+        const V3 pc = v_sub(p, ld3(S.geom + PT_GEOM_STRIDE * best));
+        n = v_scale(pc, 1.0 / sqrt_unscaled(v_dot(pc, pc)));
+        slot = (uint32_t)best;
+      }
+      else
+      {
+        const uint32_t ti = (uint32_t)best - S.n_sph;
+        n = ld3(S.tri_normal + 3 * (size_t)ti);
+        slot = S.tri_object[ti];
+      }
+      const uint32_t flags = (uint32_t)__double_as_longlong(S.mat[PT_MAT_STRIDE * slot + 7]);
+      V3 color = ld3(S.color_raw + 3 * (size_t)slot);
+
+      /* shadow ray :570-572 */
+      const V3 light_pos = {2, 7, 2};
+      const V3 ldir = v_normalize(v_sub(light_pos, p));
+      n_casts++;
+      double shadow_t = 1.7976931348623157e308, su = 0, sv = 0;
+      int blocker = -1;
+      scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
+                                                       S.n_sph + S.n_tri, p, ldir, shadow_t, blocker, su, sv, diag_ptr,
+                                                       S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri);
+      const double lit = blocker >= 0 ? 0.0 : 1.0;
+
+      if (flags & PT_FLAG_CHECKER)
+      {
+        double tex_u, tex_v;
+        if (!is_tri)
+        {
+          tex_u = atan2(n.x, n.z) / (2 * kPi) + 0.5; /* :410-411 */
+          tex_v = n.y * 0.5 + 0.5;
+        }
+        else
+        {
+          const double *tx = S.tri_tex + 6 * (size_t)((uint32_t)best - S.n_sph);
+          const double w0 = 1 - bary_u - bary_v;
+          tex_u = (tx[0] * w0 + tx[2] * bary_u) + tx[4] * bary_v;
+          tex_v = (tx[1] * w0 + tx[3] * bary_u) + tx[5] * bary_v;
+        }
+        /* checkered_texture :386-391 with M = 10 (:583) */
+        const double on = (double)((fmod(tex_u * 10.0, 1.0) > 0.5) ^ (fmod(tex_v * 10.0, 1.0) < 0.5));
+        color = v_scale(color, 0.3 * (1 - on) + 0.7 * on);
+      }
+
+      /* :586-603; light_color = (1,1,1), so each term is the same scalar in all channels */
+      const double ka = 0.25, kd = 0.5, ks = 0.8, alpha = 10.0;
+      const double n_dot_l = v_dot(n, ldir);
+      const double diffuse = 1.0 * (kd * (0.0 > n_dot_l ? 0.0 : n_dot_l)); /* MAX(0.0, x) */
+      const V3 reflected = v_sub(ldir, v_scale(n, 2 * v_dot(ldir, n)));
+      const V3 view = v_normalize(v_sub(p, o));
+      const double v_dot_r = v_dot(view, reflected);
+      const double specular = 1.0 * (ks * pow(v_dot_r > 0.0 ? v_dot_r : 0.0, alpha)); /* MAX(x, 0.0) */
+      const double shade = 1.0 * ka + (specular + diffuse) * lit;
+      const V3 surface = v_scale(color, shade);
+      add = surface;
+
+      const bool mirror = (flags & PT_FLAG_MIRROR) != 0, glass = (flags & PT_FLAG_REFRACT) != 0;
+      if (mirror || glass)
+      {
+        double kr = 1.0, kt = 0.0;
+        V3 through = d;
+        if (glass)
+        {
+          const double facing = -v_dot(d, n);
+          const double fresnel = 1 * 0.1 + pow(1 - facing, 3.0) * (1 - 0.1); /* mix() :255 */
+          kr = fresnel; /* :622 -- also the weight of an M_REFLECTION child of the same hit */
+          kt = (1 - fresnel) * 0.5;
+          /* refract(I, N, 1.0) :354-373 with cosi == 1: I*1 + (-N)*(1*1 - sqrtf(1)) */
+          const double coef = 1.0 * 1.0 - (double)sqrtf(1.0f);
+          through = v_normalize(v_add(v_scale(d, 1.0), v_scale(v_scale(n, -1), coef)));
+        }
+        P.Ls = v_add(P.Ls, v_mul(P.T, surface));
+        const V3 weight = P.T;
+        if (mirror)
+        {
+          const V3 refl = v_normalize(v_sub(d, v_scale(n, 2 * v_dot(d, n))));
+          if (glass && stack_n < PT_REFRACT_STACK)
+          {
+            PendingRay &pend = stack[stack_n++];
+            pend.o = p;
+            pend.d = through;
+            pend.T = v_scale(weight, kt);
+            pend.depth = P.depth + 1;
+          }
+          P.d = refl;
+          P.T = v_scale(weight, kr);
+        }
+        else
+        {
+          P.d = through;
+          P.T = v_scale(weight, kt);
+        }
+        P.o = p;
+        P.depth++;
+        path_ends = false;
+      }
+    }
+  }
+  if (path_ends)
+  {
+    P.Ls = v_add(P.Ls, v_mul(P.T, add));
+    if (stack_n > 0)
+    {
+      const PendingRay &pend = stack[--stack_n];
+      P.o = pend.o;
+      P.d = pend.d;
+      P.T = pend.T;
+      P.depth = pend.depth;
+      path_ends = false;
+    }
+  }
+  return path_ends;
+}
+
 /* ---- epilogue shared by both kernels: coalesced tile store + counters ------------------- */
 
 /* per-pixel mean (raytracer.c:215) and gamma-5 tonemap (:218-220) of one tile from its
@@ -997,7 +1147,7 @@ PT_KERNEL(pt_render_tiles_tri_big_chk, __launch_bounds__(PT_BLOCK), true, true, 
  * order.  Floating-point sums have no range limit, which is what scenes with M_REFRACTION
  * need (see render_tiles_pooled); VARIANT 0 of it is the plain reference kernel
  * (RT_HIP_KERNEL_VARIANT=0). */
-template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS>
+template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, bool WHITTED = false>
 __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
 {
   extern __shared__ double lds[];
@@ -1032,7 +1182,7 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   uint32_t n_rays = 0, n_casts = 0;
   uint32_t s = inside ? slice : spp;
   bool fresh = true;
-  PendingRay stack[REFRACT ? PT_REFRACT_STACK : 1];
+  PendingRay stack[(REFRACT || WHITTED) ? PT_REFRACT_STACK : 1];
   int stack_n = 0;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
@@ -1049,7 +1199,10 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
       fresh = false;
     }
     n_rays++;
-    if (trace_step<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, stack, stack_n))
+    const bool finished = WHITTED ? whitted_step<TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, stack, stack_n)
+                                  : trace_step<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr,
+                                                                                          stack, stack_n);
+    if (finished)
     {
       acc = v_add(acc, P.Ls);
       s += PT_SLICES;
@@ -1094,6 +1247,18 @@ PT_KERNEL_STATIC(pt_render_tiles_big_refr, 1, true, true, false, false)
 PT_KERNEL_STATIC(pt_render_tiles_tri_refr, 1, true, true, true, true)
 PT_KERNEL_STATIC(pt_render_tiles_tri_big_refr, 1, true, true, true, false)
 #undef PT_KERNEL_STATIC
+
+/* cast_ray kernels: the static body with whitted_step */
+#define PT_KERNEL_WHITTED(name, TRIS, FILT_LDS)                                              \
+  extern "C" __global__ __launch_bounds__(PT_BLOCK) void name(const PtLaunch L)             \
+  {                                                                                         \
+    render_tiles_static<1, false, true, TRIS, FILT_LDS, true>(L);                           \
+  }
+PT_KERNEL_WHITTED(pt_whitted_tiles, false, true)
+PT_KERNEL_WHITTED(pt_whitted_tiles_big, false, false)
+PT_KERNEL_WHITTED(pt_whitted_tiles_tri, true, true)
+PT_KERNEL_WHITTED(pt_whitted_tiles_tri_big, true, false)
+#undef PT_KERNEL_WHITTED
 
 /* Second pass of a chunked render: per-tile fixed-point sums -> float3 + tonemapped bytes. */
 extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const PtLaunch L)
@@ -1270,10 +1435,12 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   static const Kernel family[12] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
                                     pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr};
-  const int which = (refr ? 8 : (chk ? 4 : 0)) + (tris ? 2 : 0) + (big ? 1 : 0);
-  const bool plain = variant == 0 && !refr;
-  const Kernel kernel = plain ? pt_render_tiles_v0 : family[which];
-  static size_t lds_allowed[13] = {0}; /* raised once per process if a scene needs > 64 KiB */
+  static const Kernel whitted[4] = {pt_whitted_tiles, pt_whitted_tiles_big, pt_whitted_tiles_tri, pt_whitted_tiles_tri_big};
+  const bool cast_ray = launch.integrator == 1;
+  const int which = cast_ray ? 13 + (tris ? 2 : 0) + (big ? 1 : 0) : (refr ? 8 : (chk ? 4 : 0)) + (tris ? 2 : 0) + (big ? 1 : 0);
+  const bool plain = variant == 0 && !refr && !cast_ray;
+  const Kernel kernel = plain ? pt_render_tiles_v0 : (cast_ray ? whitted[which - 13] : family[which]);
+  static size_t lds_allowed[17] = {0}; /* raised once per process if a scene needs > 64 KiB */
   size_t &allowed = lds_allowed[plain ? 12 : which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {

@@ -32,6 +32,7 @@ struct RtHipScene
   void *blob = nullptr; /* one device allocation holding every array */
   double reach = 0;     /* >= |p| for every point p on a primitive of ordinary size (radius < 1000) */
   double max_emission = 0; /* max |emission component| over all materials */
+  bool any_mirror_glass = false; /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children */
 };
 
 namespace
@@ -230,6 +231,8 @@ int check_params(const RtHipParams *p)
     return fail(RT_HIP_EINVAL, "samples must be in [1, 2^26]");
   if (p->max_depth < 0 || p->max_depth > 1000000)
     return fail(RT_HIP_EINVAL, "max_depth out of range");
+  if (p->integrator != RT_HIP_TRACE_PATH && p->integrator != RT_HIP_CAST_RAY)
+    return fail(RT_HIP_EINVAL, "integrator must be RT_HIP_TRACE_PATH (0) or RT_HIP_CAST_RAY (1)");
   if ((uint64_t)p->width * (uint64_t)p->height > 0xFFFFFFFFull)
     return fail(RT_HIP_EINVAL, "image has more than 2^32 pixels");
   if (p->width > (1 << 20) || p->height > (1 << 20))
@@ -328,10 +331,12 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     return fail(RT_HIP_ENODEV, "no HIP device %d (found %d)", device, usable_devices());
 
   size_t n_tri = 0;
-  bool any_checker = false, any_refract = false;
+  bool any_checker = false, any_refract = false, any_mirror_glass = false;
+  const uint32_t both = PT_FLAG_MIRROR | PT_FLAG_REFRACT;
   for (size_t i = 0; i < n_spheres; i++)
   {
     any_refract |= (spheres[i].flags & PT_FLAG_REFRACT) != 0;
+    any_mirror_glass |= (spheres[i].flags & both) == both;
     any_checker |= (spheres[i].flags & PT_FLAG_CHECKER) != 0;
     if (!material_ok(spheres[i].color, spheres[i].emission))
       return fail(RT_HIP_EINVAL, "sphere %zu: colour must be finite and >= 0, emission finite", i);
@@ -341,6 +346,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   for (size_t m = 0; m < n_meshes; m++)
   {
     any_refract |= (meshes[m].flags & PT_FLAG_REFRACT) != 0;
+    any_mirror_glass |= (meshes[m].flags & both) == both;
     if (!material_ok(meshes[m].color, meshes[m].emission))
       return fail(RT_HIP_EINVAL, "mesh %zu: colour must be finite and >= 0, emission finite", m);
     if (meshes[m].num_triangles && !meshes[m].vertices)
@@ -363,6 +369,11 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   std::vector<double> geom(PT_ENTRY_SRC_STRIDE * (n_spheres + n_tri)), mat(PT_MAT_STRIDE * n_mat), tgeom(9 * n_tri), tnorm(3 * n_tri),
       ttex(6 * n_tri);
   std::vector<uint32_t> tobj(n_tri);
+  std::vector<double> craw(3 * n_mat);
+  for (size_t i = 0; i < n_spheres; i++)
+    memcpy(&craw[3 * i], spheres[i].color, 3 * sizeof(double));
+  for (size_t m = 0; m < n_meshes; m++)
+    memcpy(&craw[3 * (n_spheres + m)], meshes[m].color, 3 * sizeof(double));
   for (size_t i = 0; i < n_spheres; i++)
   {
     double *g = &geom[PT_ENTRY_SRC_STRIDE * i];
@@ -448,7 +459,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t off_geom = 0;
   const size_t off_mat = off_geom + pad(geom.size() * 8);
-  const size_t off_tgeom = off_mat + pad(mat.size() * 8);
+  const size_t off_craw = off_mat + pad(mat.size() * 8);
+  const size_t off_tgeom = off_craw + pad(craw.size() * 8);
   const size_t off_tnorm = off_tgeom + pad(tgeom.size() * 8);
   const size_t off_ttex = off_tnorm + pad(tnorm.size() * 8);
   const size_t off_tobj = off_ttex + pad(ttex.size() * 8);
@@ -478,6 +490,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   };
   e = up(off_geom, geom.data(), geom.size() * 8);
   if (e == hipSuccess) e = up(off_mat, mat.data(), mat.size() * 8);
+  if (e == hipSuccess) e = up(off_craw, craw.data(), craw.size() * 8);
   if (e == hipSuccess) e = up(off_tgeom, tgeom.data(), tgeom.size() * 8);
   if (e == hipSuccess) e = up(off_tnorm, tnorm.data(), tnorm.size() * 8);
   if (e == hipSuccess) e = up(off_ttex, ttex.data(), ttex.size() * 8);
@@ -497,6 +510,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.bvh_tri = reinterpret_cast<const uint32_t *>(base + off_bvh_tri);
   sc->view.n_bvh_nodes = (uint32_t)n_bvh_nodes;
   sc->view.material = reinterpret_cast<const double *>(base + off_mat);
+  sc->view.color_raw = reinterpret_cast<const double *>(base + off_craw);
   sc->view.tri_geom = reinterpret_cast<const double *>(base + off_tgeom);
   sc->view.tri_normal = reinterpret_cast<const double *>(base + off_tnorm);
   sc->view.tri_tex = reinterpret_cast<const double *>(base + off_ttex);
@@ -508,6 +522,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.any_refract = any_refract ? 1u : 0u;
   sc->reach = reach;
   sc->max_emission = max_emission;
+  sc->any_mirror_glass = any_mirror_glass;
   *out_scene = sc;
   return RT_HIP_OK;
 }
@@ -575,9 +590,14 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   int rc = check_params(params);
   if (rc)
     return rc;
-  if (scene->view.any_refract && params->max_depth > PT_REFRACT_MAX_DEPTH)
+  const bool cast_ray = params->integrator == RT_HIP_CAST_RAY;
+  if (!cast_ray && scene->view.any_refract && params->max_depth > PT_REFRACT_MAX_DEPTH)
     return fail(RT_HIP_ELIMIT, "scenes with M_REFRACTION materials support max_depth <= %d (two rays per "
                                "refractive hit, raytracer.c:523-529; the pending-ray stack is fixed)",
+                PT_REFRACT_MAX_DEPTH);
+  if (cast_ray && scene->any_mirror_glass && params->max_depth > PT_REFRACT_MAX_DEPTH)
+    return fail(RT_HIP_ELIMIT, "cast_ray with M_REFLECTION|M_REFRACTION materials supports max_depth <= %d (two "
+                               "rays per such hit, raytracer.c:609-628; the pending-ray stack is fixed)",
                 PT_REFRACT_MAX_DEPTH);
   const uint32_t tx = tiles_x_of(params->width), ty = tiles_y_of(params->height);
   const uint64_t n_tiles = (uint64_t)tx * ty;
@@ -637,7 +657,8 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   L.tile_count = params->tile_count;
   L.tiles_x = tx;
   /* the static kernels (plain reference variant; scenes with M_REFRACTION) do not split samples */
-  L.sample_chunks = (kernel_variant() == 0 || scene->view.any_refract) ? 1u : sample_chunks;
+  L.sample_chunks = (kernel_variant() == 0 || scene->view.any_refract || cast_ray) ? 1u : sample_chunks;
+  L.integrator = cast_ray ? 1u : 0u;
   L.acc_ws = static_cast<unsigned long long *>(d_workspace);
   if ((uint64_t)L.tile_count * L.sample_chunks > 0x7FFFFFFFull)
     return fail(RT_HIP_EINVAL, "tile_count x sample_chunks exceeds the grid limit");

@@ -9,6 +9,8 @@
  *   -c <config>  scene 1..5 of BASELINE.json (default 4, the reference's room)
  *   -g <gpus>    GPUs of this node to spread the image over (default 1)
  *   -r <seed>    RNG seed (default 1666943821)
+ *   -i <0|1>     integrator: 0 trace_path (default), 1 cast_ray -- the `#if 1` of
+ *                raytracer.c:207-211
  * Timing is wall-clock (the reference's clock()/integer division, main.c:427-433,
  * reports summed CPU time truncated to seconds -- deliberately not reproduced).
  * SIGINT: the reference's handler writes and frees the live framebuffer from
@@ -41,7 +43,7 @@ static double now_seconds(void)
 typedef struct
 {
   Options options;
-  int depth, config, gpus;
+  int depth, config, gpus, integrator;
   uint64_t seed;
 } Args;
 
@@ -49,7 +51,8 @@ static void usage(const char *prog)
 {
   fprintf(stderr,
           "Usage: %s -w <width> -h <height> -s <samples per pixel> -o <filename>\n"
-          "          [-d <max depth>] [-c <scene config 1..5>] [-g <gpus>] [-r <seed>]\n",
+          "          [-d <max depth>] [-c <scene config 1..5>] [-g <gpus>] [-r <seed>]\n"
+          "          [-i <integrator: 0 trace_path, 1 cast_ray>]\n",
           prog);
 }
 
@@ -70,6 +73,7 @@ static int parse_args(int argc, char **argv, Args *a)
     case 'c': a->config = atoi(val); break;
     case 'g': a->gpus = atoi(val); break;
     case 'r': a->seed = strtoull(val, NULL, 10); break;
+    case 'i': a->integrator = atoi(val); break;
     default: return -1;
     }
   }
@@ -96,7 +100,8 @@ int main(int argc, char **argv)
     return EXIT_FAILURE;
   }
   RtSceneInfo info;
-  if (rt_scene_info(a.config, &info) != 0 || a.options.width < 2 || a.options.height < 2 || a.options.samples < 1)
+  if (rt_scene_info(a.config, &info) != 0 || a.options.width < 2 || a.options.height < 2 || a.options.samples < 1 ||
+      (a.integrator != RT_TRACE_PATH && a.integrator != RT_CAST_RAY))
   {
     usage(argv[0]);
     return EXIT_FAILURE;
@@ -124,6 +129,7 @@ int main(int argc, char **argv)
   rt_set_max_depth(a.depth);
   rt_set_seed(a.seed);
   rt_set_devices(a.gpus);
+  rt_set_integrator(a.integrator);
 
   double tic = now_seconds();
   render_ex(framebuffer, NULL, scene, info.n_objects, meshes, info.n_meshes, &camera, &a.options);

@@ -25,6 +25,7 @@ long long intersection_test_count = 0;
 static int g_max_depth = MAX_DEPTH;
 static uint64_t g_seed = 1666943821ull; /* reference main.c:182 */
 static int g_devices = 1;
+static int g_integrator = RT_TRACE_PATH;
 static uint64_t g_host_rng = 0;
 static double g_last_seconds = 0;
 static long long g_last_bounces = 0;
@@ -49,6 +50,12 @@ void rt_set_seed(uint64_t seed)
 }
 uint64_t rt_get_seed(void) { return g_seed; }
 void rt_set_devices(int n_devices) { g_devices = n_devices < 1 ? 1 : n_devices; }
+void rt_set_integrator(int integrator)
+{
+  if (integrator == RT_TRACE_PATH || integrator == RT_CAST_RAY)
+    g_integrator = integrator;
+}
+int rt_get_integrator(void) { return g_integrator; }
 double rt_last_render_seconds(void) { return g_last_seconds; }
 void rt_set_cancel_flag(const volatile int *flag) { rt_hip_set_cancel_flag(flag); }
 int rt_last_render_cancelled(void) { return g_last_cancelled; }
@@ -216,6 +223,7 @@ void render_ex(uint8_t *framebuffer, float *linear_rgb, Object *objects, size_t 
   p.samples = options->samples;
   p.max_depth = g_max_depth;
   p.seed = g_seed;
+  p.integrator = g_integrator == RT_CAST_RAY ? RT_HIP_CAST_RAY : RT_HIP_TRACE_PATH;
 
   uint64_t stats[RT_HIP_NSTATS] = {0, 0, 0, 0};
   double seconds = 0;

@@ -69,7 +69,11 @@ class RtHipMesh(C.Structure):
 class RtHipParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32), ("max_depth", C.c_int32),
                 ("seed", C.c_uint64), ("tile_first", C.c_uint32), ("tile_stride", C.c_uint32),
-                ("tile_count", C.c_uint32), ("reserved", C.c_uint32)]
+                ("tile_count", C.c_uint32), ("integrator", C.c_uint32)]
+
+
+TRACE_PATH, CAST_RAY = 0, 1  # RtHipParams.integrator / rt_set_integrator()
+INTEGRATORS = {"path": TRACE_PATH, "whitted": CAST_RAY}
 
 
 class RtSceneInfo(C.Structure):
@@ -121,6 +125,8 @@ HOST_SYMBOLS = {
                          C.POINTER(Camera), C.POINTER(Options)]),
     "rt_set_max_depth": (None, [C.c_int]),
     "rt_set_seed": (None, [C.c_uint64]),
+    "rt_set_integrator": (None, [C.c_int]),
+    "rt_get_integrator": (C.c_int, []),
     "rt_set_devices": (None, [C.c_int]),
     "rt_get_max_depth": (C.c_int, []),
     "rt_get_seed": (C.c_uint64, []),

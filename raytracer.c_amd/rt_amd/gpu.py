@@ -47,8 +47,9 @@ class GpuScene:
         except Exception:
             pass
 
-    def params(self, seed, first, stride, count, samples=None, max_depth=None):
+    def params(self, seed, first, stride, count, samples=None, max_depth=None, integrator="path"):
         p = abi.RtHipParams()
+        p.integrator = abi.INTEGRATORS[integrator]
         p.width, p.height = self.scene.width, self.scene.height
         p.samples = samples or self.scene.samples
         p.max_depth = self.scene.max_depth if max_depth is None else max_depth
@@ -60,10 +61,11 @@ class GpuScene:
         return int(self.shim.rt_hip_suggest_chunks(self.handle, count, samples or self.scene.samples))
 
     def render_tiles(self, seed, first, stride, count, tiles=None, tiles8=None, stats=None, samples=None,
-                     max_depth=None, chunks=1, workspace=None):
+                     max_depth=None, chunks=1, workspace=None, integrator="path"):
         """Asynchronous on torch's current stream.  Returns (tiles f32 [count,64,3],
         tiles8 u8 [count,64,3], stats i64 [4]); pass buffers to reuse them.  chunks > 1 splits
-        every tile's samples over that many workgroups (same image, bit for bit)."""
+        every tile's samples over that many workgroups (same image, bit for bit).
+        integrator: "path" = trace_path (what the reference ships), "whitted" = cast_ray."""
         dev = torch.device("cuda", self.device)
         if tiles is None:
             tiles = torch.empty((max(count, 1), abi.TILE_PIXELS, 3), dtype=torch.float32, device=dev)
@@ -71,7 +73,7 @@ class GpuScene:
             tiles8 = torch.empty((max(count, 1), abi.TILE_PIXELS, 3), dtype=torch.uint8, device=dev)
         if stats is None:
             stats = torch.zeros(abi.NSTATS, dtype=torch.int64, device=dev)
-        p = self.params(seed, first, stride, count, samples, max_depth)
+        p = self.params(seed, first, stride, count, samples, max_depth, integrator)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if chunks > 1 and workspace is None:
             workspace = torch.empty(self.shim.rt_hip_chunk_workspace_bytes(max(count, 1)), dtype=torch.uint8, device=dev)
@@ -98,10 +100,11 @@ class GpuScene:
                "rt_hip_untile")
         return image, image8
 
-    def render_image(self, seed, samples=None, max_depth=None):
+    def render_image(self, seed, samples=None, max_depth=None, integrator="path"):
         """Whole image on this one GPU -> (image f32 [H,W,3], image8 u8 [H,W,3], stats dict), synchronised."""
         total = n_tiles(self.scene.width, self.scene.height)
-        tiles, tiles8, stats = self.render_tiles(seed, 0, 1, total, samples=samples, max_depth=max_depth)
+        tiles, tiles8, stats = self.render_tiles(seed, 0, 1, total, samples=samples, max_depth=max_depth,
+                                                 integrator=integrator)
         image, image8 = self.untile(tiles, tiles8, 0, 1, total)
         torch.cuda.synchronize(tiles.device)
         st = stats.cpu().tolist()
@@ -109,7 +112,7 @@ class GpuScene:
                                    samples=st[abi.STAT_SAMPLES])
 
 
-def render_image_host(scene, seed, n_devices=1, samples=None, max_depth=None):
+def render_image_host(scene, seed, n_devices=1, samples=None, max_depth=None, integrator="path"):
     """rt_hip_render_image(): the C hosts' entry point (host buffers, synchronous)."""
     import numpy as np
     shim = abi.load_shim()
@@ -118,6 +121,7 @@ def render_image_host(scene, seed, n_devices=1, samples=None, max_depth=None):
     p.samples = samples or scene.samples
     p.max_depth = scene.max_depth if max_depth is None else max_depth
     p.seed = seed
+    p.integrator = abi.INTEGRATORS[integrator]
     img = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
     img8 = np.zeros((scene.height, scene.width, 3), dtype=np.uint8)
     stats = (C.c_uint64 * abi.NSTATS)()

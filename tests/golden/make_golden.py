@@ -18,6 +18,9 @@ Files
   frames.npz       linear fp64 means + tonemapped bytes + ray/test counts:
                    config 1 whole frame at 64x64; a 96x64 'glass' frame (refraction, checker); tiles of configs 1, 2, 4 at full size
   samples.npz      per-(pixel, sample) traces: radiance, rays, tests, draws
+  whitted.npz      the same kinds of vectors from the reference's compiled cast_ray()
+                   (raytracer.c:556-641): a 96x64 frame covering every branch, tiles of
+                   configs 2 and 4 at full size, per-sample traces
 """
 import os
 import sys
@@ -33,7 +36,7 @@ os.environ.setdefault("OMP_NUM_THREADS", "1")
 
 import oracle_py  # noqa: E402
 from rt_amd import scene as S  # noqa: E402
-from util import glass_scene, tile_pixels  # noqa: E402
+from util import glass_scene, tile_pixels, whitted_scene  # noqa: E402
 
 SEED = 1666943821
 
@@ -234,12 +237,47 @@ def samples():
     return out
 
 
+def whitted():
+    out = {}
+    sc = whitted_scene()
+    ref = oracle_py.RefOracle(sc.max_depth)
+    mean, rgb8, st = ref.render_pixels(sc, SEED, integrator="whitted")
+    out.update(scene_mean=mean, scene_rgb8=rgb8, scene_stats=np.array([st["rays"], st["tests"]]))
+    rng = np.random.default_rng(6)
+    for cfg, ntiles, spp in [(2, 16, 4), (4, 16, 4)]:
+        sc = S.build_scene(cfg, samples=spp)
+        ref = oracle_py.RefOracle(sc.max_depth)
+        total = ((sc.width + 7) // 8) * ((sc.height + 7) // 8)
+        tiles = np.sort(rng.choice(total, size=ntiles, replace=False)).astype(np.uint32)
+        px = tile_pixels(sc.width, sc.height, tiles)
+        mean, rgb8, st = ref.render_pixels(sc, SEED, pixels=px, integrator="whitted")
+        tag = f"c{cfg}_s{sc.samples}"
+        out[tag + "_tiles"] = tiles
+        out[tag + "_mean"] = mean
+        out[tag + "_rgb8"] = rgb8
+        out[tag + "_stats"] = np.array([st["rays"], st["tests"]])
+        out[tag + "_dims"] = np.array([sc.width, sc.height, sc.samples, sc.max_depth])
+    sc = whitted_scene(samples=8)
+    ref = oracle_py.RefOracle(sc.max_depth)
+    keys = np.stack([rng.integers(0, sc.width, 128), rng.integers(0, sc.height, 128),
+                     rng.integers(0, sc.samples, 128)], axis=1).astype(np.uint32)
+    rgb = np.zeros((128, 3))
+    stats = np.zeros((128, 3), dtype=np.int64)
+    for k, (x, y, s) in enumerate(keys):
+        c, st = ref.trace_sample(sc, int(x), int(y), int(s), SEED, integrator="whitted")
+        rgb[k] = c
+        stats[k] = (st["rays"], st["tests"], st["draws"])
+    out.update(sample_keys=keys, sample_rgb=rgb, sample_stats=stats)
+    return out
+
+
 def main():
     assert oracle_py.ref_available(), "build oracle/_ref first (make oracle, needs /root/reference)"
     np.savez_compressed(os.path.join(HERE, "primitives.npz"), **primitives(oracle_py.RefOracle(5)))
     np.savez_compressed(os.path.join(HERE, "frames.npz"), **frames())
     np.savez_compressed(os.path.join(HERE, "samples.npz"), **samples())
-    for f in ("primitives.npz", "frames.npz", "samples.npz"):
+    np.savez_compressed(os.path.join(HERE, "whitted.npz"), **whitted())
+    for f in ("primitives.npz", "frames.npz", "samples.npz", "whitted.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -128,3 +128,46 @@ def test_glass_frame_refraction_and_checker(pt, frames):
     assert np.array_equal(rgb8, frames["glass_rgb8"])
     assert [st["rays"], st["tests"]] == frames["glass_stats"].tolist()
     assert st["rays"] > 1.5 * sc.width * sc.height * sc.samples
+
+
+# ---- cast_ray, the Whitted integrator on the other side of render()'s `#if 1` --------------
+
+@pytest.fixture(scope="module")
+def whitted():
+    return np.load(os.path.join(GOLD, "whitted.npz"), allow_pickle=False)
+
+
+def test_whitted_frame_every_branch(pt, whitted):
+    """cast_ray() as compiled from the reference (raytracer.c:556-641): Phong + checker(M=10),
+    shadow rays, mirror, 'refraction', and a sphere with both flags (two children)"""
+    from util import whitted_scene
+    sc = whitted_scene()
+    mean, rgb8, st = pt.render_pixels(sc, SEED, integrator="whitted")
+    assert np.array_equal(mean, whitted["scene_mean"])
+    assert np.array_equal(rgb8, whitted["scene_rgb8"])
+    assert [st["rays"], st["tests"]] == whitted["scene_stats"].tolist()
+    # every hit costs two scans (primary + shadow); misses and depth-terminated calls one or none
+    assert sc.n_objects * st["rays"] < st["tests"] < 2 * sc.n_objects * st["rays"]
+
+
+@pytest.mark.parametrize("tag,cfg", [("c2_s4", 2), ("c4_s4", 4)])
+def test_whitted_full_size_tiles(pt, whitted, tag, cfg):
+    from rt_amd import scene as S
+    w, h, spp, depth = [int(v) for v in whitted[tag + "_dims"]]
+    sc = S.build_scene(cfg, w, h, spp)
+    assert sc.max_depth == depth
+    px = tile_pixels(w, h, whitted[tag + "_tiles"])
+    mean, rgb8, st = pt.render_pixels(sc, SEED, pixels=px, integrator="whitted")
+    assert np.array_equal(mean, whitted[tag + "_mean"])
+    assert np.array_equal(rgb8, whitted[tag + "_rgb8"])
+    assert [st["rays"], st["tests"]] == whitted[tag + "_stats"].tolist()
+
+
+def test_whitted_sample_traces(pt, whitted):
+    from util import whitted_scene
+    sc = whitted_scene(samples=8)
+    for (x, y, s), rgb, st in zip(whitted["sample_keys"], whitted["sample_rgb"], whitted["sample_stats"]):
+        c, got = pt.trace_sample(sc, int(x), int(y), int(s), SEED, integrator="whitted")
+        assert np.array_equal(c, rgb)
+        assert [got["rays"], got["tests"], got["draws"]] == st.tolist()
+        assert got["draws"] == 2  # the camera jitter only

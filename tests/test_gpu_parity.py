@@ -22,12 +22,12 @@ def gpu():
     return G
 
 
-def _full(gpu, pt, sc, seed=SEED):
+def _full(gpu, pt, sc, seed=SEED, integrator="path"):
     gs = gpu.GpuScene(sc)
-    img, img8, st = gs.render_image(seed)
-    mean, rgb8, ost = pt.render_pixels(sc, seed)
+    img, img8, st = gs.render_image(seed, integrator=integrator)
+    mean, rgb8, ost = pt.render_pixels(sc, seed, integrator=integrator)
     assert st["samples"] == sc.width * sc.height * sc.samples
-    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"config {sc.config}")
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"config {sc.config} {integrator}")
     gs.close()
     return st
 
@@ -393,14 +393,14 @@ def test_device_math_shortcuts_are_bit_exact(gpu):
     assert np.array_equal(run(4, r, r), (r / 2147483648.0) * (1.0 - -1.0) + -1.0)
 
 
-def _random_scene(seed, with_mesh, n_tris):
+def _random_scene(seed, with_mesh, n_tris, extra_flags=()):
     """a deliberately nasty random scene: overlapping / nested / touching spheres, radii from
     1e-3 to 1e4, every material flag, HDR emission, camera possibly inside a sphere, optional
     triangle soup with degenerate and duplicated triangles"""
     from rt_amd import abi, scene as S
     rng = np.random.default_rng(1000 + seed)
     flags = [abi.M_DEFAULT, abi.M_REFLECTION, abi.M_REFRACTION, abi.M_DEFAULT | abi.M_CHECKERED,
-             abi.M_REFLECTION | abi.M_CHECKERED]
+             abi.M_REFLECTION | abi.M_CHECKERED] + list(extra_flags)
     objs = []
     for k in range(int(rng.integers(1, 70))):
         r = float(10.0 ** rng.uniform(-3, 1.3)) if rng.uniform() < 0.9 else float(10.0 ** rng.uniform(2, 4))
@@ -514,3 +514,115 @@ def test_cancel_flag_returns_the_finished_part(gpu, pt):
     host.render(again.ctypes.data, sc.objects, sc.n_objects, C.byref(sc.camera), C.byref(opt))
     host.rt_set_cancel_flag(None)
     assert host.rt_last_render_cancelled() == 0 and np.array_equal(again, full)
+
+
+# ---- cast_ray: the Whitted integrator on the other side of render()'s `#if 1` ---------------
+
+def test_whitted_golden_frame_every_branch(gpu):
+    """device cast_ray vs the reference's compiled cast_ray() (raytracer.c:556-641): Phong,
+    checker (M = 10), shadow rays, mirror, 'refraction', a sphere with both flags"""
+    from util import whitted_scene
+    fr = np.load(GOLD + "/whitted.npz", allow_pickle=False)
+    sc = whitted_scene()
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(SEED, integrator="whitted")
+    ost = dict(rays=int(fr["scene_stats"][0]), tests=int(fr["scene_stats"][1]))
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, fr["scene_mean"], fr["scene_rgb8"], ost, what="whitted")
+    # the switch is per call: the same scene object still path-traces
+    img2, _, st2 = gs.render_image(SEED)
+    assert st2["rays"] != st["rays"] and not np.array_equal(img2.cpu().numpy(), img.cpu().numpy())
+    gs.close()
+
+
+@pytest.mark.parametrize("tag,cfg", [("c2_s4", 2), ("c4_s4", 4)])
+def test_whitted_golden_full_size_tiles(gpu, tag, cfg):
+    import torch
+    from rt_amd import scene as S
+    fr = np.load(GOLD + "/whitted.npz", allow_pickle=False)
+    w, h, spp, depth = [int(v) for v in fr[tag + "_dims"]]
+    sc = S.build_scene(cfg, w, h, spp)
+    gs = gpu.GpuScene(sc)
+    got, got8 = [], []
+    stats = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for t in fr[tag + "_tiles"]:
+        tl, tl8, _ = gs.render_tiles(SEED, int(t), 1, 1, stats=stats, integrator="whitted")
+        got.append(tl[0])
+        got8.append(tl8[0])
+    torch.cuda.synchronize()
+    g = torch.stack(got).cpu().numpy().reshape(-1, 3)
+    g8 = torch.stack(got8).cpu().numpy().reshape(-1, 3)
+    st = stats.cpu().tolist()
+    ost = dict(rays=int(fr[tag + "_stats"][0]), tests=int(fr[tag + "_stats"][1]))
+    assert_parity(g, g8, dict(rays=st[0], tests=st[2]), fr[tag + "_mean"], fr[tag + "_rgb8"], ost, what="whitted " + tag)
+    gs.close()
+
+
+def test_whitted_configs_vs_oracle(gpu, pt):
+    """spheres (LDS filter), a small mesh (flat filter) and the 10,240-triangle mesh (hierarchy)"""
+    from rt_amd import scene as S
+    for cfg, w, h, spp in [(1, 96, 96, 3), (3, 120, 68, 2), (4, 160, 90, 2), (5, 64, 36, 2)]:
+        sc = S.build_scene(cfg, w, h, spp)
+        st = _full(gpu, pt, sc, integrator="whitted")
+        assert st["casts"] > st["rays"]  # shadow scans
+        sc.free()
+
+
+@pytest.mark.parametrize("seed", range(40, 52))
+def test_whitted_fuzz(gpu, pt, seed):
+    from rt_amd import abi
+    both = (abi.M_REFLECTION | abi.M_REFRACTION, abi.M_REFLECTION | abi.M_REFRACTION | abi.M_CHECKERED,
+            abi.M_REFRACTION | abi.M_CHECKERED)
+    n_tris = [0, 0, 0, 0, 0, 0, 5, 40, 200, 300, 600, 1500][seed - 40]
+    _full(gpu, pt, _random_scene(seed, n_tris > 0, n_tris, extra_flags=both), integrator="whitted")
+
+
+def test_whitted_through_the_host_api_and_cli(gpu, pt, tmp_path):
+    """rt_set_integrator(RT_CAST_RAY) + render(), and the CLI's -i 1"""
+    import ctypes as C
+    import os
+    import subprocess
+    from rt_amd import abi, scene as S
+    from util import decode_png_rgb8
+    host = abi.load_host()
+    sc = S.build_scene(1, 72, 40, 2)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED, integrator="whitted")
+    fb = np.zeros((sc.height, sc.width, 3), dtype=np.uint8)
+    opt = abi.Options()
+    opt.width, opt.height, opt.samples = sc.width, sc.height, sc.samples
+    host.rt_set_max_depth(sc.max_depth)
+    host.rt_set_seed(SEED)
+    host.rt_set_integrator(abi.CAST_RAY)
+    try:
+        assert host.rt_get_integrator() == abi.CAST_RAY
+        host.rt_set_integrator(7)  # ignored
+        assert host.rt_get_integrator() == abi.CAST_RAY
+        before = C.c_longlong.in_dll(host, "ray_count").value
+        host.render(fb.ctypes.data, sc.objects, sc.n_objects, C.byref(sc.camera), C.byref(opt))
+        assert C.c_longlong.in_dll(host, "ray_count").value - before == ost["rays"]
+    finally:
+        host.rt_set_integrator(abi.TRACE_PATH)
+    assert np.abs(fb.reshape(-1, 3).astype(np.int16) - rgb8.astype(np.int16)).max() <= 1
+    exe = os.path.join(abi.PKG_DIR, "host", "raytracer")
+    out = str(tmp_path / "whitted.png")
+    r = subprocess.run([exe, "-w", "72", "-h", "40", "-s", "2", "-o", out, "-c", "1", "-d", str(sc.max_depth), "-i", "1"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    img = decode_png_rgb8(out).reshape(-1, 3)
+    assert np.abs(img.astype(np.int16) - rgb8.astype(np.int16)).max() <= 1
+    r = subprocess.run([exe, "-w", "72", "-h", "40", "-s", "2", "-o", out, "-i", "2"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Usage:" in r.stderr
+
+
+def test_whitted_depth_limit_only_for_two_child_materials(gpu):
+    from rt_amd import abi, gpu as G, scene as S
+    from util import glass_scene, whitted_scene
+    deep = glass_scene(24, 16, 1, max_depth=40)      # M_REFRACTION alone: one child per hit, no limit
+    gs = gpu.GpuScene(deep)
+    gs.render_image(SEED, integrator="whitted")
+    with pytest.raises(G.ShimError, match="max_depth <= 32"):
+        gs.render_image(SEED)                         # the path tracer's two-child refraction
+    gs.close()
+    gs = gpu.GpuScene(whitted_scene(24, 16, 1, max_depth=40))  # has M_REFLECTION | M_REFRACTION
+    with pytest.raises(G.ShimError, match="max_depth <= 32"):
+        gs.render_image(SEED, integrator="whitted")
+    gs.close()

@@ -52,6 +52,31 @@ def test_per_sample_traces(pt, ref):
         assert (s1["rays"], s1["tests"], s1["draws"]) == (s2["rays"], s2["tests"], s2["draws"])
 
 
+@pytest.mark.parametrize("cfg,w,h,spp", [(1, 128, 128, 2), (2, 160, 120, 2), (4, 160, 90, 2)])
+def test_whitted_frames_bit_identical(pt, ref, cfg, w, h, spp):
+    """cast_ray (raytracer.c:556-641), compiled in the reference's TU though render() does not
+    call it as shipped: the restatement must match it bit for bit as well"""
+    sc = _scene(cfg, w, h, spp)
+    m1, b1, s1 = pt.render_pixels(sc, SEED, integrator="whitted")
+    m2, b2, s2 = ref(sc.max_depth).render_pixels(sc, SEED, integrator="whitted")
+    assert np.array_equal(m1, m2) and np.array_equal(b1, b2)
+    assert s1["rays"] == s2["rays"] and s1["tests"] == s2["tests"]
+    assert s1["tests"] == s1["casts"] * sc.n_objects and s1["draws"] == 2 * w * h * spp
+
+
+def test_whitted_every_branch_bit_identical(pt, ref):
+    from util import whitted_scene
+    sc = whitted_scene(samples=3)
+    m1, b1, s1 = pt.render_pixels(sc, SEED, integrator="whitted")
+    m2, b2, s2 = ref(sc.max_depth).render_pixels(sc, SEED, integrator="whitted")
+    assert np.array_equal(m1, m2) and np.array_equal(b1, b2)
+    assert (s1["rays"], s1["tests"]) == (s2["rays"], s2["tests"])
+    # the path tracer is unaffected by the switch having been used on the same library
+    m3, _, s3 = ref(sc.max_depth).render_pixels(sc, SEED)
+    m4, _, s4 = pt.render_pixels(sc, SEED)
+    assert np.array_equal(m3, m4) and s3["rays"] == s4["rays"] and not np.array_equal(m3, m2)
+
+
 def test_restated_pixel_loop_equals_render_as_shipped(ref):
     """SURVEY 8c check 1: the only restated lines of the harness (the pixel loop of render(),
     raytracer.c:197-221) reproduce the reference's render() byte for byte when both draw

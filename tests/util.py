@@ -74,6 +74,23 @@ def glass_scene(width=96, height=64, samples=8, max_depth=5):
     return S.custom_scene(objs, width, height, samples, max_depth, (0, 6, 38), (0, 0, 0))
 
 
+def whitted_scene(width=96, height=64, samples=2, max_depth=5):
+    """every branch of cast_ray() (raytracer.c:556-641): plain / checkered Phong surfaces, spheres
+    around its fixed light at (2, 7, 2) so that shadow rays hit and miss, a mirror, a 'glass'
+    sphere, and one with M_REFLECTION | M_REFRACTION (two children per hit)"""
+    from rt_amd import abi, scene as S
+    objs = [
+        dict(flags=abi.M_DEFAULT | abi.M_CHECKERED, radius=10000.0, center=(0, -10005.0, 0), color=(0.8, 0.8, 0.8)),
+        dict(flags=abi.M_DEFAULT, radius=4.0, center=(-11, -1, -2), color=(0.75, 0.25, 0.25)),
+        dict(flags=abi.M_REFRACTION, radius=4.0, center=(-2, -1, 2), color=(0.95, 0.95, 0.95)),
+        dict(flags=abi.M_REFLECTION, radius=4.0, center=(11, -1, -3), color=(1, 1, 1)),
+        dict(flags=abi.M_REFLECTION | abi.M_REFRACTION, radius=2.5, center=(5, -2.5, 8), color=(0.6, 0.9, 0.7)),
+        dict(flags=abi.M_DEFAULT | abi.M_CHECKERED, radius=2.0, center=(-6, -3, 9), color=(0.9, 0.8, 0.2)),
+        dict(flags=abi.M_DEFAULT, radius=1.0, center=(2, 4, 2), color=(0.2, 0.3, 0.9)),
+    ]
+    return S.custom_scene(objs, width, height, samples, max_depth, (0, 6, 38), (0, 0, 0))
+
+
 def decode_png_rgb8(path):
     """minimal PNG reader for 8-bit RGB, non-interlaced, all five filter types -> (h, w, 3) uint8"""
     import struct
