@@ -1000,6 +1000,10 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __shared__ unsigned long long wg_stats[2];
   __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3]; /* fixed-point radiance sums */
   __shared__ unsigned long long pix_key[PT_TILE_PIXELS];     /* per-pixel half of the RNG key */
+  /* per-wave queue of prepared camera samples: direction, RNG state, pixel slot (64 entries) */
+  __shared__ double q_dir[PT_BLOCK / 64][3 * 64];
+  __shared__ unsigned long long q_rng[PT_BLOCK / 64][64];
+  __shared__ uint32_t q_pix[PT_BLOCK / 64][64];
 
   const SceneCtx S = stage_scene(L, lds);
   if (threadIdx.x < 2)
@@ -1040,44 +1044,80 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   P.rng = 1;
   P.depth = 0;
   uint32_t n_rays = 0, n_casts = 0;
-  uint32_t next_job = 0;     /* wave-uniform */
+  uint32_t next_job = 0;     /* jobs handed out so far (wave-uniform) */
+  uint32_t made_jobs = 0;    /* jobs whose camera ray sits in the wave's queue (wave-uniform) */
   uint32_t pix_slot = 0;     /* 0..63 inside the tile */
   bool busy = false;
   int stack_n = 0; /* no pending-ray stack in this body */
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
+  const uint32_t lane = threadIdx.x & 63u;
+  double *const qd = q_dir[wave];
+  unsigned long long *const qr = q_rng[wave];
+  uint32_t *const qp = q_pix[wave];
 
   for (;;)
   {
-    /* ---- hand out jobs to idle lanes: wave-synchronous, deterministic ---- */
-    const unsigned long long idle = __ballot(!busy);
-    if (idle != 0 && next_job < pool)
+    /* ---- hand out jobs to idle lanes: wave-synchronous, deterministic ----
+     * Idle lanes take jobs next_job, next_job + 1, ... in lane order.  The camera rays are
+     * not generated by the few lanes that happen to be idle (about a fifth of the wave per
+     * trip: start_sample would run on every trip at 20 % lane occupancy) but 64 at a time by
+     * the whole wave into a queue in LDS, from which idle lanes only copy. */
+    unsigned long long idle = __ballot(!busy);
+    while (idle != 0 && next_job < pool)
     {
+      if (next_job == made_jobs)
+      {
+        /* queue empty: every lane, busy or not, prepares job made_jobs + lane */
+        const uint32_t job = made_jobs + lane;
+        if (job < pool)
+        {
+          DIAG(6, 1);
+          DIAG_LANES(7);
+          uint32_t idx, s;
+          if (n_valid == 16)
+          {
+            idx = job & 15u;
+            s = job >> 4;
+          }
+          else
+          {
+            s = job / n_valid;
+            idx = job - s * n_valid;
+          }
+          const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
+          const uint32_t col = idx - row * vcols;
+          const uint32_t slot_in_tile = (2u * wave + row) * PT_TILE + col;
+          Path Q;
+          start_sample(Q, cam, pix_key[slot_in_tile], tx0 + col, ty0 + row, s_begin + s);
+          qd[lane] = Q.d.x;
+          qd[64 + lane] = Q.d.y;
+          qd[128 + lane] = Q.d.z;
+          qr[lane] = Q.rng;
+          qp[lane] = slot_in_tile;
+        }
+        made_jobs = min(made_jobs + 64u, pool);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
       const uint32_t job = next_job + rank;
-      if (!busy && job < pool)
+      if (!busy && job < made_jobs)
       {
-        DIAG(6, 1);
-        DIAG_LANES(7);
-        uint32_t idx, s;
-        if (n_valid == 16)
-        {
-          idx = job & 15u;
-          s = job >> 4;
-        }
-        else
-        {
-          s = job / n_valid;
-          idx = job - s * n_valid;
-        }
-        const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
-        const uint32_t col = idx - row * vcols;
-        const uint32_t px = tx0 + col, py = ty0 + row;
-        pix_slot = (2u * wave + row) * PT_TILE + col;
-        start_sample(P, cam, pix_key[pix_slot], px, py, s_begin + s);
+        const uint32_t q = job & 63u; /* batches start at multiples of 64 */
+        P.o = cam.pos;
+        P.d = {qd[q], qd[64 + q], qd[128 + q]};
+        P.rng = qr[q];
+        pix_slot = qp[q];
+        P.T = {1, 1, 1};
+        P.Ls = {0, 0, 0};
+        P.depth = 0;
         busy = true;
       }
-      next_job += (uint32_t)__popcll(idle);
+      next_job = min(next_job + (uint32_t)__popcll(idle), made_jobs);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      idle = __ballot(!busy);
     }
     if (__ballot(busy) == 0)
       break; /* pool dry and every lane drained: the one exit, reached by all lanes together */
