@@ -176,7 +176,8 @@ int rt_hip_untile(const float *d_tiles_rgb, const uint8_t *d_tiles_rgb8, int32_t
 /* Evaluates one of the kernel's exact-arithmetic building blocks on host arrays (n values
  * each) so that tests can compare it bit for bit with IEEE results computed on the host:
  * op 0 sqrt without range scaling (valid for 0 or >= 2^-767), 1 quotient by a small integer
- * through its reciprocal, 2 library sqrt, 3 IEEE division, 4 the fused r*2^-30 - 1 mapping. */
+ * through its reciprocal, 2 library sqrt, 3 IEEE division, 4 the fused r*2^-30 - 1 mapping,
+ * 5 reciprocal without range scaling (valid for 2^-500 <= a <= 2^500). */
 int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h_out, size_t n, int device);
 
 /* ---- convenience for C hosts: whole image, host buffers, synchronous ----------- */

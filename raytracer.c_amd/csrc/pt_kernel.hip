@@ -68,15 +68,26 @@ __device__ __forceinline__ V3 v_normalize(V3 a) { return v_scale(a, 1.0 / sqrt(v
 
 __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
 
-/* raytracer.c:227 */
-__device__ __forceinline__ double rnd(uint64_t &state) { return rt_rng_double(&state); }
+/* The 31-bit draw as a double.  The empty asm keeps the value a 32-bit one for the compiler:
+ * seeing (double)(uint32_t)(x >> 33) it otherwise converts the 64-bit shift result, i.e.
+ * cvt(low half) + ldexp(cvt(high half), 32) with a high half that is always zero -- one
+ * wasted fp64 add per draw. */
+__device__ __forceinline__ double draw31(uint64_t &state)
+{
+  uint32_t r = rt_rng_next31(&state);
+  asm("" : "+v"(r));
+  return (double)r;
+}
+
+/* raytracer.c:227: r / 2^31, exact */
+__device__ __forceinline__ double rnd(uint64_t &state) { return draw31(state) * (1.0 / 2147483648.0); }
 
 /* random_range(-1, 1) (raytracer.c:229, :239) = rnd * (1 - -1) + -1.  rnd = r * 2^-31 and
  * the product by 2 are exact, so the only rounding is the final add: one fused
  * r * 2^-30 - 1 is the same double. */
 __device__ __forceinline__ double rnd_pm1(uint64_t &state)
 {
-  return __builtin_fma((double)rt_rng_next31(&state), 1.0 / 1073741824.0, -1.0);
+  return __builtin_fma(draw31(state), 1.0 / 1073741824.0, -1.0);
 }
 
 /* raytracer.c:218-220 */
@@ -165,6 +176,23 @@ __device__ __forceinline__ double sqrt_unscaled(double x)
   const double d1 = __builtin_fma(-g, g, x);
   g = __builtin_fma(d1, h, g);
   return x == 0.0 ? x : g;
+}
+
+/* 1.0 / x, correctly rounded, for 2^-500 <= x <= 2^500: hipcc's fp64 division expansion
+ * (v_rcp_f64, two Newton steps, quotient, residual, final fma) minus v_div_scale /
+ * v_div_fmas' scaling / v_div_fixup, which only act on operands outside that range (or
+ * zero / inf / NaN).  Same instructions on the same values => the same quotient.  Used where
+ * the range is known: the length of an accepted rejection sample is in [2^-30, 1]. */
+__device__ __forceinline__ double rcp_unscaled(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = 1.0 * r;
+  const double rem = __builtin_fma(-x, q, 1.0);
+  return __builtin_fma(rem, r, q);
 }
 
 /* intersect_sphere :82-117, exact.  Updates (min_t, best) with strict <. */
@@ -635,13 +663,15 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       V3 n;
       uint32_t slot;
       double tex_u = 0, tex_v = 0;
-      const bool is_tri = (uint32_t)best >= S.n_sph;
+      const bool is_tri = TRIS && (uint32_t)best >= S.n_sph;
       if (!is_tri)
       {
         const double *g = S.geom + PT_GEOM_STRIDE * best;
-        /* |p - c|^2 ~ r*r >= 1e-200: inside sqrt_unscaled's domain */
+        /* |p - c| is r to within a few ulps of the coordinates, r in [1e-100, 1e100]
+         * (rt_hip_scene_create): inside the domains of sqrt_unscaled and rcp_unscaled.  (Were
+         * p to round onto c exactly, IEEE gives 0 * inf and this 0 * NaN: NaN both.) */
         const V3 pc = v_sub(p, ld3(g));
-        n = v_scale(pc, 1.0 / sqrt_unscaled(v_dot(pc, pc)));
+        n = v_scale(pc, rcp_unscaled(sqrt_unscaled(v_dot(pc, pc))));
         slot = (uint32_t)best;
       }
       else
@@ -740,10 +770,16 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           } while (len2 > 1.0000000000000002 && ++tries < 100);
           /* len2 is 0 or >= 2^-60 (coordinates are multiples of 2^-30): sqrt_unscaled's domain */
           const double len = sqrt_unscaled(len2);
-          nd = v_scale(q, 1.0 / len);
-          if (v_dot(nd, n) < 0)
+          /* len2 == 0 needs three draws of exactly 2^30 (probability 2^-93); the reference
+           * aborts there (assert in vec3_normalize, vector.h:56) */
+          nd = v_scale(q, rcp_unscaled(len));
+          /* :250-252 flip into the normal's hemisphere, :549 cos_theta = dot(flipped, n):
+           * negating a vector negates its dot product exactly, so the second dot product
+           * is the first with the sign the flip gave it */
+          const double side = v_dot(nd, n);
+          if (side < 0)
             nd = v_scale(nd, -1);
-          weight = v_dot(nd, n); /* cos_theta :549 */
+          weight = side < 0 ? -side : side;
         }
         /* L = e + albedo (.) (L_next * cos)  ==>  forward form */
         if (!split)
@@ -1336,6 +1372,8 @@ extern "C" __global__ __launch_bounds__(256) void pt_selftest_math(int op, const
       r = a[i] / b[i];
     else if (op == 4)
       r = __builtin_fma(a[i], 1.0 / 1073741824.0, -1.0);
+    else if (op == 5)
+      r = rcp_unscaled(a[i]);
     out[i] = r;
   }
 }

@@ -676,7 +676,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
 
 int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h_out, size_t n, int device)
 {
-  if (!h_a || !h_b || !h_out || op < 0 || op > 4)
+  if (!h_a || !h_b || !h_out || op < 0 || op > 5)
     return fail(RT_HIP_EINVAL, "bad self-test arguments");
   if (device < 0 || device >= usable_devices())
     return fail(RT_HIP_ENODEV, "no HIP device %d", device);

@@ -391,6 +391,14 @@ def test_device_math_shortcuts_are_bit_exact(gpu):
     # fused [-1, 1) mapping
     r = rng.integers(0, 1 << 31, 200000).astype(np.float64)
     assert np.array_equal(run(4, r, r), (r / 2147483648.0) * (1.0 - -1.0) + -1.0)
+    # reciprocal without range scaling: lengths of accepted rejection samples (sqrt of sums of squares
+    # of multiples of 2^-30, <= 1), a broad range, and the ends of its stated domain
+    q = (rng.integers(0, 1 << 31, (300000, 3)) / 1073741824.0) - 1.0
+    l2 = (q * q).sum(axis=1)
+    lens = np.sqrt(l2[(l2 <= 1.0000000000000002) & (l2 > 0)])
+    y = np.concatenate([lens, 10.0 ** rng.uniform(-150, 150, 200000),
+                        np.array([2.0 ** -30, 1.0, 1.0 - 2.0 ** -53, 2.0 ** -500, 2.0 ** 500, 3.0, 1.0 / 3.0])])
+    assert np.array_equal(run(5, y, y), 1.0 / y), "unscaled reciprocal differs from IEEE division"
 
 
 def _random_scene(seed, with_mesh, n_tris, extra_flags=()):
