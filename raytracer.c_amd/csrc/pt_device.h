@@ -75,7 +75,19 @@ struct PtSceneView
   const uint32_t *bvh_tri;
   uint32_t n_spheres, n_meshes, n_triangles, any_checker;
   uint32_t any_refract, n_bvh_nodes; /* n_bvh_nodes == 0: triangles go through the flat filter */
+  uint32_t wide_range, pad_;         /* a centre or radius beyond 1e17: fp32 sums could overflow */
 };
+
+/* Small scenes keep the filter table in LDS and (sphere-only ones) use the sign-test form of
+ * the filter, whose NaN-free argument needs every |c|, r <= 1e17; everything else streams the
+ * table through scalar loads and keeps the NaN-safe compares. */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline bool pt_filter_in_lds(const PtSceneView &sc)
+{
+  return (uint64_t)sc.n_spheres + sc.n_triangles <= PT_FILT_LDS_MAX && !sc.wide_range;
+}
 
 struct PtCamera
 {
@@ -93,6 +105,7 @@ struct PtLaunch
    * they would occupy -- and spill -- vector registers): near_R^2, width-1, height-1 as the
    * reference forms them, (double)options->width - 1.0 (raytracer.c:203-204) */
   double near_R2, w_minus_1, h_minus_1;
+  double filt_shift; /* 10 e (max |c| + near_R): how far behind the origin the sign-test filter starts its ray */
   double inv_w_minus_1, inv_h_minus_1; /* RN(1/(W-1)), RN(1/(H-1)) for div_small_int */
   double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;

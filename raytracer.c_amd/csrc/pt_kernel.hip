@@ -340,13 +340,31 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
                                               uint32_t n_entries, const V3 &o, const V3 &d, double &min_t,
                                               int &best, double &bary_u, double &bary_v,
                                               unsigned long long *diag_ptr, const float *bvh_nodes = nullptr,
-                                              uint32_t n_bvh_nodes = 0, const uint32_t *bvh_tri = nullptr)
+                                              uint32_t n_bvh_nodes = 0, const uint32_t *bvh_tri = nullptr,
+                                              double filt_shift = 0.0)
 {
   /* with a hierarchy the flat filter covers the spheres only */
   if (BVH)
     n_entries = n_sph;
+  /* SHIFT form of the filter (small sphere-only scenes, i.e. the headline kernel): both
+   * rejects become SIGN tests, so a primitive's keep bit costs two integer instructions
+   * (or, funnel shift) instead of two compares, a scalar and, and an add-with-carry.
+   *   - "tca < -tol": the filter's ray starts tol_max = filt_shift behind the real origin,
+   *     o' = o - tol_max d.  That adds tol_max |d|^2 to every tca and leaves the distance of
+   *     a centre from the ray's line, d2, where it was (to (1 - |d|^2) (2 tol tca + tol^2),
+   *     ~1e-14); with tol_max = 10 e (max |c| + near_R) >= every per-sphere tolerance,
+   *     tca >= 0 implies tca32' >= 0.9998 tol_max - 6.2 e (A + 1.0001 tol_max) > 0: sign clear.
+   *   - "d2 > r2_hi": the squared-length chain starts from -r2_hi, so that
+   *     q = tca^2 - (|L|^2 - r2_hi) = r2_hi - d2 and the reject is q < 0 (pt_build_filter
+   *     widens r2_hi for the three roundings that now see r2_hi).
+   * A NaN's sign is arbitrary: rays with non-finite o skip the filter (far_origin), rays with
+   * non-finite d hit nothing in the exact test either, and scenes whose centres or radii are
+   * outside fp32's comfortable range never use this form (pt_filter_in_lds). */
+  constexpr bool SHIFT = FILT_LDS && !TRIS;
   /* the ray in fp32 (round to nearest: relative error <= 2^-24, part of the bound) */
-  const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  const float ox = SHIFT ? (float)(o.x - filt_shift * d.x) : (float)o.x;
+  const float oy = SHIFT ? (float)(o.y - filt_shift * d.y) : (float)o.y;
+  const float oz = SHIFT ? (float)(o.z - filt_shift * d.z) : (float)o.z;
   const f32x2 dx = {(float)d.x, (float)d.x}, dy = {(float)d.y, (float)d.y}, dz = {(float)d.z, (float)d.z};
   const bool far_origin = !(v_dot(o, o) <= near_R2); /* also true for NaN */
 
@@ -366,6 +384,16 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     auto filter_pair = [&](const PairRec &g, uint32_t &word, uint32_t shift) {
       const f32x2 lx = g.cx - ox, ly = g.cy - oy, lz = g.cz - oz;
       const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
+      if (SHIFT)
+      {
+        const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, __builtin_elementwise_fma(lx, lx, -g.r2_hi)));
+        const f32x2 q = __builtin_elementwise_fma(tca, tca, -ll);
+        /* pairs arrive in DESCENDING order: shifting sign bits in leaves bit k = primitive k;
+         * a set bit means DROP here, the word is inverted after the loop */
+        word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.y) | __float_as_uint(q.y), 31);
+        word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.x) | __float_as_uint(q.x), 31);
+        return;
+      }
       const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, lx * lx));
       const f32x2 d2 = __builtin_elementwise_fma(-tca, tca, ll);
       if (FILT_LDS)
@@ -401,6 +429,11 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       };
       run_desc(pairs_lo - 1u, pairs_lo, cand_lo);
       run_desc(n_pairs - 1u, n_pairs - pairs_lo, cand_hi);
+      if (SHIFT)
+      { /* drop bits -> keep bits */
+        cand_lo = ~cand_lo;
+        cand_hi = ~cand_hi;
+      }
     }
     else
     {
@@ -493,6 +526,7 @@ struct SceneCtx
   const uint32_t *bvh_tri;
   uint32_t n_bvh_nodes;
   double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
+  double filt_shift;      /* tol_max of the sign-test filter form (scan_filtered) */
   uint32_t n_sph, n_tri;
   int max_depth;
 };
@@ -519,7 +553,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
    * it through the constant cache. */
   const uint32_t n_entries = n_sph + sc.n_triangles;
   f32x2 *filt_lds = nullptr;
-  if (n_entries <= PT_FILT_LDS_MAX)
+  if (pt_filter_in_lds(sc))
   {
     filt_lds = reinterpret_cast<f32x2 *>(mat + PT_MAT_STRIDE * (size_t)n_mat);
     const uint32_t n_slots = PT_FILT_STRIDE * ((n_entries + 1u) / 2u + 1u); /* + the look-ahead pair */
@@ -541,6 +575,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.bvh_tri = sc.bvh_tri;
   ctx.n_bvh_nodes = sc.n_bvh_nodes;
   ctx.near_R2 = L.near_R2;
+  ctx.filt_shift = L.filt_shift;
   ctx.n_sph = n_sph;
   ctx.n_tri = sc.n_triangles;
   ctx.max_depth = L.max_depth;
@@ -652,7 +687,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
     else
       scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
                                              S.n_sph + S.n_tri, o, d, min_t, best, bary_u, bary_v, diag_ptr,
-                                             S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri);
+                                             S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift);
 
     if (best >= 0)
     {
@@ -836,7 +871,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
     double bary_u = 0, bary_v = 0;
     scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
                                                      S.n_sph + S.n_tri, o, d, min_t, best, bary_u, bary_v, diag_ptr,
-                                                     S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri);
+                                                     S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift);
     if (best >= 0)
     {
       const V3 p = v_add(o, v_scale(d, min_t));
@@ -866,7 +901,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
       int blocker = -1;
       scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
                                                        S.n_sph + S.n_tri, p, ldir, shadow_t, blocker, su, sv, diag_ptr,
-                                                       S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri);
+                                                       S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift);
       const double lit = blocker >= 0 ? 0.0 : 1.0;
 
       if (flags & PT_FLAG_CHECKER)
@@ -1434,7 +1469,9 @@ extern "C" __global__ __launch_bounds__(256) void pt_build_filter(const double *
       f[0] = (float)src[0];
       f[2] = (float)src[1];
       f[4] = (float)src[2];
-      f[6] = (float)((src[3] + 32.0 * e * A * A) * (1.0 + 4.0 * e));
+      /* (1 + 8 e): one e for this conversion, the rest for the roundings of the chain that
+       * carries -r2_hi as its addend (scan_filtered, SHIFT form: 3 e max(r2_hi, A^2)) */
+      f[6] = (float)((src[3] + 32.0 * e * A * A) * (1.0 + 8.0 * e));
       f[8] = -(float)((src[5] + 10.0 * e * A) * (1.0 + 4.0 * e));
     }
     else
@@ -1486,7 +1523,7 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
 {
   size_t doubles = PT_GEOM_STRIDE * (size_t)sc.n_spheres + PT_MAT_STRIDE * (size_t)(sc.n_spheres + sc.n_meshes);
   const size_t n_entries = (size_t)sc.n_spheres + sc.n_triangles;
-  if (n_entries <= PT_FILT_LDS_MAX)
+  if (pt_filter_in_lds(sc))
     doubles += PT_FILT_STRIDE * ((n_entries + 1) / 2 + 1); /* f32x2 = one double-sized slot */
   return doubles * sizeof(double);
 }
@@ -1507,7 +1544,7 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
                          launch.scene.bvh_src, n_nodes, launch.near_R, launch.scene.bvh_nodes);
   }
   const bool tris = launch.scene.n_triangles != 0;
-  const bool big = (size_t)launch.scene.n_spheres + launch.scene.n_triangles > PT_FILT_LDS_MAX;
+  const bool big = !pt_filter_in_lds(launch.scene);
   const bool refr = launch.scene.any_refract != 0, chk = launch.scene.any_checker != 0;
   typedef void (*Kernel)(const PtLaunch);
   static const Kernel family[12] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,

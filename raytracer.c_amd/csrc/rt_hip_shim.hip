@@ -33,6 +33,7 @@ struct RtHipScene
   double reach = 0;     /* >= |p| for every point p on a primitive of ordinary size (radius < 1000) */
   double max_emission = 0; /* max |emission component| over all materials */
   bool any_mirror_glass = false; /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children */
+  double max_center = 0; /* max |centre| over the spheres (rounded up) */
 };
 
 namespace
@@ -361,7 +362,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     return fail(RT_HIP_ELIMIT, "%zu spheres + %zu meshes exceed the 24 KiB LDS staging area (6 workgroups per CU)", n_spheres, n_meshes);
 
   /* ---- build the kernel layout on the host (pt_device.h) ---- */
-  double reach = 0, max_emission = 0;
+  double reach = 0, max_emission = 0, max_center = 0;
+  bool wide_range = false;
   for (size_t i = 0; i < n_spheres; i++)
     max_emission = std::fmax(max_emission, max_abs3(spheres[i].emission));
   for (size_t m = 0; m < n_meshes; m++)
@@ -384,6 +386,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     /* |c|, rounded up: feeds the conservative phase-1 thresholds only, never a result */
     g[4] = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) * (1.0 + 1e-12);
     g[5] = 0.0; /* a sphere is rejected when its centre is behind the origin at all (raytracer.c:84) */
+    max_center = std::fmax(max_center, g[4]);
+    wide_range |= !(g[4] <= 1e17) || !(std::fabs(spheres[i].radius) <= 1e17);
     if (std::fabs(spheres[i].radius) < 1000.0) /* wall-sized spheres would only loosen the filter */
       reach = std::fmax(reach, g[4] + std::fabs(spheres[i].radius));
     put_material(&mat[PT_MAT_STRIDE * i], spheres[i].flags, spheres[i].color, spheres[i].emission);
@@ -439,7 +443,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
 
   /* ---- hierarchy over the triangles of large meshes ---- */
   BvhBuild bvh;
-  if (n_spheres + n_tri > PT_FILT_LDS_MAX && n_tri > 0)
+  if ((n_spheres + n_tri > PT_FILT_LDS_MAX || wide_range) && n_tri > 0) /* = !pt_filter_in_lds() */
   {
     bvh.tgeom = tgeom.data();
     bvh.order.resize(n_tri);
@@ -520,6 +524,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.n_triangles = (uint32_t)n_tri;
   sc->view.any_checker = any_checker ? 1u : 0u;
   sc->view.any_refract = any_refract ? 1u : 0u;
+  sc->view.wide_range = wide_range ? 1u : 0u;
+  sc->max_center = max_center;
   sc->reach = reach;
   sc->max_emission = max_emission;
   sc->any_mirror_glass = any_mirror_glass;
@@ -633,6 +639,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     if (!(L.near_R < 1e15))
       return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.near_R);
     L.near_R2 = L.near_R * L.near_R;
+    L.filt_shift = 10.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
     L.w_minus_1 = (double)params->width - 1.0;
     L.h_minus_1 = (double)params->height - 1.0;
     L.inv_w_minus_1 = 1.0 / L.w_minus_1; /* IEEE division on the host: correctly rounded */
