@@ -1059,6 +1059,9 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 5
 #endif
+#ifndef PT_MIN_WAVES_TRI
+#define PT_MIN_WAVES_TRI 5
+#endif
 /* Pooled kernel body.  Not for scenes with M_REFRACTION: there the throughput is not bounded
  * by 1 (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes
  * negative), so no fixed-point scale can be fixed in advance; those scenes use the static body. */
@@ -1244,8 +1247,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   extern "C" __global__ bounds void name(const PtLaunch L) { render_tiles_pooled<CHECKER, TRIS, FILT_LDS>(L); }
 PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, true)
 PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
-PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, true, true)
-PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, true, false)
+PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_TRI), false, true, true)
+PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_TRI), false, true, false)
 PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK), true, false, true)
 PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK), true, false, false)
 PT_KERNEL(pt_render_tiles_tri_chk, __launch_bounds__(PT_BLOCK), true, true, true)

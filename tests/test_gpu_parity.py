@@ -645,10 +645,15 @@ def test_wide_range_scene_keeps_the_nan_safe_filter(gpu, pt):
         dict(flags=abi.M_DEFAULT, radius=4.0, center=(-6, -1, 0), color=(0.75, 0.25, 0.25)),
         dict(flags=abi.M_REFLECTION, radius=4.0, center=(6, -1, 0), color=(1, 1, 1)),
         dict(flags=abi.M_DEFAULT, radius=3.0, center=(0, 9, -4), color=(1, 1, 1), emission=(6, 6, 6)),
-        dict(flags=abi.M_DEFAULT, radius=1.0, center=(1e25, 0, 0), color=(0.5, 0.5, 0.5)),
         dict(flags=abi.M_DEFAULT, radius=1e30, center=(0, 0, 1e30 + 60.0), color=(0.3, 0.4, 0.8)),
     ]
     _full(gpu, pt, S.custom_scene(objs, 64, 40, 6, 5, (0, 4, 30), (0, 0, 0)))
+    # (a SMALL sphere that far out is refused: it would stretch the filter's range, near_R)
+    far = objs + [dict(flags=abi.M_DEFAULT, radius=1.0, center=(1e25, 0, 0), color=(0.5, 0.5, 0.5))]
+    gs = gpu.GpuScene(S.custom_scene(far, 16, 16, 1, 2, (0, 4, 30), (0, 0, 0)))
+    with pytest.raises(gpu.ShimError, match="finite bound"):
+        gs.render_image(SEED)
+    gs.close()
     tri = [[(-3, -4.9, 3, 0, 0), (3, -4.9, 3, 1, 0), (0, 2, 3, 0, 1)], [(-3, -4.9, 3, 0, 0), (0, 2, 3, 0, 1), (3, -4.9, 3, 1, 0)]]
     meshes = [dict(flags=abi.M_DEFAULT, color=(0.9, 0.8, 0.2), triangles=tri)]
     _full(gpu, pt, S.custom_scene(objs, 48, 32, 4, 4, (0, 4, 30), (0, 0, 0), meshes=meshes))
