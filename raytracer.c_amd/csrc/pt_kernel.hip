@@ -661,6 +661,38 @@ __device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uin
  * CHECKER: scene has M_CHECKERED materials (atan2 / fmod code; its polynomial constants
  * would otherwise be hoisted into -- and spilled from -- registers of every scene).
  * TRIS: scene has triangles.  FILT_LDS: the filter table is staged in LDS (small scenes). */
+/* One round of random_in_unit_sphere (raytracer.c:231-241): x, y, z drawn in that order.
+ * Returns true when the round must be repeated.  Reference: while (sqrt(len2) > 1); with a
+ * correctly rounded sqrt, sqrt(x) > 1  <=>  x > 1 + 2^-52 (x = 1 + 2^-52 still rounds to 1.0),
+ * so the square root is taken once, after the last round (tests/test_host.py checks the
+ * equivalence around the boundary). */
+__device__ __forceinline__ bool rejection_round(uint64_t &rng, V3 &q, double &len2)
+{
+  q.x = rnd_pm1(rng);
+  q.y = rnd_pm1(rng);
+  q.z = rnd_pm1(rng);
+  len2 = v_dot(q, q);
+  return len2 > 1.0000000000000002;
+}
+
+/* random_on_hemisphere's tail (:242-253) and the cos_theta of :549 for an accepted sample q */
+__device__ __forceinline__ V3 hemisphere_from_sample(const V3 &q, double len2, const V3 &n, double &weight)
+{
+  /* len2 is 0 or >= 2^-60 (coordinates are multiples of 2^-30): sqrt_unscaled's domain.
+   * len2 == 0 needs three draws of exactly 2^30 (probability 2^-93); the reference aborts
+   * there (assert in vec3_normalize, vector.h:56) */
+  const double len = sqrt_unscaled(len2);
+  V3 nd = v_scale(q, rcp_unscaled(len));
+  /* :250-252 flip into the normal's hemisphere, :549 cos_theta = dot(flipped, n): negating a
+   * vector negates its dot product exactly, so the second dot product is the first with the
+   * sign the flip gave it */
+  const double side = v_dot(nd, n);
+  if (side < 0)
+    nd = v_scale(nd, -1);
+  weight = side < 0 ? -side : side;
+  return nd;
+}
+
 template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
                                            unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
@@ -786,35 +818,18 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         }
         else
         {
-          /* random_on_hemisphere :231-253: x, y, z drawn in that order */
+          /* random_on_hemisphere :231-253 */
           V3 q;
           double len2;
           int tries = 0;
+          bool again;
           do
           {
             DIAG(10, 1);
             DIAG_LANES(11);
-            q.x = rnd_pm1(P.rng);
-            q.y = rnd_pm1(P.rng);
-            q.z = rnd_pm1(P.rng);
-            len2 = v_dot(q, q);
-            /* reference: while (sqrt(len2) > 1).  With correctly rounded sqrt,
-             * sqrt(x) > 1  <=>  x > 1 + 2^-52 (x = 1 + 2^-52 still rounds to 1.0), so the
-             * square root is taken once, after the loop (tests/test_host.py checks the
-             * equivalence around the boundary). */
-          } while (len2 > 1.0000000000000002 && ++tries < 100);
-          /* len2 is 0 or >= 2^-60 (coordinates are multiples of 2^-30): sqrt_unscaled's domain */
-          const double len = sqrt_unscaled(len2);
-          /* len2 == 0 needs three draws of exactly 2^30 (probability 2^-93); the reference
-           * aborts there (assert in vec3_normalize, vector.h:56) */
-          nd = v_scale(q, rcp_unscaled(len));
-          /* :250-252 flip into the normal's hemisphere, :549 cos_theta = dot(flipped, n):
-           * negating a vector negates its dot product exactly, so the second dot product
-           * is the first with the sign the flip gave it */
-          const double side = v_dot(nd, n);
-          if (side < 0)
-            nd = v_scale(nd, -1);
-          weight = side < 0 ? -side : side;
+            again = rejection_round(P.rng, q, len2);
+          } while (again && ++tries < 100);
+          nd = hemisphere_from_sample(q, len2, n, weight);
         }
         /* L = e + albedo (.) (L_next * cos)  ==>  forward form */
         if (!split)
