@@ -26,13 +26,16 @@
  *   tri_tex    [n_triangles] x 6 f64 : st0, st1, st2 (read only for a winning triangle of an
  *       M_CHECKERED mesh).
  *   tri_object [n_triangles] u32     : material slot of the owning mesh.
- *   bvh_src    [n_bvh_nodes] x 8 f64 : for meshes beyond PT_FILT_LDS_MAX primitives, a bounding-
- *       volume hierarchy over the triangles in depth-first order: box min xyz, box max xyz,
- *       then {skip, first, count} packed as three u32 + pad in the last two doubles.  `skip` =
- *       index of the next node when this subtree is left (stackless traversal); leaves have
- *       count > 0 and reference bvh_tri[first .. first+count).
- *   bvh_nodes  [n_bvh_nodes] x 8 u32/f32 : the per-launch fp32 copy, boxes widened by a bound
- *       on the fp32 ray/box arithmetic (pt_build_filter), same {skip, first, count} tail.
+ *   bvh_src    [n_bvh_nodes] x 16 f64 : for meshes beyond PT_FILT_LDS_MAX primitives, a binary
+ *       bounding-volume hierarchy over the triangles.  A node holds the boxes of its TWO children
+ *       (child 0: min xyz, max xyz; child 1: the same) and their references packed as two u32
+ *       in double 12: an inner child is its node index, a leaf child is
+ *       PT_BVH_LEAF_FLAG | first << 3 | count and covers bvh_tri[first .. first+count).  Node 0
+ *       is the root; the tree is balanced (median splits), depth <= PT_BVH_STACK.
+ *   bvh_nodes  [n_bvh_nodes] x 16 u32/f32 : the per-launch fp32 copy (pt_build_bvh): the six
+ *       planes as (child 0, child 1) pairs -- min x, max x, min y, max y, min z, max z -- so one
+ *       packed-fp32 instruction serves both children; boxes widened by a bound on the fp32
+ *       ray/box arithmetic; then the two references.
  *   bvh_tri    [n_triangles] u32     : triangle indices in leaf order.
  */
 #ifndef PT_DEVICE_H
@@ -46,8 +49,13 @@
 #define PT_BLOCK 256        /* 4 wavefronts: 64 pixels x 4 slices */
 #define PT_MAT_STRIDE 8     /* doubles per material record */
 #define PT_FILT_LDS_MAX 256  /* primitives up to which the filter table is also staged in LDS */
-#define PT_BVH_LEAF 4         /* max triangles per BVH leaf */
-#define PT_BVH_NODE_WORDS 8   /* 32-byte device node: 6 f32 box + skip + (first << 3 | count) */
+#ifndef PT_BVH_LEAF
+#define PT_BVH_LEAF 4         /* max triangles per BVH leaf (<= 7: the count has 3 bits) */
+#endif
+#define PT_BVH_NODE_WORDS 16  /* 64-byte device node: 6 f32x2 planes (child 0, child 1) + 2 refs + pad */
+#define PT_BVH_SRC_DOUBLES 16 /* fp64 source node: 2 x (min xyz, max xyz), refs, pad */
+#define PT_BVH_LEAF_FLAG 0x80000000u
+#define PT_BVH_STACK 24       /* per-lane traversal stack (LDS): tree depth limit */
 #define PT_GEOM_STRIDE 4     /* LDS doubles per sphere: cx cy cz r2 */
 #define PT_FILT_STRIDE 5     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
 #define PT_ENTRY_SRC_STRIDE 6 /* HBM doubles per primitive: cx cy cz R2 |c| Rb (bounding data, fp64) */

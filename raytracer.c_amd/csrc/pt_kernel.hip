@@ -253,58 +253,87 @@ __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, 
   }
 }
 
-/* Stackless walk of the triangle hierarchy (pt_device.h: bvh_nodes).  Per lane: node i's
- * widened fp32 box against the ray by the slab test, in fp32, made conservative --
+/* Ordered walk of the triangle hierarchy (pt_device.h: bvh_nodes).  Per lane and per visit:
+ * the widened fp32 boxes of the node's TWO children against the ray by the slab test, both
+ * in the same packed-fp32 instructions, made conservative --
  *   boxes were widened at launch by 4 e (near_R + |b|) (covers rounding o to fp32 and the
  *   subtraction b - o), and the slab distances are widened by 4 e |t| (covers rounding d,
  *   the reciprocal and the product; e = 2^-24) --
  * so a box that contains an exact hit closer than min_t is never skipped.  v_min/v_max
  * ignore NaN (0 * inf on an axis-parallel ray touching a slab plane), which leaves the
- * other, correct bound.  Leaves run the exact fp64 triangle test. */
+ * other, correct bound.  The nearer child is entered first and the other waits on a
+ * per-lane stack in LDS (the tree is balanced: at most PT_BVH_STACK deep), so the first
+ * leaves reached usually hold the closest hit and min_t prunes what lies behind it.  Leaves
+ * run the exact fp64 triangle test; with the (t, index) tie rule the outcome does not depend
+ * on the visiting order. */
 __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, uint32_t n_nodes,
                                              const uint32_t *__restrict__ tri_order, const double *tri_geom,
                                              uint32_t n_sph, bool far_origin, const V3 &o, const V3 &d,
                                              double &min_t, int &best, double &bary_u, double &bary_v,
                                              unsigned long long *diag_ptr)
 {
-  const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-  const float ix = 1.0f / (float)d.x, iy = 1.0f / (float)d.y, iz = 1.0f / (float)d.z;
+  __shared__ uint32_t stack[PT_BVH_STACK][PT_BLOCK]; /* entry-major: conflict-free per wave */
+  if (n_nodes == 0)
+    return;
+  const f32x2 ox = {(float)o.x, (float)o.x}, oy = {(float)o.y, (float)o.y}, oz = {(float)o.z, (float)o.z};
+  const float ixs = 1.0f / (float)d.x, iys = 1.0f / (float)d.y, izs = 1.0f / (float)d.z;
+  const f32x2 ix = {ixs, ixs}, iy = {iys, iys}, iz = {izs, izs};
   const float widen = 4.0f * 5.9604644775390625e-08f;
-  uint32_t i = 0;
-  while (i < n_nodes)
+  uint32_t sp = 0;
+  uint32_t ref = 0; /* the root node */
+  for (;;)
   {
-    DIAG(13, 1);
-    const float4 a = *reinterpret_cast<const float4 *>(nodes + PT_BVH_NODE_WORDS * (size_t)i);
-    const float4 b = *reinterpret_cast<const float4 *>(nodes + PT_BVH_NODE_WORDS * (size_t)i + 4);
-    const uint32_t skip = __float_as_uint(b.z), packed = __float_as_uint(b.w);
-    const float tx1 = (a.x - ox) * ix, tx2 = (a.w - ox) * ix;
-    const float ty1 = (a.y - oy) * iy, ty2 = (b.x - oy) * iy;
-    const float tz1 = (a.z - oz) * iz, tz2 = (b.y - oz) * iz;
-    float tnear = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-    float tfar = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-    tnear -= fabsf(tnear) * widen;
-    tfar += fabsf(tfar) * widen;
-    /* min_t rounded up to fp32; a node starting beyond the closest hit so far cannot matter */
-    const float tmax = __double2float_ru(min_t);
-    const bool hit = far_origin || (tfar >= tnear && tfar >= 0.0f && tnear <= tmax);
-    if (!hit)
+    if (ref & PT_BVH_LEAF_FLAG)
     {
-      i = skip;
-      continue;
+      const uint32_t first = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
+      for (uint32_t k = 0; k < count; k++)
+      {
+        DIAG(14, 1);
+        const uint32_t t = tri_order[first + k];
+        exact_triangle<true>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v);
+      }
     }
-    const uint32_t count = packed & 7u;
-    if (count == 0)
+    else
     {
-      i = i + 1;
-      continue;
+      DIAG(13, 1);
+      DIAG_LANES(15);
+      const float4 *node = reinterpret_cast<const float4 *>(nodes + PT_BVH_NODE_WORDS * (size_t)ref);
+      const float4 px = node[0], py = node[1], pz = node[2], tail = node[3];
+      /* (min, max) planes of (child 0, child 1) */
+      const f32x2 tx1 = (f32x2{px.x, px.y} - ox) * ix, tx2 = (f32x2{px.z, px.w} - ox) * ix;
+      const f32x2 ty1 = (f32x2{py.x, py.y} - oy) * iy, ty2 = (f32x2{py.z, py.w} - oy) * iy;
+      const f32x2 tz1 = (f32x2{pz.x, pz.y} - oz) * iz, tz2 = (f32x2{pz.z, pz.w} - oz) * iz;
+      float tn0 = fmaxf(fmaxf(fminf(tx1.x, tx2.x), fminf(ty1.x, ty2.x)), fminf(tz1.x, tz2.x));
+      float tf0 = fminf(fminf(fmaxf(tx1.x, tx2.x), fmaxf(ty1.x, ty2.x)), fmaxf(tz1.x, tz2.x));
+      float tn1 = fmaxf(fmaxf(fminf(tx1.y, tx2.y), fminf(ty1.y, ty2.y)), fminf(tz1.y, tz2.y));
+      float tf1 = fminf(fminf(fmaxf(tx1.y, tx2.y), fmaxf(ty1.y, ty2.y)), fmaxf(tz1.y, tz2.y));
+      tn0 -= fabsf(tn0) * widen;
+      tf0 += fabsf(tf0) * widen;
+      tn1 -= fabsf(tn1) * widen;
+      tf1 += fabsf(tf1) * widen;
+      /* min_t rounded up to fp32; a box starting beyond the closest hit so far cannot matter */
+      const float tmax = __double2float_ru(min_t);
+      const bool hit0 = far_origin || (tf0 >= tn0 && tf0 >= 0.0f && tn0 <= tmax);
+      const bool hit1 = far_origin || (tf1 >= tn1 && tf1 >= 0.0f && tn1 <= tmax);
+      const uint32_t r0 = __float_as_uint(tail.x), r1 = __float_as_uint(tail.y);
+      if (hit0 && hit1)
+      {
+        const bool zero_first = !(tn1 < tn0);
+        stack[sp][threadIdx.x] = zero_first ? r1 : r0;
+        sp++;
+        ref = zero_first ? r0 : r1;
+        continue;
+      }
+      if (hit0 || hit1)
+      {
+        ref = hit0 ? r0 : r1;
+        continue;
+      }
     }
-    const uint32_t first = packed >> 3;
-    for (uint32_t k = 0; k < count; k++)
-    {
-      const uint32_t t = tri_order[first + k];
-      exact_triangle<true>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v);
-    }
-    i = skip;
+    if (sp == 0)
+      break;
+    sp--;
+    ref = stack[sp][threadIdx.x];
   }
 }
 
@@ -1263,7 +1292,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, true)
 PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
 PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_TRI), false, true, true)
-PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_TRI), false, true, false)
+PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, 4), false, true, false) /* 24 KB of traversal stacks: 4 workgroups per CU */
 PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK), true, false, true)
 PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK), true, false, false)
 PT_KERNEL(pt_render_tiles_tri_chk, __launch_bounds__(PT_BLOCK), true, true, true)
@@ -1450,25 +1479,29 @@ hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *
  *   triangle: R2 = Rb^2 of its bounding sphere, Rb = that radius (the hit point is inside the
  *   bounding sphere, so the centre is at most Rb behind the origin).
  * Thresholds are rounded away from the accept region when stored as fp32. */
-/* fp32 hierarchy nodes for one launch: boxes widened by 4 e (near_R + |b|) and rounded
- * outward (see bvh_traverse); tail = skip link and (first << 3 | count). */
+/* fp32 hierarchy nodes for one launch: the planes of a node's two children as (child 0,
+ * child 1) pairs, boxes widened by 4 e (near_R + |b|) and rounded outward (see bvh_traverse);
+ * then the two child references. */
 extern "C" __global__ __launch_bounds__(256) void pt_build_bvh(const double *bvh_src, uint32_t n_nodes, double near_R,
                                                               float *nodes)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x)
   {
-    const double *src = bvh_src + 8 * (size_t)i;
+    const double *src = bvh_src + PT_BVH_SRC_DOUBLES * (size_t)i;
     float *dst = nodes + PT_BVH_NODE_WORDS * (size_t)i;
     const double e = 5.9604644775390625e-08;
-    for (int k = 0; k < 3; k++)
-    {
-      const double lo = src[k], hi = src[3 + k];
-      dst[k] = __double2float_rd(lo - 4.0 * e * (near_R + fabs(lo)));
-      dst[3 + k] = __double2float_ru(hi + 4.0 * e * (near_R + fabs(hi)));
-    }
-    const uint32_t *tail = reinterpret_cast<const uint32_t *>(src + 6); /* skip, first, count */
-    dst[6] = __uint_as_float(tail[0]);
-    dst[7] = __uint_as_float((tail[1] << 3) | tail[2]);
+    for (int c = 0; c < 2; c++)
+      for (int k = 0; k < 3; k++)
+      {
+        const double lo = src[6 * c + k], hi = src[6 * c + 3 + k];
+        dst[4 * k + c] = __double2float_rd(lo - 4.0 * e * (near_R + fabs(lo)));
+        dst[4 * k + 2 + c] = __double2float_ru(hi + 4.0 * e * (near_R + fabs(hi)));
+      }
+    const uint32_t *refs = reinterpret_cast<const uint32_t *>(src + 12);
+    dst[12] = __uint_as_float(refs[0]);
+    dst[13] = __uint_as_float(refs[1]);
+    dst[14] = 0.f;
+    dst[15] = 0.f;
   }
 }
 

@@ -138,17 +138,19 @@ void put_material(double *m, uint32_t flags, const double *color, const double *
 }
 
 /* ---- bounding-volume hierarchy over triangles (meshes beyond PT_FILT_LDS_MAX primitives) ----
- * Median split on the longest axis of the centroid bounds, leaves of <= PT_BVH_LEAF
- * triangles, nodes emitted in depth-first order with a `skip` link, so the device walks the
- * tree without a stack: hit -> next node, miss or leaf done -> node[skip].  The hierarchy only
- * decides WHICH triangles get the exact test; the exact test and the (t, index) tie rule
- * decide the result, so any valid hierarchy gives the linear scan's answer. */
+ * Binary tree, median split on the longest axis of the centroid bounds (balanced: depth =
+ * ceil(log2(leaves))), leaves of <= PT_BVH_LEAF triangles.  A node stores the boxes of its two
+ * children, so the device tests both with one set of packed-fp32 instructions, descends into
+ * the nearer one first and keeps the other on a small per-lane stack (bvh_traverse).  The
+ * hierarchy only decides WHICH triangles get the exact test; the exact test and the
+ * (t, index) tie rule decide the result, so any valid hierarchy gives the linear scan's answer. */
 struct BvhBuild
 {
   const double *tgeom;              /* n_tri x 9: v0, e1, e2 */
   std::vector<uint32_t> order;      /* triangle indices, permuted in place */
-  std::vector<double> nodes;        /* 8 doubles per node */
+  std::vector<double> nodes;        /* PT_BVH_SRC_DOUBLES per node: the two children's boxes + refs */
   std::vector<double> cen, lo, hi;  /* per triangle: centroid, box */
+  int depth = 0;                    /* inner nodes on the longest root-to-leaf path */
 
   void tri_box(uint32_t t)
   {
@@ -164,48 +166,60 @@ struct BvhBuild
     }
   }
 
-  uint32_t build(uint32_t begin, uint32_t end)
+  /* Builds the subtree over order[begin, end) and returns its reference (a leaf reference or
+   * the index of its inner node); box[0..5] receives its bounds. */
+  uint32_t build(uint32_t begin, uint32_t end, double *box, int level)
   {
-    const uint32_t me = (uint32_t)(nodes.size() / 8);
-    nodes.resize(nodes.size() + 8);
-    double bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
     double cl[3] = {1e300, 1e300, 1e300}, ch[3] = {-1e300, -1e300, -1e300};
+    for (int k = 0; k < 3; k++)
+    {
+      box[k] = 1e300;
+      box[3 + k] = -1e300;
+    }
     for (uint32_t i = begin; i < end; i++)
       for (int k = 0; k < 3; k++)
       {
         const uint32_t t = order[i];
-        bl[k] = std::fmin(bl[k], lo[3 * t + k]);
-        bh[k] = std::fmax(bh[k], hi[3 * t + k]);
+        box[k] = std::fmin(box[k], lo[3 * t + k]);
+        box[3 + k] = std::fmax(box[3 + k], hi[3 * t + k]);
         cl[k] = std::fmin(cl[k], cen[3 * t + k]);
         ch[k] = std::fmax(ch[k], cen[3 * t + k]);
       }
-    uint32_t first = 0, count = 0;
     if (end - begin <= PT_BVH_LEAF)
-    {
-      first = begin;
-      count = end - begin;
-    }
-    else
-    {
-      int axis = 0;
-      if (ch[1] - cl[1] > ch[axis] - cl[axis]) axis = 1;
-      if (ch[2] - cl[2] > ch[axis] - cl[axis]) axis = 2;
-      const uint32_t mid = begin + (end - begin) / 2;
-      std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end,
-                       [&](uint32_t a, uint32_t b) { return cen[3 * a + axis] < cen[3 * b + axis]; });
-      build(begin, mid);
-      build(mid, end);
-    }
-    const uint32_t skip = (uint32_t)(nodes.size() / 8);
-    double *n = &nodes[8 * (size_t)me];
-    for (int k = 0; k < 3; k++)
-    {
-      n[k] = bl[k];
-      n[3 + k] = bh[k];
-    }
-    uint32_t tail[4] = {skip, first, count, 0};
-    memcpy(&n[6], tail, sizeof tail);
+      return PT_BVH_LEAF_FLAG | (begin << 3) | (end - begin);
+    const uint32_t me = (uint32_t)(nodes.size() / PT_BVH_SRC_DOUBLES);
+    nodes.resize(nodes.size() + PT_BVH_SRC_DOUBLES, 0.0);
+    depth = std::max(depth, level + 1);
+    int axis = 0;
+    if (ch[1] - cl[1] > ch[axis] - cl[axis]) axis = 1;
+    if (ch[2] - cl[2] > ch[axis] - cl[axis]) axis = 2;
+    const uint32_t mid = begin + (end - begin) / 2;
+    std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end,
+                     [&](uint32_t a, uint32_t b) { return cen[3 * a + axis] < cen[3 * b + axis]; });
+    double b0[6], b1[6];
+    const uint32_t refs[2] = {build(begin, mid, b0, level + 1), build(mid, end, b1, level + 1)};
+    double *n = &nodes[PT_BVH_SRC_DOUBLES * (size_t)me]; /* after the recursion: nodes may have moved */
+    memcpy(n, b0, sizeof b0);
+    memcpy(n + 6, b1, sizeof b1);
+    memcpy(n + 12, refs, sizeof refs);
     return me;
+  }
+
+  /* The whole mesh.  A mesh that fits one leaf still gets a root node: child 0 = the leaf,
+   * child 1 = an empty leaf. */
+  void build_root(uint32_t n_tri)
+  {
+    double box[6];
+    const uint32_t ref = build(0, n_tri, box, 0);
+    if (ref & PT_BVH_LEAF_FLAG)
+    {
+      nodes.assign(PT_BVH_SRC_DOUBLES, 0.0);
+      const uint32_t refs[2] = {ref, PT_BVH_LEAF_FLAG};
+      memcpy(&nodes[0], box, sizeof box);
+      memcpy(&nodes[6], box, sizeof box);
+      memcpy(&nodes[12], refs, sizeof refs);
+      depth = 1;
+    }
   }
 };
 
@@ -455,9 +469,13 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
       bvh.order[k] = k;
       bvh.tri_box(k);
     }
-    bvh.build(0, (uint32_t)n_tri);
+    if (n_tri >= (1u << 28))
+      return fail(RT_HIP_ELIMIT, "%zu triangles exceed the hierarchy's leaf references (2^28)", n_tri);
+    bvh.build_root((uint32_t)n_tri);
+    if (bvh.depth > PT_BVH_STACK)
+      return fail(RT_HIP_ELIMIT, "triangle hierarchy depth %d exceeds the traversal stack (%d)", bvh.depth, PT_BVH_STACK);
   }
-  const size_t n_bvh_nodes = bvh.nodes.size() / 8;
+  const size_t n_bvh_nodes = bvh.nodes.size() / PT_BVH_SRC_DOUBLES;
 
   /* ---- one device blob ---- */
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
