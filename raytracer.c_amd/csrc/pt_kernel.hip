@@ -253,6 +253,59 @@ __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, 
   }
 }
 
+/* the ray as the hierarchy's slab tests use it: fp32, both halves of a pair alike */
+struct BvhRay
+{
+  f32x2 ox, oy, oz, ix, iy, iz;
+};
+
+__device__ __forceinline__ BvhRay bvh_ray(const V3 &o, const V3 &d)
+{
+  const float ixs = 1.0f / (float)d.x, iys = 1.0f / (float)d.y, izs = 1.0f / (float)d.z;
+  return {{(float)o.x, (float)o.x}, {(float)o.y, (float)o.y}, {(float)o.z, (float)o.z}, {ixs, ixs}, {iys, iys}, {izs, izs}};
+}
+
+/* One visit: the boxes of node `ref`'s two children against the ray (see bvh_traverse for
+ * the bounds that make it conservative).  tmax = the closest hit so far rounded up to fp32. */
+__device__ __forceinline__ void bvh_test_children(const float *__restrict__ nodes, uint32_t ref, const BvhRay &R,
+                                                  bool far_origin, float tmax, bool &hit0, bool &hit1, float &tn0,
+                                                  float &tn1, uint32_t &r0, uint32_t &r1)
+{
+  const float widen = 4.0f * 5.9604644775390625e-08f;
+  const float4 *node = reinterpret_cast<const float4 *>(nodes + PT_BVH_NODE_WORDS * (size_t)ref);
+  const float4 px = node[0], py = node[1], pz = node[2], tail = node[3];
+  /* (min, max) planes of (child 0, child 1) */
+  const f32x2 tx1 = (f32x2{px.x, px.y} - R.ox) * R.ix, tx2 = (f32x2{px.z, px.w} - R.ox) * R.ix;
+  const f32x2 ty1 = (f32x2{py.x, py.y} - R.oy) * R.iy, ty2 = (f32x2{py.z, py.w} - R.oy) * R.iy;
+  const f32x2 tz1 = (f32x2{pz.x, pz.y} - R.oz) * R.iz, tz2 = (f32x2{pz.z, pz.w} - R.oz) * R.iz;
+  tn0 = fmaxf(fmaxf(fminf(tx1.x, tx2.x), fminf(ty1.x, ty2.x)), fminf(tz1.x, tz2.x));
+  float tf0 = fminf(fminf(fmaxf(tx1.x, tx2.x), fmaxf(ty1.x, ty2.x)), fmaxf(tz1.x, tz2.x));
+  tn1 = fmaxf(fmaxf(fminf(tx1.y, tx2.y), fminf(ty1.y, ty2.y)), fminf(tz1.y, tz2.y));
+  float tf1 = fminf(fminf(fmaxf(tx1.y, tx2.y), fmaxf(ty1.y, ty2.y)), fmaxf(tz1.y, tz2.y));
+  tn0 -= fabsf(tn0) * widen;
+  tf0 += fabsf(tf0) * widen;
+  tn1 -= fabsf(tn1) * widen;
+  tf1 += fabsf(tf1) * widen;
+  /* a box starting beyond the closest hit so far cannot matter */
+  hit0 = far_origin || (tf0 >= tn0 && tf0 >= 0.0f && tn0 <= tmax);
+  hit1 = far_origin || (tf1 >= tn1 && tf1 >= 0.0f && tn1 <= tmax);
+  r0 = __float_as_uint(tail.x);
+  r1 = __float_as_uint(tail.y);
+}
+
+/* Could the ray reach a triangle closer than min_t at all?  (The root's two child boxes.) */
+__device__ __forceinline__ bool bvh_probe(const float *__restrict__ nodes, uint32_t n_nodes, bool far_origin,
+                                          const V3 &o, const V3 &d, double min_t)
+{
+  if (n_nodes == 0)
+    return false;
+  bool hit0, hit1;
+  float tn0, tn1;
+  uint32_t r0, r1;
+  bvh_test_children(nodes, 0u, bvh_ray(o, d), far_origin, __double2float_ru(min_t), hit0, hit1, tn0, tn1, r0, r1);
+  return hit0 || hit1;
+}
+
 /* Ordered walk of the triangle hierarchy (pt_device.h: bvh_nodes).  Per lane and per visit:
  * the widened fp32 boxes of the node's TWO children against the ray by the slab test, both
  * in the same packed-fp32 instructions, made conservative --
@@ -275,60 +328,48 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
   __shared__ uint32_t stack[PT_BVH_STACK][PT_BLOCK]; /* entry-major: conflict-free per wave */
   if (n_nodes == 0)
     return;
-  const f32x2 ox = {(float)o.x, (float)o.x}, oy = {(float)o.y, (float)o.y}, oz = {(float)o.z, (float)o.z};
-  const float ixs = 1.0f / (float)d.x, iys = 1.0f / (float)d.y, izs = 1.0f / (float)d.z;
-  const f32x2 ix = {ixs, ixs}, iy = {iys, iys}, iz = {izs, izs};
-  const float widen = 4.0f * 5.9604644775390625e-08f;
+  const BvhRay R = bvh_ray(o, d);
   uint32_t sp = 0;
   uint32_t ref = 0; /* the root node */
+  bool done = false;
+  /* "while-while": lanes first descend until each holds a leaf (or has finished), then the
+   * leaves are tested together -- the exact triangle test, the expensive block, runs with all
+   * the lanes that have one instead of whenever a single lane happens to reach a leaf */
   for (;;)
   {
-    if (ref & PT_BVH_LEAF_FLAG)
-    {
-      const uint32_t first = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
-      for (uint32_t k = 0; k < count; k++)
-      {
-        DIAG(14, 1);
-        const uint32_t t = tri_order[first + k];
-        exact_triangle<true>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v);
-      }
-    }
-    else
+    while (!done && !(ref & PT_BVH_LEAF_FLAG))
     {
       DIAG(13, 1);
       DIAG_LANES(15);
-      const float4 *node = reinterpret_cast<const float4 *>(nodes + PT_BVH_NODE_WORDS * (size_t)ref);
-      const float4 px = node[0], py = node[1], pz = node[2], tail = node[3];
-      /* (min, max) planes of (child 0, child 1) */
-      const f32x2 tx1 = (f32x2{px.x, px.y} - ox) * ix, tx2 = (f32x2{px.z, px.w} - ox) * ix;
-      const f32x2 ty1 = (f32x2{py.x, py.y} - oy) * iy, ty2 = (f32x2{py.z, py.w} - oy) * iy;
-      const f32x2 tz1 = (f32x2{pz.x, pz.y} - oz) * iz, tz2 = (f32x2{pz.z, pz.w} - oz) * iz;
-      float tn0 = fmaxf(fmaxf(fminf(tx1.x, tx2.x), fminf(ty1.x, ty2.x)), fminf(tz1.x, tz2.x));
-      float tf0 = fminf(fminf(fmaxf(tx1.x, tx2.x), fmaxf(ty1.x, ty2.x)), fmaxf(tz1.x, tz2.x));
-      float tn1 = fmaxf(fmaxf(fminf(tx1.y, tx2.y), fminf(ty1.y, ty2.y)), fminf(tz1.y, tz2.y));
-      float tf1 = fminf(fminf(fmaxf(tx1.y, tx2.y), fmaxf(ty1.y, ty2.y)), fmaxf(tz1.y, tz2.y));
-      tn0 -= fabsf(tn0) * widen;
-      tf0 += fabsf(tf0) * widen;
-      tn1 -= fabsf(tn1) * widen;
-      tf1 += fabsf(tf1) * widen;
-      /* min_t rounded up to fp32; a box starting beyond the closest hit so far cannot matter */
-      const float tmax = __double2float_ru(min_t);
-      const bool hit0 = far_origin || (tf0 >= tn0 && tf0 >= 0.0f && tn0 <= tmax);
-      const bool hit1 = far_origin || (tf1 >= tn1 && tf1 >= 0.0f && tn1 <= tmax);
-      const uint32_t r0 = __float_as_uint(tail.x), r1 = __float_as_uint(tail.y);
+      bool hit0, hit1;
+      float tn0, tn1;
+      uint32_t r0, r1;
+      bvh_test_children(nodes, ref, R, far_origin, __double2float_ru(min_t), hit0, hit1, tn0, tn1, r0, r1);
       if (hit0 && hit1)
       {
         const bool zero_first = !(tn1 < tn0);
         stack[sp][threadIdx.x] = zero_first ? r1 : r0;
         sp++;
         ref = zero_first ? r0 : r1;
-        continue;
       }
-      if (hit0 || hit1)
-      {
+      else if (hit0 || hit1)
         ref = hit0 ? r0 : r1;
-        continue;
+      else if (sp == 0)
+        done = true;
+      else
+      {
+        sp--;
+        ref = stack[sp][threadIdx.x];
       }
+    }
+    if (done)
+      break;
+    const uint32_t first = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
+    for (uint32_t k = 0; k < count; k++)
+    {
+      DIAG(14, 1);
+      const uint32_t t = tri_order[first + k];
+      exact_triangle<true>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v);
     }
     if (sp == 0)
       break;
@@ -363,7 +404,7 @@ __device__ __forceinline__ uint32_t push_keep_bit(uint32_t word, float tca, floa
   return word;
 }
 
-template <bool TRIS, bool BVH, bool FILT_LDS>
+template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true>
 __device__ __forceinline__ void scan_filtered(const double *geom, const double *tri_geom,
                                               const f32x2 *__restrict__ filt, double near_R2, uint32_t n_sph,
                                               uint32_t n_entries, const V3 &o, const V3 &d, double &min_t,
@@ -533,7 +574,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
         exact_triangle(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v);
     }
   }
-  if (BVH)
+  if (BVH && WALK) /* WALK = false: the caller walks the hierarchy itself, later (render_tiles_pooled) */
     bvh_traverse(bvh_nodes, n_bvh_nodes, bvh_tri, tri_geom, n_sph, far_origin, o, d, min_t, best, bary_u, bary_v,
                  diag_ptr);
 }
@@ -722,34 +763,61 @@ __device__ __forceinline__ V3 hemisphere_from_sample(const V3 &q, double len2, c
   return nd;
 }
 
-template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS>
+/* The closest hit of one intersect() call, kept between the two halves of trace_step when
+ * the pooled kernel postpones the walk of the triangle hierarchy. */
+struct HitRec
+{
+  double min_t, bary_u, bary_v;
+  int best;
+  bool depth_ok; /* the call ran the scan at all (:487) */
+};
+
+/* MODE 0: the whole call.  MODE 1: the first half only -- depth test, the flat scan WITHOUT the
+ * hierarchy walk; the result so far goes to *rec and nothing else changes.  MODE 2: the second
+ * half only, from *rec (which the caller may have completed with bvh_traverse). */
+template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int MODE = 0>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
-                                           unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
+                                           unsigned long long *diag_ptr, PendingRay *stack, int &stack_n,
+                                           HitRec *rec = nullptr)
 {
   V3 add = {kBg, kBg, kBg}; /* what this call contributes if the path ends here */
   bool path_ends = true;
   const V3 o = P.o, d = P.d;
+  HitRec local;
+  HitRec &H = MODE == 0 ? local : *rec;
 
-  if (P.depth <= S.max_depth)
+  if (MODE != 2)
   {
-    n_casts++;
-    /* ---- intersect(): closest hit, strict <, index order (:393-464) ---- */
-    double min_t = 1.7976931348623157e308; /* DBL_MAX */
-    int best = -1;
-    double bary_u = 0, bary_v = 0;
-    if (VARIANT == 0)
+    H.depth_ok = P.depth <= S.max_depth;
+    H.min_t = 1.7976931348623157e308; /* DBL_MAX */
+    H.best = -1;
+    H.bary_u = 0;
+    H.bary_v = 0;
+    if (H.depth_ok)
     {
-      /* the literal scan: spheres, then triangles, every lane on the same primitive */
-      for (uint32_t i = 0; i < S.n_sph; i++)
-        exact_sphere(S.geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
-      for (uint32_t i = 0; i < S.n_tri; i++)
-        exact_triangle(S.tri + 9 * (size_t)i, S.n_sph + i, o, d, min_t, best, bary_u, bary_v);
+      n_casts++;
+      /* ---- intersect(): closest hit, strict <, index order (:393-464) ---- */
+      if (VARIANT == 0)
+      {
+        /* the literal scan: spheres, then triangles, every lane on the same primitive */
+        for (uint32_t i = 0; i < S.n_sph; i++)
+          exact_sphere(S.geom + PT_GEOM_STRIDE * i, i, o, d, H.min_t, H.best);
+        for (uint32_t i = 0; i < S.n_tri; i++)
+          exact_triangle(S.tri + 9 * (size_t)i, S.n_sph + i, o, d, H.min_t, H.best, H.bary_u, H.bary_v);
+      }
+      else
+        scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0>(
+            S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o, d, H.min_t, H.best,
+            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift);
     }
-    else
-      scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
-                                             S.n_sph + S.n_tri, o, d, min_t, best, bary_u, bary_v, diag_ptr,
-                                             S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift);
+    if (MODE == 1)
+      return false;
+  }
+  const double min_t = H.min_t, bary_u = H.bary_u, bary_v = H.bary_v;
+  const int best = H.best;
 
+  if (H.depth_ok)
+  {
     if (best >= 0)
     {
       DIAG(8, 1);
@@ -1106,6 +1174,13 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 #ifndef PT_MIN_WAVES_TRI
 #define PT_MIN_WAVES_TRI 5
 #endif
+/* postponed hierarchy walks of the pooled kernels: lanes that make a batch; trips the oldest waits */
+#ifndef PT_MESH_BATCH
+#define PT_MESH_BATCH 32
+#endif
+#ifndef PT_MESH_MAX_WAIT
+#define PT_MESH_MAX_WAIT 16
+#endif
 /* Pooled kernel body.  Not for scenes with M_REFRACTION: there the throughput is not bounded
  * by 1 (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes
  * negative), so no fixed-point scale can be fixed in advance; those scenes use the static body. */
@@ -1162,6 +1237,16 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   P.rng = 1;
   P.depth = 0;
   uint32_t n_rays = 0, n_casts = 0;
+  /* kernels with a triangle hierarchy postpone its walks (see the loop) */
+  constexpr bool DEFER_MESH = TRIS && !FILT_LDS;
+  HitRec hit;
+  hit.min_t = 0;
+  hit.bary_u = 0;
+  hit.bary_v = 0;
+  hit.best = -1;
+  hit.depth_ok = false;
+  bool mesh_wait = false;
+  uint32_t trip = 0, wait_since = 0xFFFFFFFFu; /* wave-uniform */
   uint32_t next_job = 0;     /* jobs handed out so far (wave-uniform) */
   uint32_t made_jobs = 0;    /* jobs whose camera ray sits in the wave's queue (wave-uniform) */
   uint32_t pix_slot = 0;     /* 0..63 inside the tile */
@@ -1240,12 +1325,56 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     if (__ballot(busy) == 0)
       break; /* pool dry and every lane drained: the one exit, reached by all lanes together */
 
-    if (busy)
+    bool step_done = false;
+    if (DEFER_MESH)
+    {
+      /* Scenes with a triangle hierarchy: only about a tenth of the rays enter the mesh's
+       * bounds at all, and a walk costs several times a whole sphere-only trip -- done on the
+       * spot it would run at ~8 % lane occupancy.  So a lane whose ray can reach the mesh
+       * (bvh_probe) WAITS with its flat-scan result; the wave walks the hierarchy when enough
+       * lanes wait (PT_MESH_BATCH), when nobody else can advance, or when the oldest has
+       * waited PT_MESH_MAX_WAIT trips.  Waiting costs idle lanes in the trips between, a
+       * batch runs the walk at several times the occupancy.  Results do not depend on when a
+       * ray is walked. */
+      if (busy && !mesh_wait)
+      {
+        DIAG(0, 1);
+        DIAG_LANES(1);
+        n_rays++;
+        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+        const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
+        mesh_wait = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d, hit.min_t);
+      }
+      const uint32_t n_wait = (uint32_t)__popcll(__ballot(busy && mesh_wait));
+      const uint32_t n_go = (uint32_t)__popcll(__ballot(busy && !mesh_wait));
+      if (n_wait != 0 && wait_since == 0xFFFFFFFFu)
+        wait_since = trip;
+      const bool walk = n_wait != 0 && (n_wait >= PT_MESH_BATCH || n_go == 0 || trip - wait_since >= PT_MESH_MAX_WAIT);
+      if (walk)
+      {
+        if (busy && mesh_wait)
+        {
+          const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
+          bvh_traverse(S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.tri, S.n_sph, far_origin, P.o, P.d, hit.min_t, hit.best,
+                       hit.bary_u, hit.bary_v, diag_ptr);
+          mesh_wait = false;
+        }
+        wait_since = 0xFFFFFFFFu;
+      }
+      trip++;
+      if (busy && !mesh_wait)
+        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+    }
+    else if (busy)
     {
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      if (trace_step<1, false, CHECKER, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, nullptr, stack_n))
+      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, nullptr, stack_n);
+    }
+    if (busy)
+    {
+      if (step_done)
       {
         /* sample done: add to the pixel's fixed-point sum (integer adds commute: the
          * result does not depend on which lane finishes first) */
