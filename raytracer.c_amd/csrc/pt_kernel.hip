@@ -770,12 +770,19 @@ struct HitRec
   double min_t, bary_u, bary_v;
   int best;
   bool depth_ok; /* the call ran the scan at all (:487) */
+  /* DEFER_DIR: a diffuse hit whose new direction is still to be sampled.  P.d holds the
+   * NORMAL meanwhile, P.T lacks the factor albedo * cos; dir_slot / dir_scale say which
+   * albedo (material slot, checker factor). */
+  bool need_dir;
+  uint32_t dir_slot;
+  double dir_scale;
 };
 
 /* MODE 0: the whole call.  MODE 1: the first half only -- depth test, the flat scan WITHOUT the
  * hierarchy walk; the result so far goes to *rec and nothing else changes.  MODE 2: the second
- * half only, from *rec (which the caller may have completed with bvh_traverse). */
-template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int MODE = 0>
+ * half only, from *rec (which the caller may have completed with bvh_traverse).
+ * DEFER_DIR: a diffuse hit does not sample its direction here; the caller does (HitRec). */
+template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int MODE = 0, bool DEFER_DIR = false>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
                                            unsigned long long *diag_ptr, PendingRay *stack, int &stack_n,
                                            HitRec *rec = nullptr)
@@ -784,7 +791,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
   bool path_ends = true;
   const V3 o = P.o, d = P.d;
   HitRec local;
-  HitRec &H = MODE == 0 ? local : *rec;
+  HitRec &H = (MODE == 0 && !DEFER_DIR) ? local : *rec;
 
   if (MODE != 2)
   {
@@ -855,6 +862,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       if (rnd(P.rng) < prob)
       {
         path_ends = false;
+        double checker_scale = 1.0;
+        bool dir_deferred = false;
         if (CHECKER && (flags & PT_FLAG_CHECKER))
         {
           if (!is_tri)
@@ -874,6 +883,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           double on = (double)((fmod(tex_u * 100000.0, 1.0) > 0.5) ^ (fmod(tex_v * 100000.0, 1.0) < 0.5));
           double c = 0.3 * (1 - on) + 0.7 * on;
           albedo = v_scale(albedo, c);
+          checker_scale = c;
         }
         V3 nd;
         double weight = 1.0;
@@ -916,23 +926,35 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         else
         {
           /* random_on_hemisphere :231-253 */
-          V3 q;
-          double len2;
-          int tries = 0;
-          bool again;
-          do
+          if (DEFER_DIR)
           {
-            DIAG(10, 1);
-            DIAG_LANES(11);
-            again = rejection_round(P.rng, q, len2);
-          } while (again && ++tries < 100);
-          nd = hemisphere_from_sample(q, len2, n, weight);
+            H.need_dir = true;
+            H.dir_slot = slot;
+            H.dir_scale = checker_scale;
+            dir_deferred = true;
+            nd = n; /* P.d carries the normal until the caller has the sample */
+          }
+          else
+          {
+            V3 q;
+            double len2;
+            int tries = 0;
+            bool again;
+            do
+            {
+              DIAG(10, 1);
+              DIAG_LANES(11);
+              again = rejection_round(P.rng, q, len2);
+            } while (again && ++tries < 100);
+            nd = hemisphere_from_sample(q, len2, n, weight);
+          }
         }
         /* L = e + albedo (.) (L_next * cos)  ==>  forward form */
         if (!split)
         {
           P.Ls = v_add(P.Ls, v_mul(P.T, emission));
-          P.T = v_mul(P.T, (flags & PT_FLAG_MIRROR) ? albedo : v_scale(albedo, weight));
+          if (!(DEFER_DIR && dir_deferred))
+            P.T = v_mul(P.T, (flags & PT_FLAG_MIRROR) ? albedo : v_scale(albedo, weight));
         }
         P.o = p;
         P.d = nd;
@@ -1181,6 +1203,10 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 #ifndef PT_MESH_MAX_WAIT
 #define PT_MESH_MAX_WAIT 16
 #endif
+/* rejection rounds per trip for the directions of diffuse hits (pooled kernels) */
+#ifndef PT_DIR_ROUNDS
+#define PT_DIR_ROUNDS 4
+#endif
 /* Pooled kernel body.  Not for scenes with M_REFRACTION: there the throughput is not bounded
  * by 1 (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes
  * negative), so no fixed-point scale can be fixed in advance; those scenes use the static body. */
@@ -1245,6 +1271,9 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   hit.bary_v = 0;
   hit.best = -1;
   hit.depth_ok = false;
+  hit.need_dir = false;
+  hit.dir_slot = 0;
+  hit.dir_scale = 1.0;
   bool mesh_wait = false;
   uint32_t trip = 0, wait_since = 0xFFFFFFFFu; /* wave-uniform */
   uint32_t next_job = 0;     /* jobs handed out so far (wave-uniform) */
@@ -1326,6 +1355,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       break; /* pool dry and every lane drained: the one exit, reached by all lanes together */
 
     bool step_done = false;
+    /* lanes still sampling a direction from an earlier trip sit this trip's step out */
+    const bool stepping = busy && !hit.need_dir;
     if (DEFER_MESH)
     {
       /* Scenes with a triangle hierarchy: only about a tenth of the rays enter the mesh's
@@ -1336,12 +1367,12 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
        * waited PT_MESH_MAX_WAIT trips.  Waiting costs idle lanes in the trips between, a
        * batch runs the walk at several times the occupancy.  Results do not depend on when a
        * ray is walked. */
-      if (busy && !mesh_wait)
+      if (stepping && !mesh_wait)
       {
         DIAG(0, 1);
         DIAG_LANES(1);
         n_rays++;
-        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
         const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
         mesh_wait = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d, hit.min_t);
       }
@@ -1362,15 +1393,47 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         wait_since = 0xFFFFFFFFu;
       }
       trip++;
-      if (busy && !mesh_wait)
-        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+      if (stepping && !mesh_wait)
+        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
     }
-    else if (busy)
+    else if (stepping)
     {
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, nullptr, stack_n);
+      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 0, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+    }
+    /* ---- directions of diffuse hits: PT_DIR_ROUNDS rejection rounds per trip ----
+     * A lane needs 1.91 rounds on average, but a loop that runs until the wave's last lane has
+     * its sample takes ~6.2 (the maximum of ~45 geometric variables) at 20 % lane occupancy.
+     * Here every lane that needs a direction -- from this trip's hit or still from an earlier
+     * one -- gets PT_DIR_ROUNDS rounds; the ~5 % left without a sample carry on next trip and
+     * skip that trip's step.  A sample depends on its stream alone, not on the trip it is
+     * drawn in.  (No 100-round cap here: a lane that keeps failing simply keeps its turn; the
+     * reference aborts at 100, probability 1e-32.) */
+    if (busy && hit.need_dir)
+    {
+      V3 q;
+      double len2;
+      bool again = true;
+      for (int round = 0; round < PT_DIR_ROUNDS && again; round++)
+      {
+        DIAG(10, 1);
+        DIAG_LANES(11);
+        again = rejection_round(P.rng, q, len2);
+      }
+      if (!again)
+      {
+        const double *m = S.mat + PT_MAT_STRIDE * hit.dir_slot;
+        V3 albedo = ld3(m + 1);
+        if (CHECKER)
+          albedo = v_scale(albedo, hit.dir_scale);
+        const V3 n = P.d;
+        double weight;
+        P.d = hemisphere_from_sample(q, len2, n, weight);
+        P.T = v_mul(P.T, v_scale(albedo, weight));
+        hit.need_dir = false;
+      }
     }
     if (busy)
     {
