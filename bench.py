@@ -161,10 +161,19 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available() or abi.load_shim().rt_hip_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # RT_BENCH_REHEARSE=1: every rank on GPU 0, gloo instead of RCCL, the gather staged through the
+    # host -- the N > 1 control flow on a one-GPU box (RCCL refuses two ranks on one device).  The
+    # number it prints is not a measurement; the JSON says so.
+    rehearse = world > 1 and os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     sc = S.build_scene(args.config, args.width or None, args.height or None, args.spp or None)
     W, H, spp, depth = sc.width, sc.height, sc.samples, sc.max_depth
@@ -197,7 +206,7 @@ def main():
         if timed:
             kernel_events.append((e0, e1))
         # RCCL over xGMI when world > 1: the one exchange of the path
-        parts, parts8 = D.gather_tiles(tiles, tiles8, rank, world, gathered, gathered8)
+        parts, parts8 = D.gather_tiles(tiles, tiles8, rank, world, gathered, gathered8, via_cpu=rehearse)
         if rank == 0:
             for r, f, s_, c in D.segments(W, H, world):
                 gs.untile(parts[r], parts8[r], f, s_, c, image, image8)
@@ -223,6 +232,8 @@ def main():
     kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)],
                            dtype=torch.float64, device=dev)
     tot = stats.clone()
+    if rehearse:
+        t, kern_ms, tot = t.cpu(), kern_ms.cpu(), tot.cpu()
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
@@ -247,7 +258,8 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {W}x{H}, {spp} spp, "
                                    f"{sc.n_objects} spheres + {sc.n_triangles} triangles, depth {depth}",
                        "width": W, "height": H, "spp": spp, "max_depth": depth, "seed": SEED,
-                       "parallelism": f"tiles interleaved over {world} GPU(s), RCCL gather to rank 0",
+                       "parallelism": (f"tiles interleaved over {world} GPU(s), RCCL gather to rank 0" if not rehearse else
+                                       f"REHEARSAL: {world} ranks sharing one GPU, gloo gather through the host (not a measurement)"),
                        "sample_chunks_per_tile": chunks},
             "mpixel_samples_per_s": samples / elapsed * 1e-6,
             "rays_per_sample": rays / max(samples, 1),

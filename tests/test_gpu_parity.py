@@ -657,3 +657,61 @@ def test_wide_range_scene_keeps_the_nan_safe_filter(gpu, pt):
     tri = [[(-3, -4.9, 3, 0, 0), (3, -4.9, 3, 1, 0), (0, 2, 3, 0, 1)], [(-3, -4.9, 3, 0, 0), (0, 2, 3, 0, 1), (3, -4.9, 3, 1, 0)]]
     meshes = [dict(flags=abi.M_DEFAULT, color=(0.9, 0.8, 0.2), triangles=tri)]
     _full(gpu, pt, S.custom_scene(objs, 48, 32, 4, 4, (0, 4, 30), (0, 0, 0), meshes=meshes))
+
+
+def test_bench_two_ranks_rehearsal(gpu):
+    """bench.py's N > 1 control flow (torch.distributed.run, RANK/WORLD_SIZE, tile partition,
+    gather, untile on rank 0, max/sum reductions, one JSON line from rank 0) with two ranks
+    sharing this box's one GPU: gloo instead of RCCL (RCCL refuses two ranks on one device)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "2", "--spp", "4", "--steps", "1", "--warmup", "1", "--cpu-tiles", "0"]
+    env = dict(os.environ, RT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(root, "bench.py"),
+                          "--gpus", "2"] + common, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d2 = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and d2["scaling"] == "strong"
+    # the same frame: identical ray and cast counts whatever the partition
+    assert d2["ray_count_per_step"] == d1["ray_count_per_step"]
+    assert d2["ray_bounces_per_step"] == d1["ray_bounces_per_step"]
+    assert "REHEARSAL" in d2["config"]["parallelism"]
+
+
+def test_mesh_hierarchy_partitions_and_chunks_are_bit_invariant(gpu):
+    """the kernels with postponed hierarchy walks and carried-over direction sampling: when a ray
+    is walked or a direction drawn depends on what else the wave holds, the image must not --
+    interleaved tile subsets and sample chunks reproduce the full render bit for bit"""
+    import torch
+    from rt_amd import scene as S
+    sc = S.build_scene(5, 72, 40, 10)
+    gs = gpu.GpuScene(sc)
+    total = gpu.n_tiles(sc.width, sc.height)
+    ref_t, ref_t8, ref_s = gs.render_tiles(SEED, 0, 1, total)
+    torch.cuda.synchronize()
+    for chunks in (2, 5):
+        t, t8, s = gs.render_tiles(SEED, 0, 1, total, chunks=chunks)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref_t) and torch.equal(t8, ref_t8) and torch.equal(s, ref_s), chunks
+    full, full8 = gs.untile(ref_t, ref_t8, 0, 1, total)
+    image, image8 = torch.zeros_like(full), torch.zeros_like(full8)
+    tot = torch.zeros(4, dtype=torch.int64, device=full.device)
+    for r in range(3):
+        first, stride, count = gpu.rank_tiles(sc.width, sc.height, r, 3)
+        t, t8, s = gs.render_tiles(SEED, first, stride, count)
+        gs.untile(t, t8, first, stride, count, image, image8)
+        tot += s
+    torch.cuda.synchronize()
+    assert torch.equal(image, full) and torch.equal(image8, full8) and torch.equal(tot, ref_s)
+    gs.close()
+    sc.free()
