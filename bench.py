@@ -115,7 +115,9 @@ def cpu_as_shipped():
     if not oracle_py.ref_available(5):
         return None
     sc = S.build_scene(4, 320, 180, 16, max_depth=5)
+    small = S.build_scene(4, 160, 90, 16, max_depth=5)
     ref = oracle_py.RefOracle(5)
+    threads = min(os.cpu_count() or 1, 64)
     devnull = os.open(os.devnull, os.O_WRONLY)       # render() prints a progress bar
     saved = os.dup(1)
     os.dup2(devnull, 1)
@@ -123,6 +125,13 @@ def cpu_as_shipped():
         t0 = time.perf_counter()
         _, st = ref.render_as_shipped(sc, SEED, threads=1)
         dt = time.perf_counter() - t0
+        # CPU-B: the same render() with its OpenMP team on every core.  rand() is one locked global
+        # stream and the two counters one contended cache line, so this is the slower way
+        # to run it -- shown because it is what `make && ./raytracer` does on a many-core host.
+        t0 = time.perf_counter()
+        _, st_all = ref.render_as_shipped(small, SEED, threads=threads)
+        dt_all = time.perf_counter() - t0
+        ref.lib.ref_set_threads(1)
     finally:
         import ctypes
         ctypes.CDLL(None).fflush(None)               # its printf buffer must drain into /dev/null, not after our JSON
@@ -130,7 +139,10 @@ def cpu_as_shipped():
         os.close(devnull)
         os.close(saved)
     return {"value": st["tests"] / sc.n_objects / dt, "unit": "ray-bounces/s", "cores": 1, "kind": "reference",
-            "sample": f"render() as shipped, 320x180, 16 spp, MAX_DEPTH 5, libc rand(), 1 thread, {dt:.1f} s"}
+            "sample": f"render() as shipped, 320x180, 16 spp, MAX_DEPTH 5, libc rand(), 1 thread, {dt:.1f} s",
+            "all_cores": {"value": st_all["tests"] / small.n_objects / dt_all, "unit": "ray-bounces/s", "cores": threads,
+                          "sample": f"render() as shipped, 160x90, 16 spp, MAX_DEPTH 5, libc rand(), {threads} OpenMP "
+                                    f"threads, {dt_all:.1f} s (racy counters: the count is approximate)"}}
 
 
 # ---- main ------------------------------------------------------------------------------
