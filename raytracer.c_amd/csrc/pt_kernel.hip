@@ -16,12 +16,23 @@
  * iteration slot (wave-synchronous: ballot + prefix count, no atomics), so all 64 lanes
  * stay busy until the pool is dry whatever the individual path lengths are.  The scene
  * scan -- 80 % of the work -- is split into a wave-uniform conservative filter and a
- * per-lane exact test over the survivors (scan_spheres below).  Per-pixel sums are
+ * per-lane exact test over the survivors (scan_filtered below).  Per-pixel sums are
  * kept in LDS as 64-bit FIXED-POINT integers (power-of-two scale chosen per launch from a
  * bound on the radiance, ~2^-40 relative resolution): integer addition is associative,
  * so the image is bit-identical under any lane / tile / GPU assignment although samples
  * finish in a data-dependent order.  The tile leaves as one coalesced 768-byte float3
  * store (+192 tonemapped bytes).
+ *   Three more things keep lanes from idling in divergent code (render_tiles_pooled):
+ * camera samples are prepared 64 at a time by the whole wave into an LDS queue instead of by
+ * whichever few lanes are idle; the direction of a diffuse hit gets four rejection rounds per
+ * trip and the rare lane still without a sample carries on next trip instead of the wave
+ * looping on it; and, in scenes with a triangle hierarchy, rays that can reach the mesh wait
+ * until a batch of them walks it together.  None of this can change a value: a sample
+ * depends only on its (seed, pixel, sample) stream.
+ *
+ * Kernel family: pt_render_tiles[_tri][_big][_chk] (pooled body, by scene content),
+ * pt_render_tiles[..]_refr and pt_whitted_tiles[..] (static body: refraction's two-child
+ * tree, and cast_ray, raytracer.c:556-641), see the PT_KERNEL lists below.
  *
  * pt_render_tiles_v0 (kept for A/B and as the plainest statement of the algorithm): static
  * assignment lane = (pixel, sample slice), literal scan, fp64 partial sums combined by
