@@ -80,8 +80,7 @@ static void build_c2(Object *o)
 
 /* The 8 corner positions and 6 quads of that file (a Blender cube of side 2
  * with three coordinates perturbed in the 6th decimal), as the float values an
- * OBJ loader yields.  tests/test_obj.py checks load_obj() on the file itself
- * against this table. */
+ * OBJ loader yields.  tests/test_host.py checks load_obj() against this table. */
 static const float cube_corner[8][3] = {
     {1.000000f, -1.000000f, -1.000000f}, {1.000000f, -1.000000f, 1.000000f},
     {-1.000000f, -1.000000f, 1.000000f}, {-1.000000f, -1.000000f, -1.000000f},

@@ -7,8 +7,8 @@ sides).  Run in the build container, where /root/reference exists:
     make oracle && python tests/golden/make_golden.py
 
 The fixtures are DATA (inputs + expected outputs as float64 / integer arrays in .npz,
-loadable with allow_pickle=False); no reference source text is stored.  cube.obj is the
-reference's 753-byte asset assets/cube.obj, an input data file.
+loadable with allow_pickle=False); no reference source text is stored.  c3_cube.obj (the
+cube of config 3 as an OBJ) is written by make_cube_obj.py.
 
 Files
   primitives.npz   ray/sphere and ray/triangle known answers (incl. grazing, inside,

@@ -468,7 +468,7 @@ def test_obj_file_through_render_ex(gpu, pt):
     from rt_amd import abi, scene as S
     host = abi.load_host()
     mesh = abi.TriangleMesh()
-    assert host.load_obj((GOLD + "/cube.obj").encode(), C.byref(mesh))
+    assert host.load_obj((GOLD + "/c3_cube.obj").encode(), C.byref(mesh))
     host.rt_mesh_flip_winding(C.byref(mesh))
     for k in range(36):  # scale the unit cube up so it is visible
         v = mesh.vertices[k]

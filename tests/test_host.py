@@ -104,10 +104,11 @@ def test_rng_python_reimplementation(pt):
 
 
 def test_load_obj_cube(host, pt):
-    """load_obj() on the reference's assets/cube.obj == the procedural cube of scene 3"""
+    """load_obj() on an OBJ of config 3's cube (quads, v//vn faces, comments, mtl lines) == the
+    procedural cube of scene 3; where the reference is mounted, its own assets/cube.obj too"""
     from rt_amd import abi, scene as S
     mesh = abi.TriangleMesh()
-    assert host.load_obj(os.path.join(GOLD, "cube.obj").encode(), C.byref(mesh))
+    assert host.load_obj(os.path.join(GOLD, "c3_cube.obj").encode(), C.byref(mesh))
     assert mesh.num_triangles == 12
     sc = S.build_scene(3, 64, 36, 1)
     assert sc.n_meshes == 1 and sc.meshes[0].mesh.num_triangles == 12
@@ -126,6 +127,13 @@ def test_load_obj_cube(host, pt):
         n = pt.surface_normal(np.array(v).reshape(-1))
         assert np.dot(n, np.mean(v, axis=0)) > 0.5
     assert not host.load_obj(b"/nonexistent.obj", C.byref(mesh))
+    ref_asset = "/root/reference/assets/cube.obj"  # build container only; nothing is copied
+    if os.path.exists(ref_asset):
+        other = abi.TriangleMesh()
+        assert host.load_obj(ref_asset.encode(), C.byref(other)) and other.num_triangles == 12
+        host.rt_mesh_flip_winding(C.byref(other))
+        for k in range(36):
+            assert other.vertices[k].pos.tuple() == mesh.vertices[k].pos.tuple()
     sc.free()
 
 
