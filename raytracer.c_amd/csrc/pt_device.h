@@ -114,6 +114,10 @@ struct PtLaunch
    * reference forms them, (double)options->width - 1.0 (raytracer.c:203-204) */
   double near_R2, w_minus_1, h_minus_1;
   double filt_shift; /* 10 e (max |c| + near_R): how far behind the origin the sign-test filter starts its ray */
+  /* two constants passed in so that they live in SGPRs (as literals the compiler parks each in a
+   * VGPR pair for the whole loop, and spilled them): BACKGROUND's component 10/255
+   * (raytracer.h:46) and DBL_MAX, the initial min_t of intersect() (raytracer.c:396) */
+  double background, t_start;
   double inv_w_minus_1, inv_h_minus_1; /* RN(1/(W-1)), RN(1/(H-1)) for div_small_int */
   double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;

@@ -134,7 +134,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 #endif
 
 constexpr double kEps = 1e-8;       /* raytracer.h:24 */
-constexpr double kBg = 10 / 255.0;  /* raytracer.h:46 BACKGROUND */
 constexpr double kPi = 3.14159265359; /* raytracer.h:22 */
 
 } // namespace
@@ -608,6 +607,7 @@ struct SceneCtx
   uint32_t n_bvh_nodes;
   double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
   double filt_shift;      /* tol_max of the sign-test filter form (scan_filtered) */
+  double bg, t_start;     /* BACKGROUND's component and DBL_MAX, from the launch arguments (SGPR pairs) */
   uint32_t n_sph, n_tri;
   int max_depth;
 };
@@ -657,6 +657,8 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.n_bvh_nodes = sc.n_bvh_nodes;
   ctx.near_R2 = L.near_R2;
   ctx.filt_shift = L.filt_shift;
+  ctx.bg = L.background;
+  ctx.t_start = L.t_start;
   ctx.n_sph = n_sph;
   ctx.n_tri = sc.n_triangles;
   ctx.max_depth = L.max_depth;
@@ -798,7 +800,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
                                            unsigned long long *diag_ptr, PendingRay *stack, int &stack_n,
                                            HitRec *rec = nullptr)
 {
-  V3 add = {kBg, kBg, kBg}; /* what this call contributes if the path ends here */
+  V3 add = {S.bg, S.bg, S.bg}; /* what this call contributes if the path ends here */
   bool path_ends = true;
   const V3 o = P.o, d = P.d;
   HitRec local;
@@ -807,7 +809,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
   if (MODE != 2)
   {
     H.depth_ok = P.depth <= S.max_depth;
-    H.min_t = 1.7976931348623157e308; /* DBL_MAX */
+    H.min_t = S.t_start; /* DBL_MAX */
     H.best = -1;
     H.bary_u = 0;
     H.bary_v = 0;
@@ -1004,14 +1006,14 @@ template <bool TRIS, bool FILT_LDS>
 __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
                                              unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
 {
-  V3 add = {kBg, kBg, kBg}; /* depth limit or no hit: BACKGROUND (:561-564) */
+  V3 add = {S.bg, S.bg, S.bg}; /* depth limit or no hit: BACKGROUND (:561-564) */
   bool path_ends = true;
   const V3 o = P.o, d = P.d;
 
   if (P.depth <= S.max_depth)
   {
     n_casts++;
-    double min_t = 1.7976931348623157e308;
+    double min_t = S.t_start;
     int best = -1;
     double bary_u = 0, bary_v = 0;
     scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
@@ -1042,7 +1044,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
       const V3 light_pos = {2, 7, 2};
       const V3 ldir = v_normalize(v_sub(light_pos, p));
       n_casts++;
-      double shadow_t = 1.7976931348623157e308, su = 0, sv = 0;
+      double shadow_t = S.t_start, su = 0, sv = 0;
       int blocker = -1;
       scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
                                                        S.n_sph + S.n_tri, p, ldir, shadow_t, blocker, su, sv, diag_ptr,

@@ -658,6 +658,8 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
       return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.near_R);
     L.near_R2 = L.near_R * L.near_R;
     L.filt_shift = 10.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
+    L.background = 10 / 255.0;
+    L.t_start = 1.7976931348623157e308; /* DBL_MAX */
     L.w_minus_1 = (double)params->width - 1.0;
     L.h_minus_1 = (double)params->height - 1.0;
     L.inv_w_minus_1 = 1.0 / L.w_minus_1; /* IEEE division on the host: correctly rounded */
