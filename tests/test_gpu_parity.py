@@ -127,6 +127,19 @@ def test_full_size_config4_tiles_vs_oracle(gpu, pt):
     gs.close()
 
 
+def test_full_frame_1080p_every_pixel_vs_oracle(gpu, pt):
+    """every one of the 2,073,600 pixels of the headline geometry (1 spp so that the
+    single-threaded oracle finishes in seconds), and the whole frame's counters"""
+    from rt_amd import scene as S
+    sc = S.build_scene(4, samples=1)
+    assert (sc.width, sc.height) == (1920, 1080)
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(SEED)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="config 4, full 1080p frame")
+    gs.close()
+
+
 def test_host_api_render_matches_tiles(gpu, pt):
     """render() of the raytracer.h boundary (C host -> rt_hip_render_image) == tile API"""
     import ctypes as C
