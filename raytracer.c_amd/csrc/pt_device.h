@@ -7,7 +7,8 @@
  *                 it once is the same double), |centre|, 0
  *       triangle: centre / squared radius / radius of a bounding sphere (filter only)
  *       The first four doubles of the sphere records are what the exact test and the
- *       normal use; they are staged in LDS per workgroup.
+ *       normal use; they are staged in LDS per workgroup (scenes beyond the 24 KiB staging
+ *       budget read the compact copy geom4 from memory instead).
  *   filt       [ceil(entries/2)] x 5 f32x2       : cx cy cz r2_hi neg_tol, two primitives per
  *       f32x2 -- the packed-fp32 phase-1 filter table, rebuilt per launch (pt_build_filter)
  *       because its thresholds depend on the camera distance; read with wave-uniform
@@ -59,7 +60,6 @@
 #define PT_GEOM_STRIDE 4     /* LDS doubles per sphere: cx cy cz r2 */
 #define PT_FILT_STRIDE 5     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
 #define PT_ENTRY_SRC_STRIDE 6 /* HBM doubles per primitive: cx cy cz R2 |c| Rb (bounding data, fp64) */
-#define PT_MAX_LDS_SPHERES 1024
 
 #define PT_REFRACT_MAX_DEPTH 32 /* pending-ray stack of pt_render_tiles_refract holds max_depth + 2 */
 
@@ -71,6 +71,8 @@
 struct PtSceneView
 {
   const double *entry_src; /* n_spheres + n_triangles bounding records, scan order */
+  const double *geom4;     /* n_spheres x PT_GEOM_STRIDE: cx cy cz r2, what the exact test reads when the
+                            * scene is too large to stage in LDS */
   float *filt;             /* packed-fp32 filter table, rebuilt per launch by pt_build_filter */
   const double *material;
   const double *color_raw;
@@ -92,9 +94,16 @@ struct PtSceneView
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
+static inline bool pt_geom_in_lds(const PtSceneView &sc)
+{ /* sphere geometry + materials within the 24 KiB staging budget (6 workgroups per CU) */
+  return (PT_GEOM_STRIDE * (uint64_t)sc.n_spheres + PT_MAT_STRIDE * ((uint64_t)sc.n_spheres + sc.n_meshes)) * 8u <= 24u * 1024u;
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
 static inline bool pt_filter_in_lds(const PtSceneView &sc)
 {
-  return (uint64_t)sc.n_spheres + sc.n_triangles <= PT_FILT_LDS_MAX && !sc.wide_range;
+  return (uint64_t)sc.n_spheres + sc.n_triangles <= PT_FILT_LDS_MAX && !sc.wide_range && pt_geom_in_lds(sc);
 }
 
 struct PtCamera

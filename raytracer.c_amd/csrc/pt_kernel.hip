@@ -612,29 +612,38 @@ struct SceneCtx
   int max_depth;
 };
 
+/* GEOM_LDS: sphere geometry and materials are staged in LDS (the pointers are LDS pointers at
+ * compile time); otherwise the scene is beyond the staging budget (pt_geom_in_lds) and the
+ * kernel reads them from memory.  Kernels pick the instantiation once, at entry. */
+template <bool GEOM_LDS, bool FILT_LDS>
 __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
 {
+  static_assert(GEOM_LDS || !FILT_LDS, "a filter table in LDS implies staged geometry");
   const PtSceneView &sc = L.scene;
   const uint32_t n_sph = sc.n_spheres, n_mat = sc.n_spheres + sc.n_meshes;
+  constexpr bool staged = GEOM_LDS;
   double *geom = lds;
   double *mat = geom + PT_GEOM_STRIDE * (size_t)n_sph;
-  for (uint32_t i = threadIdx.x; i < n_sph; i += PT_BLOCK)
+  if (staged)
   {
-    const double *src = sc.entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz r2 |c| R */
-    double *g = geom + PT_GEOM_STRIDE * i;
-    g[0] = src[0];
-    g[1] = src[1];
-    g[2] = src[2];
-    g[3] = src[3];
+    for (uint32_t i = threadIdx.x; i < n_sph; i += PT_BLOCK)
+    {
+      const double *src = sc.entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz r2 |c| R */
+      double *g = geom + PT_GEOM_STRIDE * i;
+      g[0] = src[0];
+      g[1] = src[1];
+      g[2] = src[2];
+      g[3] = src[3];
+    }
+    for (uint32_t k = threadIdx.x; k < PT_MAT_STRIDE * n_mat; k += PT_BLOCK)
+      mat[k] = sc.material[k];
   }
-  for (uint32_t k = threadIdx.x; k < PT_MAT_STRIDE * n_mat; k += PT_BLOCK)
-    mat[k] = sc.material[k];
   /* Small scenes keep the filter table in LDS (measured 4 % faster than scalar loads on the
    * 38-sphere room: ds_read is prefetched across pairs, s_load is not); large ones stream
    * it through the constant cache. */
   const uint32_t n_entries = n_sph + sc.n_triangles;
   f32x2 *filt_lds = nullptr;
-  if (pt_filter_in_lds(sc))
+  if (FILT_LDS)
   {
     filt_lds = reinterpret_cast<f32x2 *>(mat + PT_MAT_STRIDE * (size_t)n_mat);
     const uint32_t n_slots = PT_FILT_STRIDE * ((n_entries + 1u) / 2u + 1u); /* + the look-ahead pair */
@@ -643,8 +652,16 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
       filt_lds[k] = src[k];
   }
   SceneCtx ctx;
-  ctx.geom = geom;
-  ctx.mat = mat;
+  if (GEOM_LDS)
+  {
+    ctx.geom = geom;
+    ctx.mat = mat;
+  }
+  else
+  {
+    ctx.geom = sc.geom4;
+    ctx.mat = sc.material;
+  }
   ctx.color_raw = sc.color_raw;
   ctx.tri = sc.tri_geom;
   ctx.tri_normal = sc.tri_normal;
@@ -1223,7 +1240,7 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 /* Pooled kernel body.  Not for scenes with M_REFRACTION: there the throughput is not bounded
  * by 1 (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes
  * negative), so no fixed-point scale can be fixed in advance; those scenes use the static body. */
-template <bool CHECKER, bool TRIS, bool FILT_LDS>
+template <bool CHECKER, bool TRIS, bool FILT_LDS, bool GEOM_LDS>
 __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 {
   extern __shared__ double lds[];
@@ -1237,7 +1254,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __shared__ unsigned long long q_rng[PT_BLOCK / 64][64];
   __shared__ uint32_t q_pix[PT_BLOCK / 64][64];
 
-  const SceneCtx S = stage_scene(L, lds);
+  const SceneCtx S = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
   if (threadIdx.x < PT_TILE_PIXELS * 3)
@@ -1493,7 +1510,10 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
  * pt_render_tiles itself is the headline configuration: diffuse / mirror / emissive spheres,
  * small scene. */
 #define PT_KERNEL(name, bounds, CHECKER, TRIS, FILT_LDS)                                     \
-  extern "C" __global__ bounds void name(const PtLaunch L) { render_tiles_pooled<CHECKER, TRIS, FILT_LDS>(L); }
+  extern "C" __global__ bounds void name(const PtLaunch L)                                  \
+  {                                                                                         \
+    render_tiles_pooled<CHECKER, TRIS, FILT_LDS, true>(L);                                  \
+  }
 PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, true)
 PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
 PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_TRI), false, true, true)
@@ -1510,7 +1530,7 @@ PT_KERNEL(pt_render_tiles_tri_big_chk, __launch_bounds__(PT_BLOCK), true, true, 
  * order.  Floating-point sums have no range limit, which is what scenes with M_REFRACTION
  * need (see render_tiles_pooled); VARIANT 0 of it is the plain reference kernel
  * (RT_HIP_KERNEL_VARIANT=0). */
-template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, bool WHITTED = false>
+template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, bool WHITTED, bool GEOM_LDS>
 __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
 {
   extern __shared__ double lds[];
@@ -1518,7 +1538,7 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
 
-  const SceneCtx S = stage_scene(L, lds);
+  const SceneCtx S = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
   __syncthreads();
@@ -1602,7 +1622,7 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
 #define PT_KERNEL_STATIC(name, VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS)                    \
   extern "C" __global__ __launch_bounds__(PT_BLOCK) void name(const PtLaunch L)             \
   {                                                                                         \
-    render_tiles_static<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS>(L);                      \
+    render_tiles_static<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS, false, true>(L);         \
   }
 PT_KERNEL_STATIC(pt_render_tiles_v0, 0, false, true, true, false)
 PT_KERNEL_STATIC(pt_render_tiles_refr, 1, true, true, false, true)
@@ -1615,13 +1635,26 @@ PT_KERNEL_STATIC(pt_render_tiles_tri_big_refr, 1, true, true, true, false)
 #define PT_KERNEL_WHITTED(name, TRIS, FILT_LDS)                                              \
   extern "C" __global__ __launch_bounds__(PT_BLOCK) void name(const PtLaunch L)             \
   {                                                                                         \
-    render_tiles_static<1, false, true, TRIS, FILT_LDS, true>(L);                           \
+    render_tiles_static<1, false, true, TRIS, FILT_LDS, true, true>(L);                     \
   }
 PT_KERNEL_WHITTED(pt_whitted_tiles, false, true)
 PT_KERNEL_WHITTED(pt_whitted_tiles_big, false, false)
 PT_KERNEL_WHITTED(pt_whitted_tiles_tri, true, true)
 PT_KERNEL_WHITTED(pt_whitted_tiles_tri_big, true, false)
 #undef PT_KERNEL_WHITTED
+
+/* Scenes whose sphere geometry + materials exceed the LDS staging budget (pt_geom_in_lds: more
+ * than ~256 spheres, or thousands of meshes): the most general static body -- every material,
+ * triangles through the hierarchy -- reading geometry and materials from memory.  The O(n)
+ * sphere scan dominates such scenes whatever the kernel around it does. */
+extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_mem(const PtLaunch L)
+{
+  render_tiles_static<1, true, true, true, false, false, false>(L);
+}
+extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_whitted_tiles_mem(const PtLaunch L)
+{
+  render_tiles_static<1, false, true, true, false, true, false>(L);
+}
 
 /* Second pass of a chunked render: per-tile fixed-point sums -> float3 + tonemapped bytes. */
 extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const PtLaunch L)
@@ -1777,6 +1810,8 @@ extern "C" __global__ __launch_bounds__(256) void pt_untile(const float *tiles_r
 
 size_t pt_render_lds_bytes(const PtSceneView &sc)
 {
+  if (!pt_geom_in_lds(sc))
+    return 0;
   size_t doubles = PT_GEOM_STRIDE * (size_t)sc.n_spheres + PT_MAT_STRIDE * (size_t)(sc.n_spheres + sc.n_meshes);
   const size_t n_entries = (size_t)sc.n_spheres + sc.n_triangles;
   if (pt_filter_in_lds(sc))
@@ -1809,8 +1844,10 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   static const Kernel whitted[4] = {pt_whitted_tiles, pt_whitted_tiles_big, pt_whitted_tiles_tri, pt_whitted_tiles_tri_big};
   const bool cast_ray = launch.integrator == 1;
   const int which = cast_ray ? 13 + (tris ? 2 : 0) + (big ? 1 : 0) : (refr ? 8 : (chk ? 4 : 0)) + (tris ? 2 : 0) + (big ? 1 : 0);
-  const bool plain = variant == 0 && !refr && !cast_ray;
-  const Kernel kernel = plain ? pt_render_tiles_v0 : (cast_ray ? whitted[which - 13] : family[which]);
+  const bool in_memory = !pt_geom_in_lds(launch.scene); /* too large to stage: the two general kernels */
+  const bool plain = variant == 0 && !refr && !cast_ray && !in_memory;
+  const Kernel kernel = in_memory ? (cast_ray ? pt_whitted_tiles_mem : pt_render_tiles_mem)
+                                  : (plain ? pt_render_tiles_v0 : (cast_ray ? whitted[which - 13] : family[which]));
   static size_t lds_allowed[17] = {0}; /* raised once per process if a scene needs > 64 KiB */
   size_t &allowed = lds_allowed[plain ? 12 : which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)

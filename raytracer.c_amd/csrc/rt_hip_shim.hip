@@ -372,8 +372,6 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   if (n_spheres + n_meshes > 0xFFFFFFu || n_tri > 0x7FFFFFFFu - n_spheres)
     return fail(RT_HIP_ELIMIT, "scene too large");
   const size_t n_mat = n_spheres + n_meshes;
-  if ((PT_GEOM_STRIDE * n_spheres + PT_MAT_STRIDE * n_mat) * sizeof(double) > 24 * 1024)
-    return fail(RT_HIP_ELIMIT, "%zu spheres + %zu meshes exceed the 24 KiB LDS staging area (6 workgroups per CU)", n_spheres, n_meshes);
 
   /* ---- build the kernel layout on the host (pt_device.h) ---- */
   double reach = 0, max_emission = 0, max_center = 0;
@@ -385,7 +383,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   std::vector<double> geom(PT_ENTRY_SRC_STRIDE * (n_spheres + n_tri)), mat(PT_MAT_STRIDE * n_mat), tgeom(9 * n_tri), tnorm(3 * n_tri),
       ttex(6 * n_tri);
   std::vector<uint32_t> tobj(n_tri);
-  std::vector<double> craw(3 * n_mat);
+  std::vector<double> craw(3 * n_mat), geom4(PT_GEOM_STRIDE * n_spheres);
   for (size_t i = 0; i < n_spheres; i++)
     memcpy(&craw[3 * i], spheres[i].color, 3 * sizeof(double));
   for (size_t m = 0; m < n_meshes; m++)
@@ -400,6 +398,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     /* |c|, rounded up: feeds the conservative phase-1 thresholds only, never a result */
     g[4] = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) * (1.0 + 1e-12);
     g[5] = 0.0; /* a sphere is rejected when its centre is behind the origin at all (raytracer.c:84) */
+    memcpy(&geom4[PT_GEOM_STRIDE * i], g, PT_GEOM_STRIDE * sizeof(double));
     max_center = std::fmax(max_center, g[4]);
     wide_range |= !(g[4] <= 1e17) || !(std::fabs(spheres[i].radius) <= 1e17);
     if (std::fabs(spheres[i].radius) < 1000.0) /* wall-sized spheres would only loosen the filter */
@@ -457,7 +456,12 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
 
   /* ---- hierarchy over the triangles of large meshes ---- */
   BvhBuild bvh;
-  if ((n_spheres + n_tri > PT_FILT_LDS_MAX || wide_range) && n_tri > 0) /* = !pt_filter_in_lds() */
+  PtSceneView shape{};
+  shape.n_spheres = (uint32_t)n_spheres;
+  shape.n_meshes = (uint32_t)n_meshes;
+  shape.n_triangles = (uint32_t)n_tri;
+  shape.wide_range = wide_range ? 1u : 0u;
+  if (!pt_filter_in_lds(shape) && n_tri > 0) /* the kernels that will run walk a hierarchy */
   {
     bvh.tgeom = tgeom.data();
     bvh.order.resize(n_tri);
@@ -482,7 +486,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   const size_t off_geom = 0;
   const size_t off_mat = off_geom + pad(geom.size() * 8);
   const size_t off_craw = off_mat + pad(mat.size() * 8);
-  const size_t off_tgeom = off_craw + pad(craw.size() * 8);
+  const size_t off_geom4 = off_craw + pad(craw.size() * 8);
+  const size_t off_tgeom = off_geom4 + pad(geom4.size() * 8);
   const size_t off_tnorm = off_tgeom + pad(tgeom.size() * 8);
   const size_t off_ttex = off_tnorm + pad(tnorm.size() * 8);
   const size_t off_tobj = off_ttex + pad(ttex.size() * 8);
@@ -513,6 +518,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   e = up(off_geom, geom.data(), geom.size() * 8);
   if (e == hipSuccess) e = up(off_mat, mat.data(), mat.size() * 8);
   if (e == hipSuccess) e = up(off_craw, craw.data(), craw.size() * 8);
+  if (e == hipSuccess) e = up(off_geom4, geom4.data(), geom4.size() * 8);
   if (e == hipSuccess) e = up(off_tgeom, tgeom.data(), tgeom.size() * 8);
   if (e == hipSuccess) e = up(off_tnorm, tnorm.data(), tnorm.size() * 8);
   if (e == hipSuccess) e = up(off_ttex, ttex.data(), ttex.size() * 8);
@@ -533,6 +539,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.n_bvh_nodes = (uint32_t)n_bvh_nodes;
   sc->view.material = reinterpret_cast<const double *>(base + off_mat);
   sc->view.color_raw = reinterpret_cast<const double *>(base + off_craw);
+  sc->view.geom4 = reinterpret_cast<const double *>(base + off_geom4);
   sc->view.tri_geom = reinterpret_cast<const double *>(base + off_tgeom);
   sc->view.tri_normal = reinterpret_cast<const double *>(base + off_tnorm);
   sc->view.tri_tex = reinterpret_cast<const double *>(base + off_ttex);
@@ -683,8 +690,8 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   L.tile_stride = params->tile_stride;
   L.tile_count = params->tile_count;
   L.tiles_x = tx;
-  /* the static kernels (plain reference variant; scenes with M_REFRACTION) do not split samples */
-  L.sample_chunks = (kernel_variant() == 0 || scene->view.any_refract || cast_ray) ? 1u : sample_chunks;
+  /* the static kernels (plain reference variant; M_REFRACTION; cast_ray; scenes too large to stage) do not split samples */
+  L.sample_chunks = (kernel_variant() == 0 || scene->view.any_refract || cast_ray || !pt_geom_in_lds(scene->view)) ? 1u : sample_chunks;
   L.integrator = cast_ray ? 1u : 0u;
   L.acc_ws = static_cast<unsigned long long *>(d_workspace);
   if ((uint64_t)L.tile_count * L.sample_chunks > 0x7FFFFFFFull)

@@ -728,3 +728,25 @@ def test_mesh_hierarchy_partitions_and_chunks_are_bit_invariant(gpu):
     assert torch.equal(image, full) and torch.equal(image8, full8) and torch.equal(tot, ref_s)
     gs.close()
     sc.free()
+
+
+def test_many_spheres_beyond_the_lds_staging_budget(gpu, pt):
+    """600 spheres (57 KB of geometry + materials: more than a workgroup stages in LDS): the
+    scalar-table kernels read geometry and materials from memory; with and without a mesh"""
+    from rt_amd import abi, scene as S
+    rng = np.random.default_rng(77)
+    objs = [dict(flags=abi.M_DEFAULT, radius=10000.0, center=(0, -10004.0, 0), color=(0.7, 0.7, 0.7))]
+    flags = [abi.M_DEFAULT, abi.M_DEFAULT, abi.M_REFLECTION, abi.M_DEFAULT | abi.M_CHECKERED]
+    for k in range(599):
+        c = rng.uniform(-20, 20, 3)
+        c[1] = rng.uniform(-3, 12)
+        emi = tuple(rng.uniform(0, 4, 3)) if k % 9 == 0 else (0, 0, 0)
+        objs.append(dict(flags=int(flags[k % 4]), radius=float(rng.uniform(0.3, 1.2)), center=tuple(c),
+                         color=tuple(rng.uniform(0.2, 1, 3)), emission=emi))
+    sc = S.custom_scene(objs, 56, 32, 3, 5, (0, 6, 45), (0, 2, 0))
+    st = _full(gpu, pt, sc)
+    assert st["tests"] == st["casts"] * 600
+    tri = [[(-6, -3.9, 6, 0, 0), (6, -3.9, 6, 1, 0), (0, 9, 6, 0, 1)]]
+    meshes = [dict(flags=abi.M_REFLECTION, color=(0.9, 0.9, 0.9), triangles=tri)]
+    _full(gpu, pt, S.custom_scene(objs, 40, 24, 2, 4, (0, 6, 45), (0, 2, 0), meshes=meshes))
+    _full(gpu, pt, S.custom_scene(objs, 40, 24, 2, 3, (0, 6, 45), (0, 2, 0), meshes=meshes), integrator="whitted")
