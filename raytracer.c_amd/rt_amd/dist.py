@@ -51,15 +51,38 @@ def gather_tiles(tiles, tiles8, rank, world, gathered=None, gathered8=None, dst=
             return None, None
         return ([t.to(tiles.device) for t in host],
                 [t.to(tiles.device) for t in host8] if host8 is not None else None)
+    if _MODE[0] == "all_gather":
+        return _all_gather_tiles(tiles, tiles8, rank, world, dst)
     if rank == dst:
         if gathered is None:
             gathered = [torch.empty_like(tiles) for _ in range(world)]
         if gathered8 is None and tiles8 is not None:
             gathered8 = [torch.empty_like(tiles8) for _ in range(world)]
-    dist.gather(tiles, gathered if rank == dst else None, dst=dst)
+    try:
+        dist.gather(tiles, gathered if rank == dst else None, dst=dst)
+    except (RuntimeError, NotImplementedError) as exc:
+        # a backend without gather-to-root: every rank takes the same branch (the call fails
+        # before any communication), so switching collectively is safe
+        import sys
+        print(f"rt_amd.dist: gather unavailable ({exc}); using all_gather", file=sys.stderr)
+        _MODE[0] = "all_gather"
+        return _all_gather_tiles(tiles, tiles8, rank, world, dst)
     if tiles8 is not None:
         dist.gather(tiles8, gathered8 if rank == dst else None, dst=dst)
     return (gathered, gathered8) if rank == dst else (None, None)
+
+
+_MODE = ["gather"]  # "gather" (to the root only) or "all_gather" (fallback: G times the traffic)
+
+
+def _all_gather_tiles(tiles, tiles8, rank, world, dst):
+    parts = [torch.empty_like(tiles) for _ in range(world)]
+    dist.all_gather(parts, tiles)
+    parts8 = None
+    if tiles8 is not None:
+        parts8 = [torch.empty_like(tiles8) for _ in range(world)]
+        dist.all_gather(parts8, tiles8)
+    return (parts, parts8) if rank == dst else (None, None)
 
 
 def segments(width, height, world):

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, w, h, spp, out_path):
+def _worker(rank, world, port, w, h, spp, out_path, mode="gather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       OMP_NUM_THREADS="1")
     for p in (os.path.join(ROOT, "raytracer.c_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -32,6 +32,7 @@ def _worker(rank, world, port, w, h, spp, out_path):
     from util import tile_pixels, untile_numpy
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    D._MODE[0] = mode  # "all_gather": the fallback for a backend without gather-to-root
     sc = S.build_scene(2, w, h, spp)
     pt = oracle_py.PtOracle()
     first, stride, count = D.rank_tiles(w, h, rank, world)
@@ -68,6 +69,13 @@ def test_gather_assembles_the_frame(tmp_path, world, w, h):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(world, _free_port(), w, h, 2, out), nprocs=world, join=True)
+    assert open(out).read() == "OK"
+
+
+def test_all_gather_fallback_assembles_the_same_frame(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), 40, 24, 2, out, "all_gather"), nprocs=2, join=True)
     assert open(out).read() == "OK"
 
 
