@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""One-off wide fuzz: many random scenes (tests/test_gpu_parity._random_scene), both integrators,
+GPU vs the CPU oracle with the tests' parity bar.  usage: python tools/gpu_fuzz_parity.py [first] [count]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("raytracer.c_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+import numpy as np
+import oracle_py
+from rt_amd import abi, gpu as G
+from test_gpu_parity import _random_scene
+from util import assert_parity
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+pt = oracle_py.PtOracle()
+both = (abi.M_REFLECTION | abi.M_REFRACTION, abi.M_REFRACTION | abi.M_CHECKERED)
+bad = 0
+for k in range(first, first + count):
+    n_tris = [0, 0, 0, 7, 60, 300, 900][k % 7]
+    sc = _random_scene(k, n_tris > 0, n_tris, extra_flags=both if k % 2 else ())
+    for integrator in ("path", "whitted"):
+        gs = G.GpuScene(sc)
+        try:
+            img, img8, st = gs.render_image(1666943821 + k, integrator=integrator)
+        except G.ShimError as e:
+            print(f"scene {k} {integrator}: refused ({str(e)[:90]})")
+            gs.close()
+            continue
+        mean, rgb8, ost = pt.render_pixels(sc, 1666943821 + k, integrator=integrator)
+        try:
+            assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"scene {k} {integrator}")
+        except AssertionError as e:
+            bad += 1
+            print("FAIL", e)
+        gs.close()
+    if (k - first) % 50 == 49:
+        print(f"{k - first + 1} scenes done, {bad} failures", flush=True)
+print("failures:", bad)
+sys.exit(1 if bad else 0)
