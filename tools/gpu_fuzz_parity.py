@@ -20,6 +20,7 @@ bad = 0
 for k in range(first, first + count):
     n_tris = [0, 0, 0, 7, 60, 300, 900][k % 7]
     sc = _random_scene(k, n_tris > 0, n_tris, extra_flags=both if k % 2 else ())
+    sc.samples *= int(os.environ.get("FUZZ_SPP_MULT", "1"))  # more samples per pixel: longer job pools
     for integrator in ("path", "whitted"):
         gs = G.GpuScene(sc)
         try:
