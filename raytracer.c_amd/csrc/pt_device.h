@@ -27,8 +27,9 @@
  *   tri_tex    [n_triangles] x 6 f64 : st0, st1, st2 (read only for a winning triangle of an
  *       M_CHECKERED mesh).
  *   tri_object [n_triangles] u32     : material slot of the owning mesh.
- *   bvh_src    [n_bvh_nodes] x 16 f64 : for meshes beyond PT_FILT_LDS_MAX primitives, a binary
- *       bounding-volume hierarchy over the triangles.  A node holds the boxes of its TWO children
+ *   bvh_src    [n_bvh_nodes] x 16 f64 : a binary bounding-volume hierarchy over the triangles
+ *       (built for every scene that has any; the small-scene kernels scan triangles through
+ *       the flat filter and ignore it).  A node holds the boxes of its TWO children
  *       (child 0: min xyz, max xyz; child 1: the same) and their references packed as two u32
  *       in double 12: an inner child is its node index, a leaf child is
  *       PT_BVH_LEAF_FLAG | first << 3 | count and covers bvh_tri[first .. first+count).  Node 0
@@ -84,8 +85,9 @@ struct PtSceneView
   float *bvh_nodes;
   const uint32_t *bvh_tri;
   uint32_t n_spheres, n_meshes, n_triangles, any_checker;
-  uint32_t any_refract, n_bvh_nodes; /* n_bvh_nodes == 0: triangles go through the flat filter */
-  uint32_t wide_range, pad_;         /* a centre or radius beyond 1e17: fp32 sums could overflow */
+  uint32_t any_refract, n_bvh_nodes; /* n_bvh_nodes == 0: the scene has no triangles */
+  uint32_t wide_range;               /* a centre or radius beyond 1e17: fp32 sums could overflow */
+  uint32_t any_mirror_glass;         /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children per hit */
 };
 
 /* Small scenes keep the filter table in LDS and (sphere-only ones) use the sign-test form of

@@ -1019,7 +1019,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
  * (:617-628).  Children are weighted by scalars, so the forward form carries a scalar weight
  * in P.T; a hit with both M_REFLECTION and M_REFRACTION traces the mirror child first and
  * parks the other on the pending-ray stack.  No random draws after the camera jitter. */
-template <bool TRIS, bool FILT_LDS>
+template <bool TRIS, bool FILT_LDS, bool STACK>
 __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
                                              unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
 {
@@ -1120,7 +1120,8 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
         if (mirror)
         {
           const V3 refl = v_normalize(v_sub(d, v_scale(n, 2 * v_dot(d, n))));
-          if (glass && stack_n < PT_REFRACT_STACK)
+          /* STACK = false: the launcher has checked that no material carries both flags */
+          if (STACK && glass && stack_n < PT_REFRACT_STACK)
           {
             PendingRay &pend = stack[stack_n++];
             pend.o = p;
@@ -1145,7 +1146,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
   if (path_ends)
   {
     P.Ls = v_add(P.Ls, v_mul(P.T, add));
-    if (stack_n > 0)
+    if (STACK && stack_n > 0)
     {
       const PendingRay &pend = stack[--stack_n];
       P.o = pend.o;
@@ -1530,7 +1531,9 @@ PT_KERNEL(pt_render_tiles_tri_big_chk, __launch_bounds__(PT_BLOCK), true, true, 
  * order.  Floating-point sums have no range limit, which is what scenes with M_REFRACTION
  * need (see render_tiles_pooled); VARIANT 0 of it is the plain reference kernel
  * (RT_HIP_KERNEL_VARIANT=0). */
-template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, bool WHITTED, bool GEOM_LDS>
+/* WHITTED: 0 = trace_path, 1 = cast_ray for scenes where no material has both M_REFLECTION and
+ * M_REFRACTION (one child per hit at most: no pending-ray stack), 2 = cast_ray with the stack */
+template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int WHITTED, bool GEOM_LDS>
 __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
 {
   extern __shared__ double lds[];
@@ -1565,7 +1568,7 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   uint32_t n_rays = 0, n_casts = 0;
   uint32_t s = inside ? slice : spp;
   bool fresh = true;
-  PendingRay stack[(REFRACT || WHITTED) ? PT_REFRACT_STACK : 1];
+  PendingRay stack[(REFRACT || WHITTED == 2) ? PT_REFRACT_STACK : 1];
   int stack_n = 0;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
@@ -1582,7 +1585,7 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
       fresh = false;
     }
     n_rays++;
-    const bool finished = WHITTED ? whitted_step<TRIS, FILT_LDS>(S, P, n_casts, diag_ptr, stack, stack_n)
+    const bool finished = WHITTED ? whitted_step<TRIS, FILT_LDS, WHITTED == 2>(S, P, n_casts, diag_ptr, stack, stack_n)
                                   : trace_step<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS>(S, P, n_casts, diag_ptr,
                                                                                           stack, stack_n);
     if (finished)
@@ -1622,7 +1625,7 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
 #define PT_KERNEL_STATIC(name, VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS)                    \
   extern "C" __global__ __launch_bounds__(PT_BLOCK) void name(const PtLaunch L)             \
   {                                                                                         \
-    render_tiles_static<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS, false, true>(L);         \
+    render_tiles_static<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS, 0, true>(L);             \
   }
 PT_KERNEL_STATIC(pt_render_tiles_v0, 0, false, true, true, false)
 PT_KERNEL_STATIC(pt_render_tiles_refr, 1, true, true, false, true)
@@ -1631,11 +1634,12 @@ PT_KERNEL_STATIC(pt_render_tiles_tri_refr, 1, true, true, true, true)
 PT_KERNEL_STATIC(pt_render_tiles_tri_big_refr, 1, true, true, true, false)
 #undef PT_KERNEL_STATIC
 
-/* cast_ray kernels: the static body with whitted_step */
+/* cast_ray kernels: the static body with whitted_step, without a pending-ray stack (scenes with
+ * a material that has both M_REFLECTION and M_REFRACTION take pt_whitted_tiles_mem) */
 #define PT_KERNEL_WHITTED(name, TRIS, FILT_LDS)                                              \
-  extern "C" __global__ __launch_bounds__(PT_BLOCK) void name(const PtLaunch L)             \
+  extern "C" __global__ __launch_bounds__(PT_BLOCK, 4) void name(const PtLaunch L)          \
   {                                                                                         \
-    render_tiles_static<1, false, true, TRIS, FILT_LDS, true, true>(L);                     \
+    render_tiles_static<1, false, true, TRIS, FILT_LDS, 1, true>(L);                        \
   }
 PT_KERNEL_WHITTED(pt_whitted_tiles, false, true)
 PT_KERNEL_WHITTED(pt_whitted_tiles_big, false, false)
@@ -1649,11 +1653,11 @@ PT_KERNEL_WHITTED(pt_whitted_tiles_tri_big, true, false)
  * sphere scan dominates such scenes whatever the kernel around it does. */
 extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_mem(const PtLaunch L)
 {
-  render_tiles_static<1, true, true, true, false, false, false>(L);
+  render_tiles_static<1, true, true, true, false, 0, false>(L);
 }
 extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_whitted_tiles_mem(const PtLaunch L)
 {
-  render_tiles_static<1, false, true, true, false, true, false>(L);
+  render_tiles_static<1, false, true, true, false, 2, false>(L);
 }
 
 /* Second pass of a chunked render: per-tile fixed-point sums -> float3 + tonemapped bytes. */
@@ -1825,7 +1829,9 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   {
     /* the filter table for this camera: a ~2 us kernel ahead of the render on the same stream */
     const uint32_t n_nodes = launch.scene.n_bvh_nodes;
-    const uint32_t n_entries = launch.scene.n_spheres + (n_nodes ? 0u : launch.scene.n_triangles);
+    /* every primitive gets a filter entry: small-scene kernels scan triangles through the flat
+     * filter, the others read the sphere part only and walk the hierarchy for the triangles */
+    const uint32_t n_entries = launch.scene.n_spheres + launch.scene.n_triangles;
     const uint32_t blocks = n_entries ? min(1024u, (n_entries + 255u) / 256u) : 0u;
     if (blocks)
       hipLaunchKernelGGL(pt_build_filter, dim3(blocks), dim3(256), 0, stream, launch.scene.entry_src, n_entries,
@@ -1844,7 +1850,8 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   static const Kernel whitted[4] = {pt_whitted_tiles, pt_whitted_tiles_big, pt_whitted_tiles_tri, pt_whitted_tiles_tri_big};
   const bool cast_ray = launch.integrator == 1;
   const int which = cast_ray ? 13 + (tris ? 2 : 0) + (big ? 1 : 0) : (refr ? 8 : (chk ? 4 : 0)) + (tris ? 2 : 0) + (big ? 1 : 0);
-  const bool in_memory = !pt_geom_in_lds(launch.scene); /* too large to stage: the two general kernels */
+  /* too large to stage, or cast_ray with two-child materials: the two general kernels */
+  const bool in_memory = !pt_geom_in_lds(launch.scene) || (launch.integrator == 1 && launch.scene.any_mirror_glass);
   const bool plain = variant == 0 && !refr && !cast_ray && !in_memory;
   const Kernel kernel = in_memory ? (cast_ray ? pt_whitted_tiles_mem : pt_render_tiles_mem)
                                   : (plain ? pt_render_tiles_v0 : (cast_ray ? whitted[which - 13] : family[which]));

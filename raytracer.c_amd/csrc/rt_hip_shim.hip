@@ -454,14 +454,12 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     }
   }
 
-  /* ---- hierarchy over the triangles of large meshes ---- */
+  /* ---- hierarchy over the triangles ---- */
   BvhBuild bvh;
-  PtSceneView shape{};
-  shape.n_spheres = (uint32_t)n_spheres;
-  shape.n_meshes = (uint32_t)n_meshes;
-  shape.n_triangles = (uint32_t)n_tri;
-  shape.wide_range = wide_range ? 1u : 0u;
-  if (!pt_filter_in_lds(shape) && n_tri > 0) /* the kernels that will run walk a hierarchy */
+  /* built for every scene with triangles: the small-scene kernels scan them through the flat
+   * filter instead, but the general in-memory kernels (too-large scenes, cast_ray with
+   * two-child materials) always walk the hierarchy */
+  if (n_tri > 0)
   {
     bvh.tgeom = tgeom.data();
     bvh.order.resize(n_tri);
@@ -554,6 +552,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->reach = reach;
   sc->max_emission = max_emission;
   sc->any_mirror_glass = any_mirror_glass;
+  sc->view.any_mirror_glass = any_mirror_glass ? 1u : 0u;
   *out_scene = sc;
   return RT_HIP_OK;
 }
