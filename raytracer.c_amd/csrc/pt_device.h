@@ -62,7 +62,7 @@
 #define PT_FILT_STRIDE 5     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
 #define PT_ENTRY_SRC_STRIDE 6 /* HBM doubles per primitive: cx cy cz R2 |c| Rb (bounding data, fp64) */
 
-#define PT_REFRACT_MAX_DEPTH 32 /* pending-ray stack of pt_render_tiles_refract holds max_depth + 2 */
+#define PT_REFRACT_MAX_DEPTH 32 /* the pending-ray stack of the two-child kernels holds max_depth + 2 */
 
 #define PT_FLAG_DIFFUSE 2u
 #define PT_FLAG_MIRROR 4u

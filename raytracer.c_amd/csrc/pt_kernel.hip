@@ -152,7 +152,7 @@ constexpr double kPi = 3.14159265359; /* raytracer.h:22 */
  *     fp32 with fused multiply-adds (v_pk_fma_f32: 5 packed ops per sphere instead of 15
  *     fp64 ops).  fp32 values differ from the reference's fp64 ones by a bounded amount;
  *     the thresholds are widened by a rigorous bound on that difference (derivation at
- *     stage_scene), so phase 1 NEVER drops a sphere the reference accepts -- it can only
+ *     pt_build_filter), so phase 1 NEVER drops a sphere the reference accepts -- it can only
  *     let extra ones through.  It records, per lane, a bit mask of surviving spheres.
  *     Rays that start farther out than the staging assumed (|o| > near_R) skip the filter
  *     and keep every sphere.
@@ -1504,9 +1504,10 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 }
 
 /* Kernel family pt_render_tiles[_tri][_big][_chk|_refr], picked by scene content
- * (pt_launch_render): "_tri" = scene has triangles, "_big" = more than PT_FILT_LDS_MAX
- * primitives (filter table by scalar loads, triangles through the hierarchy), "_chk" = scene
- * has M_CHECKERED materials (atan2 / fmod), "_refr" = scene has M_REFRACTION materials
+ * (pt_launch_render): "_tri" = scene has triangles; "_big" = the filter table is not in LDS
+ * (more than PT_FILT_LDS_MAX primitives, or centres / radii beyond fp32's comfortable range):
+ * table by scalar loads, NaN-safe compares, triangles through the hierarchy; "_chk" = scene
+ * has M_CHECKERED materials (atan2 / fmod); "_refr" = scene has M_REFRACTION materials
  * (static body + per-lane stack of pending second children; also covers M_CHECKERED).
  * pt_render_tiles itself is the headline configuration: diffuse / mirror / emissive spheres,
  * small scene. */

@@ -137,7 +137,7 @@ void put_material(double *m, uint32_t flags, const double *color, const double *
   memcpy(&m[7], &bits, sizeof bits);
 }
 
-/* ---- bounding-volume hierarchy over triangles (meshes beyond PT_FILT_LDS_MAX primitives) ----
+/* ---- bounding-volume hierarchy over triangles ----
  * Binary tree, median split on the longest axis of the centroid bounds (balanced: depth =
  * ceil(log2(leaves))), leaves of <= PT_BVH_LEAF triangles.  A node stores the boxes of its two
  * children, so the device tests both with one set of packed-fp32 instructions, descends into
@@ -654,7 +654,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   L.seed = params->seed;
   {
     /* Ray origins are the camera or points on primitives.  The packed-fp32 filter of
-     * scan_spheres is built for origins within near_R; a ray starting farther out (e.g. on
+     * scan_filtered is built for origins within near_R; a ray starting farther out (e.g. on
      * the far side of a radius-1e4 "wall" sphere) is still traced exactly, it just skips
      * the filter.  near_R only trades filter tightness against that fallback. */
     const double *c = camera->position;
