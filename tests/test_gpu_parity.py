@@ -750,3 +750,20 @@ def test_many_spheres_beyond_the_lds_staging_budget(gpu, pt):
     meshes = [dict(flags=abi.M_REFLECTION, color=(0.9, 0.9, 0.9), triangles=tri)]
     _full(gpu, pt, S.custom_scene(objs, 40, 24, 2, 4, (0, 6, 45), (0, 2, 0), meshes=meshes))
     _full(gpu, pt, S.custom_scene(objs, 40, 24, 2, 3, (0, 6, 45), (0, 2, 0), meshes=meshes), integrator="whitted")
+
+
+def test_many_samples_per_pixel(gpu, pt):
+    """16x16 pixels x 20,000 spp: long job pools (1,250 refills of a wave's sample queue), 5 million
+    fixed-point additions per tile, and the same again split over 7 sample chunks"""
+    import torch
+    from rt_amd import scene as S
+    sc = S.build_scene(1, 16, 16, 20000)
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(SEED)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="20000 spp")
+    t, t8, _ = gs.render_tiles(SEED, 0, 1, 4, chunks=7)
+    full, full8 = gs.untile(t, t8, 0, 1, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(full, img) and torch.equal(full8, img8)
+    gs.close()
