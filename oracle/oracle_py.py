@@ -142,6 +142,15 @@ class PtOracle(_Common):
             C.c_uint32(s), C.c_uint64(seed), _ptr(rgb), stats)
         return rgb, dict(rays=stats[0], tests=stats[1], casts=stats[2], draws=stats[3])
 
+    def intersect_mesh_scene(self, ray, scene):
+        pn, tuv, oid, tests = np.zeros(6), np.zeros(3), C.c_uint32(0), C.c_longlong(0)
+        fn = self.lib.pto_intersect_mesh_scene
+        fn.restype = C.c_int
+        ok = fn(_ptr(_dbl(ray)), scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
+                _ptr(pn), _ptr(tuv), C.byref(oid), C.byref(tests))
+        return dict(hit=bool(ok), point=pn[:3].copy(), normal=pn[3:].copy(), min_t=tuv[0], u=tuv[1], v=tuv[2],
+                    id=oid.value, tests=tests.value)
+
     def tonemap(self, mean):
         mean = _dbl(mean)
         out = np.zeros(mean.shape, dtype=np.uint8)
@@ -207,3 +216,61 @@ class RefOracle(_Common):
             _ptr(fb, C.c_uint8), scene.objects, C.c_size_t(scene.n_objects), C.byref(scene.camera),
             C.c_int(scene.width), C.c_int(scene.height), C.c_int(spp or scene.samples), C.c_uint(libc_seed), stats)
         return fb, dict(rays=stats[0], tests=stats[1])
+
+
+def ref_mesh_path(depth):
+    return os.path.join(HERE, "_ref", f"libref_mesh_d{depth}.so")
+
+
+def ref_mesh_available(depth=None):
+    depths = REF_DEPTHS if depth is None else (depth,)
+    return all(os.path.exists(ref_mesh_path(d)) for d in depths)
+
+
+class RefMeshOracle(RefOracle):
+    """The reference's compiled trace_path() / cast_ray() and primitives with its commented-out
+    mesh scan (raytracer.c:417-435) revived around them (ref_harness.c, ORACLE_MESH_HOOK).
+    Scenes without meshes go through the same hook and must equal RefOracle's bit for bit."""
+
+    def __init__(self, depth):
+        path = ref_mesh_path(depth)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing (built by `make oracle` where /root/reference exists)")
+        self.lib = C.CDLL(path)
+        self.depth = depth
+        assert self.lib.ref_max_depth() == depth and self.lib.ref_mesh_hook() == 1
+        self.lib.ref_mesh_layout.restype = C.c_uint64
+        assert self.lib.ref_mesh_layout() == C.sizeof(abi.MeshObject)
+
+    def render_pixels(self, scene, seed, pixels=None, spp=None, want_rgb8=True, integrator="path"):
+        self.lib.ref_set_integrator(C.c_int(INTEGRATORS[integrator]))
+        ptr, npix, keep = _pixels_arg(pixels, scene.width, scene.height)
+        mean = np.zeros((npix, 3))
+        rgb8 = np.zeros((npix, 3), dtype=np.uint8)
+        stats = (C.c_longlong * 2)()
+        self.lib.ref_mesh_render_pixels(
+            scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
+            C.byref(scene.camera), C.c_int(scene.width), C.c_int(scene.height), C.c_int(spp or scene.samples),
+            C.c_uint64(seed), ptr, C.c_size_t(npix), _ptr(mean), _ptr(rgb8, C.c_uint8) if want_rgb8 else None, stats)
+        return mean, rgb8, dict(rays=stats[0], tests=stats[1])
+
+    def trace_sample(self, scene, x, y, s, seed, integrator="path"):
+        rgb = np.zeros(3)
+        stats = (C.c_longlong * 3)()
+        self.lib.ref_set_integrator(C.c_int(INTEGRATORS[integrator]))
+        self.lib.ref_mesh_trace_sample(
+            scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
+            C.byref(scene.camera), C.c_int(scene.width), C.c_int(scene.height), C.c_uint32(x), C.c_uint32(y),
+            C.c_uint32(s), C.c_uint64(seed), _ptr(rgb), stats)
+        return rgb, dict(rays=stats[0], tests=stats[1], draws=stats[2])
+
+    def intersect_mesh_scene(self, ray, scene):
+        """One call of the revived scan -> dict(hit, point, normal, t/u/v as the literal block leaves
+        them (stale), min_t and the winner's own u/v, object id, primitive tests)."""
+        pn, tuv, win, oid, tests = np.zeros(6), np.zeros(3), np.zeros(3), C.c_uint32(0), C.c_longlong(0)
+        fn = self.lib.ref_intersect_mesh_scene
+        fn.restype = C.c_int
+        ok = fn(_ptr(_dbl(ray)), scene.objects, C.c_size_t(scene.n_objects), scene.meshes, C.c_size_t(scene.n_meshes),
+                _ptr(pn), _ptr(tuv), _ptr(win), C.byref(oid), C.byref(tests))
+        return dict(hit=bool(ok), point=pn[:3].copy(), normal=pn[3:].copy(), t_stale=tuv[0], u=tuv[1], v=tuv[2],
+                    min_t=win[0], u_win=win[1], v_win=win[2], id=oid.value, tests=tests.value)

@@ -13,9 +13,12 @@
  * BASELINE.json's configs, and to the golden fixtures under tests/golden/
  * that the compiled reference generated.  The triangle-mesh scene scan has no
  * live caller in the reference (its intersect() mesh branch is commented out,
- * raytracer.c:414-455); for it parity is pinned at PRIMITIVE level only
- * (intersect_triangle, calculate_surface_normal vs the compiled reference) and
- * the scan order follows that comment block.
+ * raytracer.c:414-455); it is pinned IN COMPOSITION against oracle/_ref/
+ * libref_mesh_d<N>.so, where that comment block is revived around the
+ * reference's compiled intersect_triangle / calculate_surface_normal / point_at
+ * and called by its compiled trace_path() / cast_ray() (ref_harness.c,
+ * ORACLE_MESH_HOOK): closest hits on random rays, per-sample traces and whole
+ * frames of mesh scenes are bit-identical (tests/test_oracle_ref.py).
  *
  * Compile without FMA contraction (oracle/Makefile: -ffp-contract=off), as
  * the reference is (gcc --std=c99, no -march).
@@ -153,6 +156,14 @@ static int closest_hit(Ctx *c, const Ray *ray, Closest *best)
       best->normal = vec3_normalize(vec3_sub(best->point, c->objs[i].center));
     }
   }
+  /* intersect_triangle() stores the texture coordinates into the caller's Hit whenever it
+   * returns true (:165-166), i.e. BEFORE the caller's `local.t < min_t` test (:426), and the
+   * scan never restores them: after the loop hit.u / hit.v are those of the LAST triangle in
+   * scan order that the ray passes at t > EPSILON -- closest or not, and even when the closest
+   * hit is a sphere (spheres are scanned first, and their u / v are written only on a closer
+   * hit, :410-411).  Reproduced here; only M_CHECKERED materials read u / v. */
+  int any_triangle = 0;
+  double last_u = 0, last_v = 0;
   for (size_t m = 0; m < c->n_meshes; m++)
   {
     const TriangleMesh *mesh = &c->meshes[m].mesh;
@@ -161,21 +172,30 @@ static int closest_hit(Ctx *c, const Ray *ray, Closest *best)
       const Vertex *a = &mesh->vertices[3 * ti], *b = a + 1, *d = a + 2;
       double t, u, v;
       c->tests++;
-      if (triangle_test(ray, a, b, d, &t, &u, &v) && t < min_t)
+      if (triangle_test(ray, a, b, d, &t, &u, &v))
       {
-        min_t = t;
-        found = 1;
-        best->t = t;
-        best->u = u;
-        best->v = v;
-        best->is_mesh = 1;
-        best->index = m;
-        best->point = at(ray, t);
-        best->normal = surface_normal(a->pos, b->pos, d->pos);
+        any_triangle = 1;
+        last_u = u;
+        last_v = v;
+        if (t < min_t)
+        {
+          min_t = t;
+          found = 1;
+          best->t = t;
+          best->is_mesh = 1;
+          best->index = m;
+          best->point = at(ray, t);
+          best->normal = surface_normal(a->pos, b->pos, d->pos);
+        }
       }
     }
   }
-  if (found && !best->is_mesh)
+  if (any_triangle)
+  {
+    best->u = last_u;
+    best->v = last_v;
+  }
+  else if (found)
   {
     /* raytracer.c:410-411, evaluated once for the winner (same value as
      * evaluating it at every provisional winner) */
@@ -593,6 +613,28 @@ int pto_intersect_scene(const double ray[6], const Object *objs, size_t n, doubl
   out_tuv[1] = hit.u;
   out_tuv[2] = hit.v;
   *id = (uint32_t)hit.index;
+  return ok;
+}
+
+/* the scan with meshes; out_tuv: closest t, then Hit.u / .v as the scan leaves them; id: sphere
+ * index, or n + mesh index (Hit.object_id of the revived block); tests: primitive tests */
+int pto_intersect_mesh_scene(const double ray[6], const Object *objs, size_t n, const MeshObject *meshes,
+                             size_t n_meshes, double out_pn[6], double out_tuv[3], uint32_t *id, long long *tests)
+{
+  Ctx c;
+  Closest hit;
+  Ray r = {arr3(ray), arr3(ray + 3)};
+  ctx_init(&c, objs, n, meshes, n_meshes, 0);
+  memset(&hit, 0, sizeof hit);
+  hit.t = DBL_MAX;
+  int ok = closest_hit(&c, &r, &hit);
+  out3(out_pn, hit.point);
+  out3(out_pn + 3, hit.normal);
+  out_tuv[0] = hit.t;
+  out_tuv[1] = hit.u;
+  out_tuv[2] = hit.v;
+  *id = (uint32_t)(hit.is_mesh ? n + hit.index : hit.index);
+  *tests = c.tests;
   return ok;
 }
 

@@ -47,6 +47,8 @@ void pto_refract(const double in[3], const double n[3], double iot, double out[3
 void pto_checkered(const double color[3], double u, double v, double m, double out[3]);
 int pto_intersect_scene(const double ray[6], const Object *objs, size_t n, double out_pn[6],
                         double out_tuv[3], uint32_t *id);
+int pto_intersect_mesh_scene(const double ray[6], const Object *objs, size_t n, const MeshObject *meshes,
+                             size_t n_meshes, double out_pn[6], double out_tuv[3], uint32_t *id, long long *tests);
 void pto_random_doubles(uint64_t seed, uint32_t pixel, uint32_t sample, int count, double *out);
 void pto_tonemap(const double *mean, size_t npix, uint8_t *out_rgb8);
 

@@ -55,3 +55,19 @@ def ref():
             cache[depth] = oracle_py.RefOracle(depth)
         return cache[depth]
     return get
+
+
+@pytest.fixture(scope="session")
+def ref_mesh():
+    """factory: depth -> RefMeshOracle (the reference's compiled code with its commented-out mesh
+    scan revived, oracle/ref_harness.c ORACLE_MESH_HOOK), or skip when not built"""
+    import oracle_py
+    cache = {}
+
+    def get(depth):
+        if not oracle_py.ref_mesh_available(depth):
+            pytest.skip(f"oracle/_ref/libref_mesh_d{depth}.so not built (needs /root/reference)")
+        if depth not in cache:
+            cache[depth] = oracle_py.RefMeshOracle(depth)
+        return cache[depth]
+    return get

@@ -95,6 +95,35 @@ def whitted_scene(width=96, height=64, samples=2, max_depth=5):
     return S.custom_scene(objs, width, height, samples, max_depth, (0, 6, 38), (0, 0, 0))
 
 
+def mesh_soup_scene(seed=5, n_tris=40, width=64, height=48, samples=4, max_depth=8, checker=True, duplicates=True):
+    """spheres + a random triangle soup with random texture coordinates, some triangles duplicated
+    (exact ties between indices) and some degenerate (zero area, |a| < EPSILON): the scene on which
+    the mesh scan of raytracer.c:417-435 is pinned.  With checker=True a checkered sphere stands in
+    front of checkered triangles, which exercises the scan's stale hit.u / hit.v (ref_harness.c)."""
+    from rt_amd import abi, scene as S
+    rng = np.random.default_rng(seed)
+
+    def tri(p0, p1, p2):
+        return [tuple(p0) + tuple(rng.random(2)), tuple(p1) + tuple(rng.random(2)), tuple(p2) + tuple(rng.random(2))]
+    tris = []
+    for _ in range(n_tris):
+        c = rng.uniform(-6, 6, 3)
+        tris.append(tri(c + rng.normal(0, 2, 3), c + rng.normal(0, 2, 3), c + rng.normal(0, 2, 3)))
+    if duplicates:
+        tris += [tris[3], tris[7], tris[3]]                 # equal t at different indices: first index wins
+        p = rng.uniform(-3, 3, 3)
+        tris.append(tri(p, p, p + 1.0))                     # two equal vertices
+        tris.append(tri(p, p + 1.0, p + 2.0))               # collinear
+    chk = abi.M_CHECKERED if checker else 0
+    objs = [dict(flags=abi.M_DEFAULT | chk, radius=3.0, center=(0, 0, 4), color=(.8, .7, .6)),
+            dict(flags=abi.M_DEFAULT, radius=1e4, center=(0, -10008, 0), color=(.75, .75, .75)),
+            dict(flags=abi.M_REFLECTION, radius=2.0, center=(-7, 0, 2), color=(1, 1, 1)),
+            dict(flags=abi.M_DEFAULT, radius=2, center=(5, 9, 0), color=(1, 1, 1), emission=(5, 5, 5))]
+    meshes = [dict(flags=abi.M_DEFAULT | chk, color=(.6, .8, .7), triangles=tris[:len(tris) // 2]),
+              dict(flags=abi.M_DEFAULT, color=(.9, .5, .4), triangles=tris[len(tris) // 2:])]
+    return S.custom_scene(objs, width, height, samples, max_depth, (0, 3, 30), (0, 0, 0), meshes=meshes)
+
+
 def decode_png_rgb8(path):
     """minimal PNG reader for 8-bit RGB, non-interlaced, all five filter types -> (h, w, 3) uint8"""
     import struct
