@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per tile (0 = rt_hip_suggest_chunks)")
     ap.add_argument("--shard", type=str, default="", help="dev: render only rank R of a W-way partition, 'R/W', on this one GPU")
     ap.add_argument("--cpu-tiles", type=int, default=384, help="8x8 tiles of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration array")
     args = ap.parse_args()
 
     import torch
@@ -277,7 +278,7 @@ def main():
             "rays_per_sample": rays / max(samples, 1),
             "ray_count_per_step": rays / steps, "ray_bounces_per_step": casts_per_step,
             "intersection_tests_per_s": tests / elapsed,
-            "roofline": {"bound": "valu_fp64", "kernel": "pt_render_tiles", "achieved": achieved_tflops,
+            "roofline": {"bound": "valu_fp64", "kernel": gs.kernel_name(), "achieved": achieved_tflops,
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_TFLOPS,
                          "traffic": measured_traffic(args.config, W, H, spp, world), "flops_per_ray_bounce": fr,
                          "kernel_ms": kern_s * 1e3,

@@ -144,6 +144,9 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
 void rt_hip_scene_destroy(RtHipScene *scene);
 int rt_hip_scene_device(const RtHipScene *scene);
 size_t rt_hip_scene_primitives(const RtHipScene *scene); /* spheres + triangles */
+/* name of the render kernel a launch of this scene takes (the family is picked by scene content:
+ * triangles, table size, M_CHECKERED / M_REFRACTION materials) -- for profiles and bench lines */
+const char *rt_hip_kernel_name(const RtHipScene *scene, uint32_t integrator);
 
 /* ---- the hot path: replaces the loop nest of render() (raytracer.c:184-222) ---- */
 
@@ -179,6 +182,21 @@ int rt_hip_untile(const float *d_tiles_rgb, const uint8_t *d_tiles_rgb8, int32_t
  * through its reciprocal, 2 library sqrt, 3 IEEE division, 4 the fused r*2^-30 - 1 mapping,
  * 5 reciprocal without range scaling (valid for 2^-500 <= a <= 2^500). */
 int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h_out, size_t n, int device);
+
+/* Runs the render kernels' own exact primitive tests (intersect_sphere raytracer.c:77-118,
+ * intersect_triangle :120-174 as the device states them) and their conservative phase-1
+ * filter on host arrays, one GPU lane per case, so that known-answer vectors reach the device
+ * code itself.  kind 0: h_prims = n x 4 (cx cy cz radius); kind 1: h_prims = n x 9 (v0 v1 v2
+ * positions); h_rays = n x 6 (origin, direction).  Case i = ray i against primitive i:
+ * h_hit[i] 0/1 and h_tuv[3i..] = t (DBL_MAX on a miss) and, for triangles, the barycentric
+ * u, v (a texture coordinate is st0 (1-u-v) + st1 u + st2 v, raytracer.c:154-167).
+ * h_keep[3i + f], f = 0..2: 64-bit masks of the filter's three forms (sign tests from LDS --
+ * spheres only, all ones for triangles; compares from LDS; compares by scalar loads) for ray i
+ * against the 64 primitives of its block [64 (i/64), +64): bit j set = primitive 64 (i/64) + j
+ * is kept.  The filter is built for ray origins within near_R (rays beyond keep everything),
+ * as rt_hip_render_tiles builds it per launch.  |centre|, |radius| <= 1e17. */
+int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_prims, size_t n, double near_R,
+                              uint8_t *h_hit, double *h_tuv, uint64_t *h_keep, int device);
 
 /* ---- convenience for C hosts: whole image, host buffers, synchronous ----------- */
 

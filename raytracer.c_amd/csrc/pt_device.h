@@ -10,9 +10,10 @@
  *       normal use; they are staged in LDS per workgroup (scenes beyond the 24 KiB staging
  *       budget read the compact copy geom4 from memory instead).
  *   filt       [ceil(entries/2)] x 5 f32x2       : cx cy cz r2_hi neg_tol, two primitives per
- *       f32x2 -- the packed-fp32 phase-1 filter table, rebuilt per launch (pt_build_filter)
- *       because its thresholds depend on the camera distance; read with wave-uniform
- *       indices, i.e. through scalar loads.
+ *       f32x2 -- the packed-fp32 phase-1 filter table (pt_build_filter).  Its thresholds depend
+ *       on the camera distance (near_R), so the shim keeps one table set per (scene, near_R),
+ *       built once and immutable afterwards; read with wave-uniform indices, i.e. through
+ *       scalar loads.
  *   material   [n_spheres + n_meshes] x 8 f64    : prob, albedo_rr xyz, emission xyz, flags
  *       prob      = MAX(color) (raytracer.c:497)
  *       albedo_rr = color * (1/prob), the albedo after a survived Russian roulette (:500);
@@ -34,7 +35,7 @@
  *       in double 12: an inner child is its node index, a leaf child is
  *       PT_BVH_LEAF_FLAG | first << 3 | count and covers bvh_tri[first .. first+count).  Node 0
  *       is the root; the tree is balanced (median splits), depth <= PT_BVH_STACK.
- *   bvh_nodes  [n_bvh_nodes] x 16 u32/f32 : the per-launch fp32 copy (pt_build_bvh): the six
+ *   bvh_nodes  [n_bvh_nodes] x 16 u32/f32 : the fp32 copy for one near_R (pt_build_bvh): the six
  *       planes as (child 0, child 1) pairs -- min x, max x, min y, max y, min z, max z -- so one
  *       packed-fp32 instruction serves both children; boxes widened by a bound on the fp32
  *       ray/box arithmetic; then the two references.
@@ -62,6 +63,8 @@
 #define PT_FILT_STRIDE 5     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
 #define PT_ENTRY_SRC_STRIDE 6 /* HBM doubles per primitive: cx cy cz R2 |c| Rb (bounding data, fp64) */
 
+#define PT_ACC_WS_WORDS (PT_TILE_PIXELS * 3 + 3) /* chunked renders: u64 per tile in the workspace: 192 sums + 3 NaN masks */
+
 #define PT_REFRACT_MAX_DEPTH 32 /* the pending-ray stack of the two-child kernels holds max_depth + 2 */
 
 #define PT_FLAG_DIFFUSE 2u
@@ -74,7 +77,8 @@ struct PtSceneView
   const double *entry_src; /* n_spheres + n_triangles bounding records, scan order */
   const double *geom4;     /* n_spheres x PT_GEOM_STRIDE: cx cy cz r2, what the exact test reads when the
                             * scene is too large to stage in LDS */
-  float *filt;             /* packed-fp32 filter table, rebuilt per launch by pt_build_filter */
+  float *filt;             /* packed-fp32 filter table for the launch's near_R (pt_build_filter; the shim keeps one
+                            * immutable table set per (scene, near_R)) */
   const double *material;
   const double *color_raw;
   const double *tri_geom;
@@ -134,7 +138,7 @@ struct PtLaunch
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
   uint32_t sample_chunks; /* workgroups per tile: each renders 1/sample_chunks of the samples */
   uint32_t integrator;    /* 0 trace_path (raytracer.c:482-554), 1 cast_ray (:556-641) */
-  unsigned long long *acc_ws;        /* tile_count x 192 fixed-point sums, used when sample_chunks > 1 */
+  unsigned long long *acc_ws;        /* sample_chunks > 1: tile_count x 192 fixed-point sums, then tile_count x 3 NaN masks */
   float *tiles_rgb;
   uint8_t *tiles_rgb8;
   unsigned long long *stats;
@@ -145,7 +149,12 @@ struct PtLaunch
 /* host-side launchers, defined next to the kernels in pt_kernel.hip */
 size_t pt_render_lds_bytes(const PtSceneView &scene);
 hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant);
+hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream);
+const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant);
 hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream);
+hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,
+                                        float *filt, uint32_t n, double near_R, double filt_shift, uint8_t *hit,
+                                        double *tuv, unsigned long long *keep, hipStream_t stream);
 hipError_t pt_launch_untile(const float *tiles_rgb, const uint8_t *tiles_rgb8, int width, int height,
                             uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count, float *image_rgb,
                             uint8_t *image_rgb8, hipStream_t stream);

@@ -232,9 +232,21 @@ __device__ __forceinline__ void exact_sphere(const double *g, uint32_t index, co
  * TIE = false: candidates arrive in increasing index order, strict < keeps the first (the
  * reference's rule).  TIE = true: they arrive in hierarchy order, so an equal t from a LOWER
  * index must still win: the result is then the linear scan's, whatever the visiting order. */
-template <bool TIE = false>
+/* LAST: also remember the highest-index triangle the ray passes at t > EPSILON, closest or not.
+ * intersect_triangle() writes the texture coordinates into the caller's Hit on every such hit
+ * (:165-166), before the scan's `local.t < min_t` test (:426), and the scan never restores them:
+ * after it hit.u / hit.v belong to the LAST passing triangle in scan order (oracle/ref_harness.c
+ * revives the block around the compiled primitives and shows it).  Only M_CHECKERED reads them. */
+struct TriLast
+{
+  int idx; /* scan index (n_sph + triangle) of the last passing triangle, -1: none */
+  double u, v; /* its barycentrics */
+};
+
+template <bool TIE = false, bool LAST = false>
 __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, const V3 &o, const V3 &d,
-                                               double &min_t, int &best, double &bary_u, double &bary_v)
+                                               double &min_t, int &best, double &bary_u, double &bary_v,
+                                               TriLast *last = nullptr)
 {
   V3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
   V3 h = v_cross(d, e2);
@@ -251,6 +263,12 @@ __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, 
       if (!(v < 0.0 || u + v > 1.0))
       {
         double t = f * v_dot(e2, q);
+        if (LAST && t > kEps && (int)index > last->idx)
+        {
+          last->idx = (int)index;
+          last->u = u;
+          last->v = v;
+        }
         if (t > kEps && (t < min_t || (TIE && t == min_t && (int)index < best)))
         {
           min_t = t;
@@ -329,11 +347,15 @@ __device__ __forceinline__ bool bvh_probe(const float *__restrict__ nodes, uint3
  * leaves reached usually hold the closest hit and min_t prunes what lies behind it.  Leaves
  * run the exact fp64 triangle test; with the (t, index) tie rule the outcome does not depend
  * on the visiting order. */
+/* LAST / no_prune: scenes with M_CHECKERED materials and triangles need every triangle the ray
+ * passes, not only those closer than the closest hit so far (TriLast): no pruning by min_t then. */
+template <bool LAST = false>
 __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, uint32_t n_nodes,
                                              const uint32_t *__restrict__ tri_order, const double *tri_geom,
                                              uint32_t n_sph, bool far_origin, const V3 &o, const V3 &d,
                                              double &min_t, int &best, double &bary_u, double &bary_v,
-                                             unsigned long long *diag_ptr)
+                                             unsigned long long *diag_ptr, TriLast *last = nullptr,
+                                             bool no_prune = false)
 {
   __shared__ uint32_t stack[PT_BVH_STACK][PT_BLOCK]; /* entry-major: conflict-free per wave */
   if (n_nodes == 0)
@@ -354,7 +376,8 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
       bool hit0, hit1;
       float tn0, tn1;
       uint32_t r0, r1;
-      bvh_test_children(nodes, ref, R, far_origin, __double2float_ru(min_t), hit0, hit1, tn0, tn1, r0, r1);
+      bvh_test_children(nodes, ref, R, far_origin, (LAST && no_prune) ? 3.4028234663852886e38f : __double2float_ru(min_t),
+                        hit0, hit1, tn0, tn1, r0, r1);
       if (hit0 && hit1)
       {
         const bool zero_first = !(tn1 < tn0);
@@ -379,7 +402,7 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
     {
       DIAG(14, 1);
       const uint32_t t = tri_order[first + k];
-      exact_triangle<true>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v);
+      exact_triangle<true, LAST>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v, last);
     }
     if (sp == 0)
       break;
@@ -414,14 +437,139 @@ __device__ __forceinline__ uint32_t push_keep_bit(uint32_t word, float tca, floa
   return word;
 }
 
-template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true>
+/* the ray as phase 1 of scan_filtered sees it: fp32 (round to nearest: relative error <= 2^-24,
+ * part of the bound), origin pulled back by filt_shift along d in the sign-test form */
+struct FiltRay
+{
+  float ox, oy, oz;
+  f32x2 dx, dy, dz;
+  bool far_origin;
+};
+
+template <bool SHIFT>
+__device__ __forceinline__ FiltRay filter_ray(const V3 &o, const V3 &d, double filt_shift, double near_R2)
+{
+  FiltRay r;
+  r.ox = SHIFT ? (float)(o.x - filt_shift * d.x) : (float)o.x;
+  r.oy = SHIFT ? (float)(o.y - filt_shift * d.y) : (float)o.y;
+  r.oz = SHIFT ? (float)(o.z - filt_shift * d.z) : (float)o.z;
+  r.dx = {(float)d.x, (float)d.x};
+  r.dy = {(float)d.y, (float)d.y};
+  r.dz = {(float)d.z, (float)d.z};
+  r.far_origin = !(v_dot(o, o) <= near_R2); /* also true for NaN */
+  return r;
+}
+
+/* Phase 1 of scan_filtered for one chunk of up to 64 primitives starting at `base` (a multiple
+ * of 64): the conservative packed-fp32 filter, all lanes on the same pair.  Returns the lane's
+ * keep mask (bit k = primitive base + k survives).  The ray arrives in fp32, SHIFTed where the
+ * sign-test form applies (see scan_filtered); far_origin lanes keep everything. */
+template <bool TRIS, bool FILT_LDS>
+__device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uint32_t base, uint32_t chunk, float ox,
+                                             float oy, float oz, f32x2 dx, f32x2 dy, f32x2 dz, bool far_origin,
+                                             uint32_t &cand_lo, uint32_t &cand_hi)
+{
+  constexpr bool SHIFT = FILT_LDS && !TRIS;
+  /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
+  cand_lo = 0;
+  cand_hi = 0;
+  struct PairRec
+  {
+    f32x2 cx, cy, cz, r2_hi, neg_tol;
+  };
+  auto load_pair = [&](uint32_t pair) -> PairRec {
+    const f32x2 *g = filt + PT_FILT_STRIDE * (size_t)((base >> 1) + pair);
+    return {g[0], g[1], g[2], g[3], g[4]};
+  };
+  auto filter_pair = [&](const PairRec &g, uint32_t &word, uint32_t shift) {
+    const f32x2 lx = g.cx - ox, ly = g.cy - oy, lz = g.cz - oz;
+    const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
+    if (SHIFT)
+    {
+      const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, __builtin_elementwise_fma(lx, lx, -g.r2_hi)));
+      const f32x2 q = __builtin_elementwise_fma(tca, tca, -ll);
+      /* pairs arrive in DESCENDING order: shifting sign bits in leaves bit k = primitive k;
+       * a set bit means DROP here, the word is inverted after the loop */
+      word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.y) | __float_as_uint(q.y), 31);
+      word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.x) | __float_as_uint(q.x), 31);
+      return;
+    }
+    const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, lx * lx));
+    const f32x2 d2 = __builtin_elementwise_fma(-tca, tca, ll);
+    if (FILT_LDS)
+    { /* pairs arrive in DESCENDING order, so shifting bits in leaves bit k = primitive k */
+      word = push_keep_bit(word, tca.y, g.neg_tol.y, d2.y, g.r2_hi.y);
+      word = push_keep_bit(word, tca.x, g.neg_tol.x, d2.x, g.r2_hi.x);
+    }
+    else
+    {
+      /* bitwise |: no short-circuit branch.  NaNs compare false and stay candidates. */
+      const bool drop0 = (bool)((int)(tca.x < g.neg_tol.x) | (int)(d2.x > g.r2_hi.x));
+      const bool drop1 = (bool)((int)(tca.y < g.neg_tol.y) | (int)(d2.y > g.r2_hi.y));
+      word |= (drop0 ? 0u : (1u << shift)) | (drop1 ? 0u : (2u << shift));
+    }
+  };
+  const uint32_t n_pairs = (chunk + 1u) >> 1;
+  const uint32_t pairs_lo = min(n_pairs, 16u);
+  if (FILT_LDS)
+  {
+    /* descending pair order (see filter_pair); the LDS reads of the next pair are issued
+     * before the current one computes */
+    /* (unrolled by hand: inline asm is convergent, which rules out runtime unrolling) */
+    auto run_desc = [&](uint32_t top, uint32_t count, uint32_t &word) {
+      uint32_t q = 0;
+      for (; q + 2 <= count; q += 2)
+      {
+        const PairRec a = load_pair(top - q), b = load_pair(top - q - 1u);
+        filter_pair(a, word, 0);
+        filter_pair(b, word, 0);
+      }
+      for (; q < count; q++)
+        filter_pair(load_pair(top - q), word, 0);
+    };
+    run_desc(pairs_lo - 1u, pairs_lo, cand_lo);
+    run_desc(n_pairs - 1u, n_pairs - pairs_lo, cand_hi);
+    if (SHIFT)
+    { /* drop bits -> keep bits */
+      cand_lo = ~cand_lo;
+      cand_hi = ~cand_hi;
+    }
+  }
+  else
+  {
+    /* software pipeline: the scalar loads of pair p+1 are in flight while pair p computes
+     * (the table is padded to a whole number of pairs, and one pair past the end) */
+    PairRec cur = load_pair(0);
+#pragma unroll 2
+    for (uint32_t p = 0; p < pairs_lo; p++)
+    {
+      const PairRec nxt = load_pair(p + 1);
+      filter_pair(cur, cand_lo, 2u * p);
+      cur = nxt;
+    }
+#pragma unroll 2
+    for (uint32_t p = 16; p < n_pairs; p++)
+    {
+      const PairRec nxt = load_pair(p + 1);
+      filter_pair(cur, cand_hi, 2u * (p - 16u));
+      cur = nxt;
+    }
+  }
+  /* entries that exist in this chunk (an odd count leaves one padding slot) */
+  const uint32_t valid_lo = chunk >= 32u ? 0xFFFFFFFFu : ((1u << chunk) - 1u);
+  const uint32_t valid_hi = chunk >= 64u ? 0xFFFFFFFFu : (chunk > 32u ? ((1u << (chunk - 32u)) - 1u) : 0u);
+  cand_lo = far_origin ? valid_lo : (cand_lo & valid_lo);
+  cand_hi = far_origin ? valid_hi : (cand_hi & valid_hi);
+}
+
+template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true, bool LAST = false>
 __device__ __forceinline__ void scan_filtered(const double *geom, const double *tri_geom,
                                               const f32x2 *__restrict__ filt, double near_R2, uint32_t n_sph,
                                               uint32_t n_entries, const V3 &o, const V3 &d, double &min_t,
                                               int &best, double &bary_u, double &bary_v,
                                               unsigned long long *diag_ptr, const float *bvh_nodes = nullptr,
                                               uint32_t n_bvh_nodes = 0, const uint32_t *bvh_tri = nullptr,
-                                              double filt_shift = 0.0)
+                                              double filt_shift = 0.0, TriLast *last = nullptr, bool no_prune = false)
 {
   /* with a hierarchy the flat filter covers the spheres only */
   if (BVH)
@@ -441,105 +589,17 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
    * non-finite d hit nothing in the exact test either, and scenes whose centres or radii are
    * outside fp32's comfortable range never use this form (pt_filter_in_lds). */
   constexpr bool SHIFT = FILT_LDS && !TRIS;
-  /* the ray in fp32 (round to nearest: relative error <= 2^-24, part of the bound) */
-  const float ox = SHIFT ? (float)(o.x - filt_shift * d.x) : (float)o.x;
-  const float oy = SHIFT ? (float)(o.y - filt_shift * d.y) : (float)o.y;
-  const float oz = SHIFT ? (float)(o.z - filt_shift * d.z) : (float)o.z;
-  const f32x2 dx = {(float)d.x, (float)d.x}, dy = {(float)d.y, (float)d.y}, dz = {(float)d.z, (float)d.z};
-  const bool far_origin = !(v_dot(o, o) <= near_R2); /* also true for NaN */
+  const FiltRay fr = filter_ray<SHIFT>(o, d, filt_shift, near_R2);
+  const float ox = fr.ox, oy = fr.oy, oz = fr.oz;
+  const f32x2 dx = fr.dx, dy = fr.dy, dz = fr.dz;
+  const bool far_origin = fr.far_origin;
 
   for (uint32_t base = 0; base < n_entries; base += 64)
   {
     const uint32_t chunk = min(64u, n_entries - base);
     /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
-    uint32_t cand_lo = 0, cand_hi = 0;
-    struct PairRec
-    {
-      f32x2 cx, cy, cz, r2_hi, neg_tol;
-    };
-    auto load_pair = [&](uint32_t pair) -> PairRec {
-      const f32x2 *g = filt + PT_FILT_STRIDE * (size_t)((base >> 1) + pair);
-      return {g[0], g[1], g[2], g[3], g[4]};
-    };
-    auto filter_pair = [&](const PairRec &g, uint32_t &word, uint32_t shift) {
-      const f32x2 lx = g.cx - ox, ly = g.cy - oy, lz = g.cz - oz;
-      const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
-      if (SHIFT)
-      {
-        const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, __builtin_elementwise_fma(lx, lx, -g.r2_hi)));
-        const f32x2 q = __builtin_elementwise_fma(tca, tca, -ll);
-        /* pairs arrive in DESCENDING order: shifting sign bits in leaves bit k = primitive k;
-         * a set bit means DROP here, the word is inverted after the loop */
-        word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.y) | __float_as_uint(q.y), 31);
-        word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.x) | __float_as_uint(q.x), 31);
-        return;
-      }
-      const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, lx * lx));
-      const f32x2 d2 = __builtin_elementwise_fma(-tca, tca, ll);
-      if (FILT_LDS)
-      { /* pairs arrive in DESCENDING order, so shifting bits in leaves bit k = primitive k */
-        word = push_keep_bit(word, tca.y, g.neg_tol.y, d2.y, g.r2_hi.y);
-        word = push_keep_bit(word, tca.x, g.neg_tol.x, d2.x, g.r2_hi.x);
-      }
-      else
-      {
-        /* bitwise |: no short-circuit branch.  NaNs compare false and stay candidates. */
-        const bool drop0 = (bool)((int)(tca.x < g.neg_tol.x) | (int)(d2.x > g.r2_hi.x));
-        const bool drop1 = (bool)((int)(tca.y < g.neg_tol.y) | (int)(d2.y > g.r2_hi.y));
-        word |= (drop0 ? 0u : (1u << shift)) | (drop1 ? 0u : (2u << shift));
-      }
-    };
-    const uint32_t n_pairs = (chunk + 1u) >> 1;
-    const uint32_t pairs_lo = min(n_pairs, 16u);
-    if (FILT_LDS)
-    {
-      /* descending pair order (see filter_pair); the LDS reads of the next pair are issued
-       * before the current one computes */
-      /* (unrolled by hand: inline asm is convergent, which rules out runtime unrolling) */
-      auto run_desc = [&](uint32_t top, uint32_t count, uint32_t &word) {
-        uint32_t q = 0;
-        for (; q + 2 <= count; q += 2)
-        {
-          const PairRec a = load_pair(top - q), b = load_pair(top - q - 1u);
-          filter_pair(a, word, 0);
-          filter_pair(b, word, 0);
-        }
-        for (; q < count; q++)
-          filter_pair(load_pair(top - q), word, 0);
-      };
-      run_desc(pairs_lo - 1u, pairs_lo, cand_lo);
-      run_desc(n_pairs - 1u, n_pairs - pairs_lo, cand_hi);
-      if (SHIFT)
-      { /* drop bits -> keep bits */
-        cand_lo = ~cand_lo;
-        cand_hi = ~cand_hi;
-      }
-    }
-    else
-    {
-      /* software pipeline: the scalar loads of pair p+1 are in flight while pair p computes
-       * (the table is padded to a whole number of pairs, and one pair past the end) */
-      PairRec cur = load_pair(0);
-#pragma unroll 2
-      for (uint32_t p = 0; p < pairs_lo; p++)
-      {
-        const PairRec nxt = load_pair(p + 1);
-        filter_pair(cur, cand_lo, 2u * p);
-        cur = nxt;
-      }
-#pragma unroll 2
-      for (uint32_t p = 16; p < n_pairs; p++)
-      {
-        const PairRec nxt = load_pair(p + 1);
-        filter_pair(cur, cand_hi, 2u * (p - 16u));
-        cur = nxt;
-      }
-    }
-    /* entries that exist in this chunk (an odd count leaves one padding slot) */
-    const uint32_t valid_lo = chunk >= 32u ? 0xFFFFFFFFu : ((1u << chunk) - 1u);
-    const uint32_t valid_hi = chunk >= 64u ? 0xFFFFFFFFu : (chunk > 32u ? ((1u << (chunk - 32u)) - 1u) : 0u);
-    cand_lo = far_origin ? valid_lo : (cand_lo & valid_lo);
-    cand_hi = far_origin ? valid_hi : (cand_hi & valid_hi);
+    uint32_t cand_lo, cand_hi;
+    filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, ox, oy, oz, dx, dy, dz, far_origin, cand_lo, cand_hi);
 #ifdef PT_DIAG
     {
       /* exactness check of the filter: any primitive it dropped that the exact test accepts? */
@@ -581,12 +641,12 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       if (!TRIS || BVH || i < n_sph)
         exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
       else
-        exact_triangle(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v);
+        exact_triangle<false, LAST>(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v, last);
     }
   }
   if (BVH && WALK) /* WALK = false: the caller walks the hierarchy itself, later (render_tiles_pooled) */
-    bvh_traverse(bvh_nodes, n_bvh_nodes, bvh_tri, tri_geom, n_sph, far_origin, o, d, min_t, best, bary_u, bary_v,
-                 diag_ptr);
+    bvh_traverse<LAST>(bvh_nodes, n_bvh_nodes, bvh_tri, tri_geom, n_sph, far_origin, o, d, min_t, best, bary_u, bary_v,
+                       diag_ptr, last, no_prune);
 }
 
 /* ---- scene as staged in LDS ------------------------------------------------------------ */
@@ -610,6 +670,7 @@ struct SceneCtx
   double bg, t_start;     /* BACKGROUND's component and DBL_MAX, from the launch arguments (SGPR pairs) */
   uint32_t n_sph, n_tri;
   int max_depth;
+  bool stale_uv;          /* M_CHECKERED materials AND triangles: hit.u / hit.v follow the TriLast rule */
 };
 
 /* GEOM_LDS: sphere geometry and materials are staged in LDS (the pointers are LDS pointers at
@@ -679,6 +740,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.n_sph = n_sph;
   ctx.n_tri = sc.n_triangles;
   ctx.max_depth = L.max_depth;
+  ctx.stale_uv = sc.any_checker != 0 && sc.n_triangles != 0;
   return ctx;
 }
 
@@ -806,6 +868,7 @@ struct HitRec
   bool need_dir;
   uint32_t dir_slot;
   double dir_scale;
+  TriLast last; /* kernels with M_CHECKERED code and triangles only */
 };
 
 /* MODE 0: the whole call.  MODE 1: the first half only -- depth test, the flat scan WITHOUT the
@@ -830,6 +893,9 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
     H.best = -1;
     H.bary_u = 0;
     H.bary_v = 0;
+    H.last.idx = -1;
+    H.last.u = 0;
+    H.last.v = 0;
     if (H.depth_ok)
     {
       n_casts++;
@@ -840,17 +906,18 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         for (uint32_t i = 0; i < S.n_sph; i++)
           exact_sphere(S.geom + PT_GEOM_STRIDE * i, i, o, d, H.min_t, H.best);
         for (uint32_t i = 0; i < S.n_tri; i++)
-          exact_triangle(S.tri + 9 * (size_t)i, S.n_sph + i, o, d, H.min_t, H.best, H.bary_u, H.bary_v);
+          exact_triangle<false, CHECKER && TRIS>(S.tri + 9 * (size_t)i, S.n_sph + i, o, d, H.min_t, H.best, H.bary_u, H.bary_v,
+                                                 &H.last);
       }
       else
-        scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0>(
+        scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0, CHECKER && TRIS>(
             S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o, d, H.min_t, H.best,
-            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift);
+            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv);
     }
     if (MODE == 1)
       return false;
   }
-  const double min_t = H.min_t, bary_u = H.bary_u, bary_v = H.bary_v;
+  const double min_t = H.min_t;
   const int best = H.best;
 
   if (H.depth_ok)
@@ -896,7 +963,10 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         bool dir_deferred = false;
         if (CHECKER && (flags & PT_FLAG_CHECKER))
         {
-          if (!is_tri)
+          /* hit.u / hit.v as the scan leaves them: the LAST passing triangle's if the ray passes
+           * any triangle (TriLast; a winning triangle passes, so it is covered), else the closest
+           * sphere's (:410-411) */
+          if (!(TRIS && H.last.idx >= 0))
           {
             tex_u = atan2(n.x, n.z) / (2 * kPi) + 0.5; /* :410-411 */
             tex_v = n.y * 0.5 + 0.5;
@@ -904,10 +974,11 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           else
           {
             /* :154-167 barycentric blend of the texture coordinates */
-            const double *tx = S.tri_tex + 6 * (size_t)((uint32_t)best - S.n_sph);
-            double w0 = 1 - bary_u - bary_v;
-            tex_u = (tx[0] * w0 + tx[2] * bary_u) + tx[4] * bary_v;
-            tex_v = (tx[1] * w0 + tx[3] * bary_u) + tx[5] * bary_v;
+            const double *tx = S.tri_tex + 6 * (size_t)((uint32_t)H.last.idx - S.n_sph);
+            const double lu = H.last.u, lv = H.last.v;
+            double w0 = 1 - lu - lv;
+            tex_u = (tx[0] * w0 + tx[2] * lu) + tx[4] * lv;
+            tex_v = (tx[1] * w0 + tx[3] * lu) + tx[5] * lv;
           }
           /* checkered_texture :386-391, M = 100000 (:508) */
           double on = (double)((fmod(tex_u * 100000.0, 1.0) > 0.5) ^ (fmod(tex_v * 100000.0, 1.0) < 0.5));
@@ -1033,9 +1104,11 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
     double min_t = S.t_start;
     int best = -1;
     double bary_u = 0, bary_v = 0;
-    scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
-                                                     S.n_sph + S.n_tri, o, d, min_t, best, bary_u, bary_v, diag_ptr,
-                                                     S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift);
+    TriLast last = {-1, 0, 0}; /* hit.u / hit.v of the scan: the last passing triangle's (TriLast) */
+    scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, true, TRIS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2,
+                                                                 S.n_sph, S.n_sph + S.n_tri, o, d, min_t, best, bary_u,
+                                                                 bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri,
+                                                                 S.filt_shift, &last, S.stale_uv);
     if (best >= 0)
     {
       const V3 p = v_add(o, v_scale(d, min_t));
@@ -1071,17 +1144,17 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
       if (flags & PT_FLAG_CHECKER)
       {
         double tex_u, tex_v;
-        if (!is_tri)
+        if (!(TRIS && last.idx >= 0))
         {
           tex_u = atan2(n.x, n.z) / (2 * kPi) + 0.5; /* :410-411 */
           tex_v = n.y * 0.5 + 0.5;
         }
         else
         {
-          const double *tx = S.tri_tex + 6 * (size_t)((uint32_t)best - S.n_sph);
-          const double w0 = 1 - bary_u - bary_v;
-          tex_u = (tx[0] * w0 + tx[2] * bary_u) + tx[4] * bary_v;
-          tex_v = (tx[1] * w0 + tx[3] * bary_u) + tx[5] * bary_v;
+          const double *tx = S.tri_tex + 6 * (size_t)((uint32_t)last.idx - S.n_sph);
+          const double w0 = 1 - last.u - last.v;
+          tex_u = (tx[0] * w0 + tx[2] * last.u) + tx[4] * last.v;
+          tex_v = (tx[1] * w0 + tx[3] * last.u) + tx[5] * last.v;
         }
         /* checkered_texture :386-391 with M = 10 (:583) */
         const double on = (double)((fmod(tex_u * 10.0, 1.0) > 0.5) ^ (fmod(tex_v * 10.0, 1.0) < 0.5));
@@ -1163,8 +1236,14 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
 
 /* per-pixel mean (raytracer.c:215) and gamma-5 tonemap (:218-220) of one tile from its
  * fixed-point sums; thread t < 64 handles pixel t */
-__device__ __forceinline__ void finish_pixels(const PtLaunch &L, const unsigned long long *sums, uint32_t tile,
-                                              float *out_f, uint8_t *out_b)
+/* nan_mask[c]: bit t set = channel c of pixel t received a NaN sample.  The reference's fp64 sum
+ * carries a NaN to the pixel (raytracer.c:212-215) and CLAMP(NaN) = 1 stores byte 255 (:218); an
+ * integer sum cannot, so the pooled kernels flag such samples apart and the pixel becomes NaN
+ * here.  (Samples are otherwise finite and within the scale's bound: emission is finite and the
+ * throughput at most 1, rt_hip_render_tiles_chunked.) */
+__device__ __forceinline__ void finish_pixels(const PtLaunch &L, const unsigned long long *sums,
+                                              const unsigned long long *nan_mask, uint32_t tile, float *out_f,
+                                              uint8_t *out_b)
 {
   if (threadIdx.x < PT_TILE_PIXELS)
   {
@@ -1176,6 +1255,10 @@ __device__ __forceinline__ void finish_pixels(const PtLaunch &L, const unsigned 
     mean.x = ((double)(long long)sums[3 * t + 0] * L.acc_inv_scale) * inv_s;
     mean.y = ((double)(long long)sums[3 * t + 1] * L.acc_inv_scale) * inv_s;
     mean.z = ((double)(long long)sums[3 * t + 2] * L.acc_inv_scale) * inv_s;
+    const double quiet_nan = __longlong_as_double(0x7FF8000000000000ll);
+    mean.x = ((nan_mask[0] >> t) & 1ull) ? quiet_nan : mean.x;
+    mean.y = ((nan_mask[1] >> t) & 1ull) ? quiet_nan : mean.y;
+    mean.z = ((nan_mask[2] >> t) & 1ull) ? quiet_nan : mean.z;
     out_f[3 * t + 0] = inside ? (float)mean.x : 0.f;
     out_f[3 * t + 1] = inside ? (float)mean.y : 0.f;
     out_f[3 * t + 2] = inside ? (float)mean.z : 0.f;
@@ -1249,6 +1332,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
   __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3]; /* fixed-point radiance sums */
+  __shared__ unsigned long long pix_nan[3];                  /* per channel: pixels that received a NaN sample */
   __shared__ unsigned long long pix_key[PT_TILE_PIXELS];     /* per-pixel half of the RNG key */
   /* per-wave queue of prepared camera samples: direction, RNG state, pixel slot (64 entries) */
   __shared__ double q_dir[PT_BLOCK / 64][3 * 64];
@@ -1258,6 +1342,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   const SceneCtx S = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
+  if (threadIdx.x < 3)
+    pix_nan[threadIdx.x] = 0;
   if (threadIdx.x < PT_TILE_PIXELS * 3)
     pix_sum[threadIdx.x] = 0;
   if (threadIdx.x < PT_TILE_PIXELS)
@@ -1305,6 +1391,9 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   hit.need_dir = false;
   hit.dir_slot = 0;
   hit.dir_scale = 1.0;
+  hit.last.idx = -1;
+  hit.last.u = 0;
+  hit.last.v = 0;
   bool mesh_wait = false;
   uint32_t trip = 0, wait_since = 0xFFFFFFFFu; /* wave-uniform */
   uint32_t next_job = 0;     /* jobs handed out so far (wave-uniform) */
@@ -1405,7 +1494,9 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         n_rays++;
         (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
         const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
-        mesh_wait = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d, hit.min_t);
+        /* stale_uv: every triangle the ray passes matters, not only those closer than min_t (TriLast) */
+        mesh_wait = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
+                                              (CHECKER && S.stale_uv) ? S.t_start : hit.min_t);
       }
       const uint32_t n_wait = (uint32_t)__popcll(__ballot(busy && mesh_wait));
       const uint32_t n_go = (uint32_t)__popcll(__ballot(busy && !mesh_wait));
@@ -1417,8 +1508,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         if (busy && mesh_wait)
         {
           const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
-          bvh_traverse(S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.tri, S.n_sph, far_origin, P.o, P.d, hit.min_t, hit.best,
-                       hit.bary_u, hit.bary_v, diag_ptr);
+          bvh_traverse<CHECKER>(S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.tri, S.n_sph, far_origin, P.o, P.d, hit.min_t,
+                                hit.best, hit.bary_u, hit.bary_v, diag_ptr, &hit.last, S.stale_uv);
           mesh_wait = false;
         }
         wait_since = 0xFFFFFFFFu;
@@ -1475,6 +1566,13 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         atomicAdd(&pix_sum[3 * pix_slot + 0], (unsigned long long)__double2ll_rn(P.Ls.x * L.acc_scale));
         atomicAdd(&pix_sum[3 * pix_slot + 1], (unsigned long long)__double2ll_rn(P.Ls.y * L.acc_scale));
         atomicAdd(&pix_sum[3 * pix_slot + 2], (unsigned long long)__double2ll_rn(P.Ls.z * L.acc_scale));
+        /* a NaN sample (a ray through a degenerate normal, say) has no integer: flag the pixel, see finish_pixels */
+        if ((int)(P.Ls.x != P.Ls.x) | (int)(P.Ls.y != P.Ls.y) | (int)(P.Ls.z != P.Ls.z))
+        {
+          if (P.Ls.x != P.Ls.x) atomicOr(&pix_nan[0], 1ull << pix_slot);
+          if (P.Ls.y != P.Ls.y) atomicOr(&pix_nan[1], 1ull << pix_slot);
+          if (P.Ls.z != P.Ls.z) atomicOr(&pix_nan[2], 1ull << pix_slot);
+        }
         busy = false;
       }
     }
@@ -1489,7 +1587,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 
   if (L.sample_chunks == 1)
   {
-    finish_pixels(L, pix_sum, tile, out_f, out_b);
+    finish_pixels(L, pix_sum, pix_nan, tile, out_f, out_b);
     __syncthreads();
     store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, true, true);
   }
@@ -1499,6 +1597,9 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
      * HBM (integer atomics: exact, order-independent); pt_resolve_tiles finishes the pixels */
     if (threadIdx.x < PT_TILE_PIXELS * 3 && pix_sum[threadIdx.x] != 0)
       atomicAdd(&L.acc_ws[(size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x], pix_sum[threadIdx.x]);
+    /* the NaN flags follow the sums of all tiles in the workspace */
+    if (threadIdx.x < 3 && pix_nan[threadIdx.x] != 0)
+      atomicOr(&L.acc_ws[(size_t)L.tile_count * (PT_TILE_PIXELS * 3) + (size_t)slot * 3 + threadIdx.x], pix_nan[threadIdx.x]);
     store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, false, chunk == 0);
   }
 }
@@ -1668,7 +1769,8 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const Pt
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   const uint32_t slot = blockIdx.x;
   const uint32_t tile = L.tile_first + slot * L.tile_stride;
-  finish_pixels(L, L.acc_ws + (size_t)slot * (PT_TILE_PIXELS * 3), tile, out_f, out_b);
+  finish_pixels(L, L.acc_ws + (size_t)slot * (PT_TILE_PIXELS * 3),
+                L.acc_ws + (size_t)L.tile_count * (PT_TILE_PIXELS * 3) + (size_t)slot * 3, tile, out_f, out_b);
   __syncthreads();
   if (threadIdx.x < PT_TILE_PIXELS * 3)
     L.tiles_rgb[(size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x] = out_f[threadIdx.x];
@@ -1700,6 +1802,71 @@ extern "C" __global__ __launch_bounds__(256) void pt_selftest_math(int op, const
     else if (op == 5)
       r = rcp_unscaled(a[i]);
     out[i] = r;
+  }
+}
+
+/* Self-test hook (rt_hip_selftest_intersect): the kernel's own exact primitive tests and its
+ * phase-1 filter on caller data, one lane per case, so that known-answer vectors generated by
+ * the compiled reference (tests/golden/primitives.npz) reach exact_sphere / exact_triangle /
+ * filter_chunk themselves and not only their host twins.
+ *   kind 0: prims = n x 4 (cx cy cz r*r), the record exact_sphere reads in the render kernels;
+ *   kind 1: prims = n x 9 (v0, e1, e2), the record exact_triangle reads.
+ * Case i = ray i against primitive i: hit[i], tuv[3i..] = t, and for triangles the barycentric
+ * u, v the render kernels blend texture coordinates with.
+ * Filter: one workgroup (one wavefront) per block of 64 cases; `filt` is the table
+ * pt_build_filter made of all n primitives for near_R, so block b's pairs are those of the 64
+ * primitives of the block.  Every lane runs phase 1 over them with its own ray, in the three
+ * forms the render kernels use, and stores the 64-bit keep masks:
+ *   keep[3i + 0]  sign-test form from LDS (pt_render_tiles; spheres only, all ones for kind 1)
+ *   keep[3i + 1]  compare form from LDS, push_keep_bit (pt_render_tiles_tri)
+ *   keep[3i + 2]  compare form, table by scalar loads (the _big kernels)
+ * bit j = ray i keeps primitive 64 b + j.  A test can so check 64 n (ray, primitive) pairs:
+ * the filter must keep every pair the exact test accepts. */
+extern "C" __global__ __launch_bounds__(64) void pt_selftest_intersect(int kind, const double *rays, const double *prims,
+                                                                      const f32x2 *filt, uint32_t n, double near_R2,
+                                                                      double filt_shift, double t_start, uint8_t *hit,
+                                                                      double *tuv, unsigned long long *keep)
+{
+  __shared__ f32x2 filt_lds[PT_FILT_STRIDE * 33]; /* 32 pairs + the look-ahead pair */
+  const uint32_t base = blockIdx.x * 64u;
+  const uint32_t chunk = min(64u, n - base);
+  for (uint32_t k = threadIdx.x; k < PT_FILT_STRIDE * 33; k += 64)
+    filt_lds[k] = filt[PT_FILT_STRIDE * (size_t)(base >> 1) + k];
+  __syncthreads();
+  const uint32_t i = base + threadIdx.x;
+  const bool live = i < n;
+  const uint32_t src = live ? i : base; /* idle lanes of the last block shadow its first case */
+  const V3 o = ld3(rays + 6 * (size_t)src), d = ld3(rays + 6 * (size_t)src + 3);
+
+  double min_t = t_start, bu = 0, bv = 0;
+  int best = -1;
+  if (kind == 0)
+    exact_sphere(prims + 4 * (size_t)src, 0u, o, d, min_t, best);
+  else
+    exact_triangle(prims + 9 * (size_t)src, 0u, o, d, min_t, best, bu, bv);
+
+  uint32_t lo, hi;
+  unsigned long long m0 = ~0ull, m1, m2;
+  if (kind == 0)
+  {
+    const FiltRay fs = filter_ray<true>(o, d, filt_shift, near_R2);
+    filter_chunk<false, true>(filt_lds, 0u, chunk, fs.ox, fs.oy, fs.oz, fs.dx, fs.dy, fs.dz, fs.far_origin, lo, hi);
+    m0 = ((unsigned long long)hi << 32) | lo;
+  }
+  const FiltRay fr = filter_ray<false>(o, d, filt_shift, near_R2);
+  filter_chunk<true, true>(filt_lds, 0u, chunk, fr.ox, fr.oy, fr.oz, fr.dx, fr.dy, fr.dz, fr.far_origin, lo, hi);
+  m1 = ((unsigned long long)hi << 32) | lo;
+  filter_chunk<false, false>(filt, base, chunk, fr.ox, fr.oy, fr.oz, fr.dx, fr.dy, fr.dz, fr.far_origin, lo, hi);
+  m2 = ((unsigned long long)hi << 32) | lo;
+  if (live)
+  {
+    hit[i] = best >= 0 ? 1 : 0;
+    tuv[3 * (size_t)i + 0] = min_t;
+    tuv[3 * (size_t)i + 1] = bu;
+    tuv[3 * (size_t)i + 2] = bv;
+    keep[3 * (size_t)i + 0] = m0;
+    keep[3 * (size_t)i + 1] = m1;
+    keep[3 * (size_t)i + 2] = m2;
   }
 }
 
@@ -1824,40 +1991,70 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
   return doubles * sizeof(double);
 }
 
+/* which member of the kernel family a launch of this scene takes (the selection of
+ * pt_launch_render, also reported by rt_hip_kernel_name for profiles and bench lines) */
+static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name)
+{
+  static const char *const names[19] = {
+      "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
+      "pt_render_tiles_chk",  "pt_render_tiles_big_chk",  "pt_render_tiles_tri_chk",  "pt_render_tiles_tri_big_chk",
+      "pt_render_tiles_refr", "pt_render_tiles_big_refr", "pt_render_tiles_tri_refr", "pt_render_tiles_tri_big_refr",
+      "pt_render_tiles_v0",   "pt_whitted_tiles",         "pt_whitted_tiles_big",     "pt_whitted_tiles_tri",
+      "pt_whitted_tiles_tri_big", "pt_render_tiles_mem",  "pt_whitted_tiles_mem"};
+  const bool tris = scene.n_triangles != 0;
+  const bool big = !pt_filter_in_lds(scene);
+  const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
+  const bool cast_ray = integrator == 1;
+  int which = cast_ray ? 13 + (tris ? 2 : 0) + (big ? 1 : 0) : (refr ? 8 : (chk ? 4 : 0)) + (tris ? 2 : 0) + (big ? 1 : 0);
+  /* too large to stage, or cast_ray with two-child materials: the two general kernels */
+  const bool in_memory = !pt_geom_in_lds(scene) || (cast_ray && scene.any_mirror_glass);
+  if (in_memory)
+    which = cast_ray ? 18 : 17;
+  else if (variant == 0 && !refr && !cast_ray)
+    which = 12;
+  if (name)
+    *name = names[which];
+  return which;
+}
+
+const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant)
+{
+  const char *name = nullptr;
+  (void)pt_pick_kernel(scene, integrator, variant, &name);
+  return name;
+}
+
+/* The camera-dependent tables of a scene for one near_R (two ~2 us kernels): the packed-fp32
+ * filter table and the fp32 hierarchy nodes.  The shim keeps them per (scene, near_R) and builds
+ * them once (rt_hip_shim.hip, TableSet), never while a render that reads them can be in flight. */
+hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream)
+{
+  const uint32_t n_nodes = scene.n_bvh_nodes;
+  /* every primitive gets a filter entry: small-scene kernels scan triangles through the flat
+   * filter, the others read the sphere part only and walk the hierarchy for the triangles */
+  const uint32_t n_entries = scene.n_spheres + scene.n_triangles;
+  const uint32_t blocks = n_entries ? min(1024u, (n_entries + 255u) / 256u) : 0u;
+  if (blocks)
+    hipLaunchKernelGGL(pt_build_filter, dim3(blocks), dim3(256), 0, stream, scene.entry_src, n_entries, near_R, filt);
+  if (n_nodes)
+    hipLaunchKernelGGL(pt_build_bvh, dim3(min(1024u, (n_nodes + 255u) / 256u)), dim3(256), 0, stream, scene.bvh_src,
+                       n_nodes, near_R, bvh_nodes);
+  return hipGetLastError();
+}
+
 hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant)
 {
   const size_t lds_bytes = pt_render_lds_bytes(launch.scene);
-  {
-    /* the filter table for this camera: a ~2 us kernel ahead of the render on the same stream */
-    const uint32_t n_nodes = launch.scene.n_bvh_nodes;
-    /* every primitive gets a filter entry: small-scene kernels scan triangles through the flat
-     * filter, the others read the sphere part only and walk the hierarchy for the triangles */
-    const uint32_t n_entries = launch.scene.n_spheres + launch.scene.n_triangles;
-    const uint32_t blocks = n_entries ? min(1024u, (n_entries + 255u) / 256u) : 0u;
-    if (blocks)
-      hipLaunchKernelGGL(pt_build_filter, dim3(blocks), dim3(256), 0, stream, launch.scene.entry_src, n_entries,
-                         launch.near_R, launch.scene.filt);
-    if (n_nodes)
-      hipLaunchKernelGGL(pt_build_bvh, dim3(min(1024u, (n_nodes + 255u) / 256u)), dim3(256), 0, stream,
-                         launch.scene.bvh_src, n_nodes, launch.near_R, launch.scene.bvh_nodes);
-  }
-  const bool tris = launch.scene.n_triangles != 0;
-  const bool big = !pt_filter_in_lds(launch.scene);
-  const bool refr = launch.scene.any_refract != 0, chk = launch.scene.any_checker != 0;
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[12] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
+  static const Kernel family[19] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
-                                    pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr};
-  static const Kernel whitted[4] = {pt_whitted_tiles, pt_whitted_tiles_big, pt_whitted_tiles_tri, pt_whitted_tiles_tri_big};
-  const bool cast_ray = launch.integrator == 1;
-  const int which = cast_ray ? 13 + (tris ? 2 : 0) + (big ? 1 : 0) : (refr ? 8 : (chk ? 4 : 0)) + (tris ? 2 : 0) + (big ? 1 : 0);
-  /* too large to stage, or cast_ray with two-child materials: the two general kernels */
-  const bool in_memory = !pt_geom_in_lds(launch.scene) || (launch.integrator == 1 && launch.scene.any_mirror_glass);
-  const bool plain = variant == 0 && !refr && !cast_ray && !in_memory;
-  const Kernel kernel = in_memory ? (cast_ray ? pt_whitted_tiles_mem : pt_render_tiles_mem)
-                                  : (plain ? pt_render_tiles_v0 : (cast_ray ? whitted[which - 13] : family[which]));
-  static size_t lds_allowed[17] = {0}; /* raised once per process if a scene needs > 64 KiB */
-  size_t &allowed = lds_allowed[plain ? 12 : which];
+                                    pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr,
+                                    pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
+                                    pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem};
+  const int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr);
+  const Kernel kernel = family[which];
+  static size_t lds_allowed[19] = {0}; /* raised once per process if a scene needs > 64 KiB */
+  size_t &allowed = lds_allowed[which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -1868,13 +2065,26 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }
   if (launch.sample_chunks > 1)
   {
-    hipError_t e = hipMemsetAsync(launch.acc_ws, 0, (size_t)launch.tile_count * PT_TILE_PIXELS * 3 * sizeof(unsigned long long), stream);
+    hipError_t e = hipMemsetAsync(launch.acc_ws, 0, (size_t)launch.tile_count * PT_ACC_WS_WORDS * sizeof(unsigned long long), stream);
     if (e != hipSuccess)
       return e;
   }
   hipLaunchKernelGGL(kernel, dim3(launch.tile_count * launch.sample_chunks), dim3(PT_BLOCK), lds_bytes, stream, launch);
   if (launch.sample_chunks > 1)
     hipLaunchKernelGGL(pt_resolve_tiles, dim3(launch.tile_count), dim3(PT_BLOCK), 0, stream, launch);
+  return hipGetLastError();
+}
+
+hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,
+                                        float *filt, uint32_t n, double near_R, double filt_shift, uint8_t *hit,
+                                        double *tuv, unsigned long long *keep, hipStream_t stream)
+{
+  if (n == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(pt_build_filter, dim3(min(1024u, (n + 255u) / 256u)), dim3(256), 0, stream, entry_src, n, near_R, filt);
+  hipLaunchKernelGGL(pt_selftest_intersect, dim3((n + 63u) / 64u), dim3(64), 0, stream, kind, rays, prims,
+                     reinterpret_cast<const f32x2 *>(filt), n, near_R * near_R, filt_shift, 1.7976931348623157e308, hit,
+                     tuv, keep);
   return hipGetLastError();
 }
 

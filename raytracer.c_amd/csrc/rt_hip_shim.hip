@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -25,10 +26,31 @@ static_assert(sizeof(RtHipVertex) == 40, "RtHipVertex must match the reference V
 static_assert(sizeof(RtHipCamera) == 96, "RtHipCamera must match the reference Camera");
 static_assert(RT_HIP_TILE == PT_TILE && RT_HIP_TILE_PIXELS == PT_TILE_PIXELS, "tile shape");
 
+/* The camera-dependent tables of a scene (packed-fp32 filter table, fp32 hierarchy nodes; both
+ * depend on near_R, i.e. on the camera's distance) for one near_R.  Built once on the stream of
+ * the first launch that needs them and immutable afterwards, so launches of one scene with
+ * different cameras on different streams or threads never write a table another launch reads;
+ * later launches on other streams wait on `built`.  A scene keeps up to RT_TABLE_SETS of them;
+ * beyond that the least recently used one is recycled after its last reader (`last_use`) is done. */
+struct TableSet
+{
+  double near_R = 0;
+  float *filt = nullptr, *bvh_nodes = nullptr;
+  hipEvent_t built = nullptr, last_use = nullptr;
+  uint64_t stamp = 0;
+  int users = 0;      /* launches between acquire_tables() and release_tables(): not recyclable */
+  bool owned = false; /* allocated apart from the scene blob */
+};
+#define RT_TABLE_SETS 8
+
 struct RtHipScene
 {
   int device = 0;
-  PtSceneView view{};
+  PtSceneView view{}; /* view.filt / view.bvh_nodes: storage of table set 0, inside the blob */
+  mutable std::mutex table_mutex;
+  mutable std::vector<TableSet> tables;
+  mutable uint64_t table_clock = 0;
+  size_t filt_bytes = 0, bvh_nodes_bytes = 0;
   void *blob = nullptr; /* one device allocation holding every array */
   double reach = 0;     /* >= |p| for every point p on a primitive of ordinary size (radius < 1000) */
   double max_emission = 0; /* max |emission component| over all materials */
@@ -137,6 +159,45 @@ void put_material(double *m, uint32_t flags, const double *color, const double *
   memcpy(&m[7], &bits, sizeof bits);
 }
 
+/* One sphere's record of entry_src (pt_device.h): cx cy cz, r*r, |c| rounded up, 0. */
+void sphere_entry(const double *center, double radius, double *g)
+{
+  g[0] = center[0];
+  g[1] = center[1];
+  g[2] = center[2];
+  g[3] = radius * radius; /* raytracer.c:87 */
+  /* |c|, rounded up: feeds the conservative phase-1 thresholds only, never a result */
+  g[4] = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) * (1.0 + 1e-12);
+  g[5] = 0.0; /* a sphere is rejected when its centre is behind the origin at all (raytracer.c:84) */
+}
+
+/* One triangle: tri_geom record (v0, e1, e2) and its entry_src record, the phase-1 bound: a
+ * sphere around the centroid through the farthest vertex, slightly enlarged; feeds the
+ * conservative filter only, never a result. */
+void triangle_entry(const double *p0, const double *p1, const double *p2, double *g, double *b)
+{
+  H3 v0 = h3(p0), v1 = h3(p1), v2 = h3(p2);
+  H3 e1 = h_sub(v1, v0), e2 = h_sub(v2, v0); /* raytracer.c:132-133 */
+  g[0] = v0.x; g[1] = v0.y; g[2] = v0.z;
+  g[3] = e1.x; g[4] = e1.y; g[5] = e1.z;
+  g[6] = e2.x; g[7] = e2.y; g[8] = e2.z;
+  H3 cen = {(v0.x + v1.x + v2.x) / 3.0, (v0.y + v1.y + v2.y) / 3.0, (v0.z + v1.z + v2.z) / 3.0};
+  double rb2 = 0;
+  const H3 vs[3] = {v0, v1, v2};
+  for (int j = 0; j < 3; j++)
+  {
+    H3 dv = h_sub(vs[j], cen);
+    rb2 = std::fmax(rb2, h_dot(dv, dv));
+  }
+  const double rb = std::sqrt(rb2) * (1.0 + 1e-9) + 1e-300;
+  b[0] = cen.x;
+  b[1] = cen.y;
+  b[2] = cen.z;
+  b[3] = rb * rb;
+  b[4] = std::sqrt(h_dot(cen, cen)) * (1.0 + 1e-12);
+  b[5] = rb;
+}
+
 /* ---- bounding-volume hierarchy over triangles ----
  * Binary tree, median split on the longest axis of the centroid bounds (balanced: depth =
  * ceil(log2(leaves))), leaves of <= PT_BVH_LEAF triangles.  A node stores the boxes of its two
@@ -231,6 +292,93 @@ int kernel_variant()
     return (e && e[0] == '0') ? 0 : 1;
   }();
   return v;
+}
+
+/* The table set of `scene` for `near_R`, ready to be read by work submitted to `stream` after this
+ * call (see TableSet).  *slot identifies it for release_tables(). */
+int acquire_tables(const RtHipScene *scene, double near_R, hipStream_t stream, float **filt, float **bvh_nodes, size_t *slot)
+{
+  std::lock_guard<std::mutex> lock(scene->table_mutex);
+  std::vector<TableSet> &tables = scene->tables;
+  for (size_t k = 0; k < tables.size(); k++)
+    if (tables[k].near_R == near_R)
+    {
+      HIP_TRY(hipStreamWaitEvent(stream, tables[k].built, 0));
+      tables[k].stamp = ++scene->table_clock;
+      tables[k].users++;
+      *filt = tables[k].filt;
+      *bvh_nodes = tables[k].bvh_nodes;
+      *slot = k;
+      return RT_HIP_OK;
+    }
+  size_t k = tables.size();
+  if (k < RT_TABLE_SETS)
+  {
+    TableSet t;
+    if (k == 0)
+    { /* the storage inside the scene blob */
+      t.filt = scene->view.filt;
+      t.bvh_nodes = scene->view.bvh_nodes;
+    }
+    else
+    {
+      t.owned = true;
+      HIP_TRY(hipMalloc(&t.filt, scene->filt_bytes ? scene->filt_bytes : 256));
+      hipError_t e = hipMalloc(&t.bvh_nodes, scene->bvh_nodes_bytes ? scene->bvh_nodes_bytes : 256);
+      if (e != hipSuccess)
+      {
+        (void)hipFree(t.filt);
+        return fail(RT_HIP_ENOMEM, "hipMalloc of a hierarchy table: %s", hipGetErrorString(e));
+      }
+    }
+    hipError_t e = hipEventCreateWithFlags(&t.built, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t.last_use, hipEventDisableTiming);
+    if (e != hipSuccess)
+    {
+      if (t.built) (void)hipEventDestroy(t.built);
+      if (t.owned)
+      {
+        (void)hipFree(t.filt);
+        (void)hipFree(t.bvh_nodes);
+      }
+      return fail(RT_HIP_ERUNTIME, "hipEventCreate: %s", hipGetErrorString(e));
+    }
+    tables.push_back(t);
+  }
+  else
+  {
+    /* recycle the least recently used set once every launch that reads it has finished */
+    k = tables.size();
+    for (size_t j = 0; j < tables.size(); j++)
+      if (tables[j].users == 0 && (k == tables.size() || tables[j].stamp < tables[k].stamp))
+        k = j;
+    if (k == tables.size())
+      return fail(RT_HIP_ELIMIT, "more than %d launches of one scene with different camera distances are being submitted at once",
+                  RT_TABLE_SETS);
+    HIP_TRY(hipEventSynchronize(tables[k].last_use));
+  }
+  TableSet &t = tables[k];
+  t.near_R = near_R;
+  t.stamp = ++scene->table_clock;
+  t.users++;
+  HIP_TRY(pt_launch_build_tables(scene->view, near_R, t.filt, t.bvh_nodes, stream));
+  HIP_TRY(hipEventRecord(t.built, stream));
+  HIP_TRY(hipEventRecord(t.last_use, stream));
+  *filt = t.filt;
+  *bvh_nodes = t.bvh_nodes;
+  *slot = k;
+  return RT_HIP_OK;
+}
+
+/* after the render that reads table set `slot` has been submitted to `stream` */
+void release_tables(const RtHipScene *scene, size_t slot, hipStream_t stream)
+{
+  std::lock_guard<std::mutex> lock(scene->table_mutex);
+  if (slot < scene->tables.size())
+  {
+    (void)hipEventRecord(scene->tables[slot].last_use, stream);
+    scene->tables[slot].users--;
+  }
 }
 
 uint32_t tiles_x_of(int width) { return ((uint32_t)width + PT_TILE - 1) / PT_TILE; }
@@ -391,13 +539,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   for (size_t i = 0; i < n_spheres; i++)
   {
     double *g = &geom[PT_ENTRY_SRC_STRIDE * i];
-    g[0] = spheres[i].center[0];
-    g[1] = spheres[i].center[1];
-    g[2] = spheres[i].center[2];
-    g[3] = spheres[i].radius * spheres[i].radius; /* raytracer.c:87 */
-    /* |c|, rounded up: feeds the conservative phase-1 thresholds only, never a result */
-    g[4] = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) * (1.0 + 1e-12);
-    g[5] = 0.0; /* a sphere is rejected when its centre is behind the origin at all (raytracer.c:84) */
+    sphere_entry(spheres[i].center, spheres[i].radius, g);
     memcpy(&geom4[PT_GEOM_STRIDE * i], g, PT_GEOM_STRIDE * sizeof(double));
     max_center = std::fmax(max_center, g[4]);
     wide_range |= !(g[4] <= 1e17) || !(std::fabs(spheres[i].radius) <= 1e17);
@@ -418,15 +560,11 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     for (size_t k = 0; k < meshes[m].num_triangles; k++, t++)
     {
       const RtHipVertex *v = meshes[m].vertices + 3 * k;
-      H3 v0 = h3(v[0].pos), v1 = h3(v[1].pos), v2 = h3(v[2].pos);
-      H3 e1 = h_sub(v1, v0), e2 = h_sub(v2, v0); /* raytracer.c:132-133 */
-      /* calculate_surface_normal :42-45: normalize(cross(v2-v0, v1-v0)) */
-      H3 c = h_cross(e2, e1);
-      H3 n = h_scale(c, 1.0 / std::sqrt(h_dot(c, c)));
       double *g = &tgeom[9 * t];
-      g[0] = v0.x; g[1] = v0.y; g[2] = v0.z;
-      g[3] = e1.x; g[4] = e1.y; g[5] = e1.z;
-      g[6] = e2.x; g[7] = e2.y; g[8] = e2.z;
+      triangle_entry(v[0].pos, v[1].pos, v[2].pos, g, &geom[PT_ENTRY_SRC_STRIDE * (n_spheres + t)]);
+      /* calculate_surface_normal :42-45: normalize(cross(v2-v0, v1-v0)) */
+      H3 c = h_cross(h3(g + 6), h3(g + 3));
+      H3 n = h_scale(c, 1.0 / std::sqrt(h_dot(c, c)));
       tnorm[3 * t + 0] = n.x; tnorm[3 * t + 1] = n.y; tnorm[3 * t + 2] = n.z;
       for (int j = 0; j < 3; j++)
       {
@@ -434,23 +572,6 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
         ttex[6 * t + 2 * j + 1] = v[j].tex[1];
       }
       tobj[t] = (uint32_t)(n_spheres + m);
-      /* phase-1 bound of the triangle: a sphere around the centroid through the farthest
-       * vertex, slightly enlarged; feeds the conservative filter only, never a result */
-      double *b = &geom[PT_ENTRY_SRC_STRIDE * (n_spheres + t)];
-      H3 cen = {(v0.x + v1.x + v2.x) / 3.0, (v0.y + v1.y + v2.y) / 3.0, (v0.z + v1.z + v2.z) / 3.0};
-      double rb2 = 0;
-      for (int j = 0; j < 3; j++)
-      {
-        H3 dv = h_sub(h3(v[j].pos), cen);
-        rb2 = std::fmax(rb2, h_dot(dv, dv));
-      }
-      const double rb = std::sqrt(rb2) * (1.0 + 1e-9) + 1e-300;
-      b[0] = cen.x;
-      b[1] = cen.y;
-      b[2] = cen.z;
-      b[3] = rb * rb;
-      b[4] = std::sqrt(h_dot(cen, cen)) * (1.0 + 1e-12);
-      b[5] = rb;
     }
   }
 
@@ -535,6 +656,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.bvh_nodes = reinterpret_cast<float *>(base + off_bvh_nodes);
   sc->view.bvh_tri = reinterpret_cast<const uint32_t *>(base + off_bvh_tri);
   sc->view.n_bvh_nodes = (uint32_t)n_bvh_nodes;
+  sc->filt_bytes = filt_bytes;
+  sc->bvh_nodes_bytes = n_bvh_nodes * PT_BVH_NODE_WORDS * 4;
   sc->view.material = reinterpret_cast<const double *>(base + off_mat);
   sc->view.color_raw = reinterpret_cast<const double *>(base + off_craw);
   sc->view.geom4 = reinterpret_cast<const double *>(base + off_geom4);
@@ -567,6 +690,17 @@ void rt_hip_scene_destroy(RtHipScene *scene)
     return;
   {
     DeviceScope scope(scene->device);
+    for (TableSet &t : scene->tables)
+    {
+      if (t.last_use) (void)hipEventSynchronize(t.last_use);
+      if (t.built) (void)hipEventDestroy(t.built);
+      if (t.last_use) (void)hipEventDestroy(t.last_use);
+      if (t.owned)
+      {
+        (void)hipFree(t.filt);
+        (void)hipFree(t.bvh_nodes);
+      }
+    }
     (void)hipFree(scene->blob);
   }
   delete scene;
@@ -579,9 +713,14 @@ size_t rt_hip_scene_primitives(const RtHipScene *scene)
   return scene ? (size_t)scene->view.n_spheres + scene->view.n_triangles : 0;
 }
 
+const char *rt_hip_kernel_name(const RtHipScene *scene, uint32_t integrator)
+{
+  return scene ? pt_kernel_name(scene->view, integrator, kernel_variant()) : "";
+}
+
 size_t rt_hip_chunk_workspace_bytes(uint32_t tile_count)
 {
-  return (size_t)tile_count * PT_TILE_PIXELS * 3 * sizeof(unsigned long long);
+  return (size_t)tile_count * PT_ACC_WS_WORDS * sizeof(unsigned long long);
 }
 
 uint32_t rt_hip_suggest_chunks(const RtHipScene *scene, uint32_t tile_count, int32_t samples)
@@ -701,7 +840,12 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
 
   DeviceScope scope(scene->device);
   HIP_TRY(scope.status);
+  size_t slot = 0;
+  rc = acquire_tables(scene, L.near_R, static_cast<hipStream_t>(stream), &L.scene.filt, &L.scene.bvh_nodes, &slot);
+  if (rc)
+    return rc;
   hipError_t e = pt_launch_render(L, static_cast<hipStream_t>(stream), kernel_variant());
+  release_tables(scene, slot, static_cast<hipStream_t>(stream));
   if (e != hipSuccess)
     return fail(RT_HIP_ERUNTIME, "pt_render_tiles launch: %s", hipGetErrorString(e));
   return RT_HIP_OK;
@@ -727,6 +871,78 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
   if (e != hipSuccess)
     return fail(RT_HIP_ERUNTIME, "self-test: %s", hipGetErrorString(e));
   return RT_HIP_OK;
+}
+
+int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_prims, size_t n, double near_R,
+                              uint8_t *h_hit, double *h_tuv, uint64_t *h_keep, int device)
+{
+  if ((kind != 0 && kind != 1) || !h_rays || !h_prims || !h_hit || !h_tuv || !h_keep)
+    return fail(RT_HIP_EINVAL, "bad self-test arguments");
+  if (!(near_R > 0) || !(near_R < 1e15) || n > 0x7FFFFFFFu)
+    return fail(RT_HIP_EINVAL, "near_R must be a positive finite bound, n < 2^31");
+  if (device < 0 || device >= usable_devices())
+    return fail(RT_HIP_ENODEV, "no HIP device %d", device);
+  if (n == 0)
+    return RT_HIP_OK;
+  try
+  {
+    /* the records exactly as rt_hip_scene_create lays them out (same helpers) */
+    const size_t rec = kind == 0 ? 4 : 9;
+    std::vector<double> prims(rec * n), entry(PT_ENTRY_SRC_STRIDE * n);
+    double max_center = 0;
+    for (size_t i = 0; i < n; i++)
+    {
+      double *e = &entry[PT_ENTRY_SRC_STRIDE * i];
+      if (kind == 0)
+      {
+        const double *p = h_prims + 4 * i;
+        if (!(std::fabs(p[3]) >= 1e-100) || !(std::fabs(p[3]) <= 1e17))
+          return fail(RT_HIP_ELIMIT, "sphere %zu: |radius| %g outside [1e-100, 1e17]", i, p[3]);
+        sphere_entry(p, p[3], e);
+        memcpy(&prims[4 * i], e, 4 * sizeof(double));
+      }
+      else
+        triangle_entry(h_prims + 9 * i, h_prims + 9 * i + 3, h_prims + 9 * i + 6, &prims[9 * i], e);
+      if (!(e[4] <= 1e17))
+        return fail(RT_HIP_ELIMIT, "primitive %zu: centre beyond 1e17", i);
+      max_center = std::fmax(max_center, e[4]);
+    }
+    const double filt_shift = 10.0 * 5.9604644775390625e-08 * (max_center + near_R) * (1.0 + 1e-9); /* as rt_hip_render_tiles */
+    const size_t n_blocks = (n + 63) / 64;
+    const size_t filt_bytes = (n_blocks * 32 + 1) * (size_t)PT_FILT_STRIDE * 2 * sizeof(float);
+    const size_t b_rays = 6 * n * 8, b_prims = rec * n * 8, b_entry = entry.size() * 8, b_tuv = 3 * n * 8, b_keep = 3 * n * 8;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_rays = 0, o_prims = o_rays + pad(b_rays), o_entry = o_prims + pad(b_prims), o_filt = o_entry + pad(b_entry),
+                 o_tuv = o_filt + pad(filt_bytes), o_keep = o_tuv + pad(b_tuv), o_hit = o_keep + pad(b_keep),
+                 total = o_hit + pad(n);
+    DeviceScope scope(device);
+    HIP_TRY(scope.status);
+    char *d = nullptr;
+    hipError_t e = hipMalloc(&d, total);
+    if (e != hipSuccess)
+      return fail(RT_HIP_ENOMEM, "hipMalloc(%zu): %s", total, hipGetErrorString(e));
+    e = hipMemset(d + o_filt, 0, filt_bytes);
+    if (e == hipSuccess) e = hipMemcpy(d + o_rays, h_rays, b_rays, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o_prims, prims.data(), b_prims, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o_entry, entry.data(), b_entry, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = pt_launch_selftest_intersect(kind, reinterpret_cast<double *>(d + o_rays), reinterpret_cast<double *>(d + o_prims),
+                                       reinterpret_cast<double *>(d + o_entry), reinterpret_cast<float *>(d + o_filt),
+                                       (uint32_t)n, near_R, filt_shift, reinterpret_cast<uint8_t *>(d + o_hit),
+                                       reinterpret_cast<double *>(d + o_tuv), reinterpret_cast<unsigned long long *>(d + o_keep),
+                                       nullptr);
+    if (e == hipSuccess) e = hipMemcpy(h_hit, d + o_hit, n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_tuv, d + o_tuv, b_tuv, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_keep, d + o_keep, b_keep, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+      return fail(RT_HIP_ERUNTIME, "intersect self-test: %s", hipGetErrorString(e));
+    return RT_HIP_OK;
+  }
+  catch (const std::bad_alloc &)
+  {
+    return fail(RT_HIP_ENOMEM, "host allocation failed in rt_hip_selftest_intersect");
+  }
 }
 
 int rt_hip_untile(const float *d_tiles_rgb, const uint8_t *d_tiles_rgb8, int32_t width, int32_t height,

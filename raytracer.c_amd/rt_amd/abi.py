@@ -92,6 +92,7 @@ SHIM_SYMBOLS = {
     "rt_hip_scene_destroy": (None, [C.c_void_p]),
     "rt_hip_scene_device": (C.c_int, [C.c_void_p]),
     "rt_hip_scene_primitives": (C.c_size_t, [C.c_void_p]),
+    "rt_hip_kernel_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "rt_hip_render_tiles": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RtHipParams), C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_hip_chunk_workspace_bytes": (C.c_size_t, [C.c_uint32]),
@@ -99,6 +100,8 @@ SHIM_SYMBOLS = {
     "rt_hip_render_tiles_chunked": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RtHipParams), C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_hip_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "rt_hip_selftest_intersect": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int]),
     "rt_hip_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_hip_set_cancel_flag": (None, [C.c_void_p]),

@@ -57,15 +57,19 @@ class GpuScene:
         p.tile_first, p.tile_stride, p.tile_count = first, stride, count
         return p
 
+    def kernel_name(self, integrator="path"):
+        return self.shim.rt_hip_kernel_name(self.handle, abi.INTEGRATORS[integrator]).decode()
+
     def suggest_chunks(self, count, samples=None):
         return int(self.shim.rt_hip_suggest_chunks(self.handle, count, samples or self.scene.samples))
 
     def render_tiles(self, seed, first, stride, count, tiles=None, tiles8=None, stats=None, samples=None,
-                     max_depth=None, chunks=1, workspace=None, integrator="path"):
+                     max_depth=None, chunks=1, workspace=None, integrator="path", camera=None):
         """Asynchronous on torch's current stream.  Returns (tiles f32 [count,64,3],
         tiles8 u8 [count,64,3], stats i64 [4]); pass buffers to reuse them.  chunks > 1 splits
         every tile's samples over that many workgroups (same image, bit for bit).
-        integrator: "path" = trace_path (what the reference ships), "whitted" = cast_ray."""
+        integrator: "path" = trace_path (what the reference ships), "whitted" = cast_ray.
+        camera: an abi.Camera to render with instead of the scene's own."""
         dev = torch.device("cuda", self.device)
         if tiles is None:
             tiles = torch.empty((max(count, 1), abi.TILE_PIXELS, 3), dtype=torch.float32, device=dev)
@@ -78,7 +82,8 @@ class GpuScene:
         if chunks > 1 and workspace is None:
             workspace = torch.empty(self.shim.rt_hip_chunk_workspace_bytes(max(count, 1)), dtype=torch.uint8, device=dev)
         self._workspace = workspace  # keep alive until the stream has used it
-        _check(self.shim.rt_hip_render_tiles_chunked(self.handle, C.byref(self.scene.camera), C.byref(p), chunks,
+        _check(self.shim.rt_hip_render_tiles_chunked(self.handle, C.byref(camera if camera is not None else self.scene.camera),
+                                                     C.byref(p), chunks,
                                                      workspace.data_ptr() if workspace is not None else None,
                                                      tiles.data_ptr(), tiles8.data_ptr(), stats.data_ptr(),
                                                      C.c_void_p(stream)),

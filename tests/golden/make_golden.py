@@ -4,7 +4,8 @@
 built in place from /root/reference by oracle/Makefile; RNG = include/rt_rng.h on both
 sides).  Run in the build container, where /root/reference exists:
 
-    make oracle && python tests/golden/make_golden.py
+    make oracle && python tests/golden/make_golden.py            (all but meshes.npz)
+    make oracle && python tests/golden/make_golden.py meshes     (meshes.npz only; minutes)
 
 The fixtures are DATA (inputs + expected outputs as float64 / integer arrays in .npz,
 loadable with allow_pickle=False); no reference source text is stored.  c3_cube.obj (the
@@ -21,6 +22,15 @@ Files
   whitted.npz      the same kinds of vectors from the reference's compiled cast_ray()
                    (raytracer.c:556-641): a 96x64 frame covering every branch, tiles of
                    configs 2 and 4 at full size, per-sample traces
+  meshes.npz       triangle-mesh scenes, from oracle/_ref/libref_mesh_d<N>.so = the reference's
+                   compiled trace_path() / cast_ray() with its commented-out mesh scan
+                   (raytracer.c:417-435) revived around its compiled intersect_triangle /
+                   calculate_surface_normal (oracle/ref_harness.c, ORACLE_MESH_HOOK): tiles of
+                   config 3 at its full 1920x1080 x 256 spp and of config 5 at its full
+                   3840x2160 x 4096 spp (10,240 triangles: ~1.3e10 primitive tests per tile, a few
+                   minutes on 8 cores), per-sample traces of both, and 64x48 frames of a random
+                   textured triangle soup with checkered materials under both integrators (the
+                   literal scan's stale hit.u / hit.v)
 """
 import os
 import sys
@@ -36,7 +46,7 @@ os.environ.setdefault("OMP_NUM_THREADS", "1")
 
 import oracle_py  # noqa: E402
 from rt_amd import scene as S  # noqa: E402
-from util import glass_scene, tile_pixels, whitted_scene  # noqa: E402
+from util import glass_scene, mesh_soup_scene, tile_pixels, whitted_scene  # noqa: E402
 
 SEED = 1666943821
 
@@ -271,7 +281,79 @@ def whitted():
     return out
 
 
+def _mesh_job(args):
+    cfg, spp, px = args
+    sc = S.build_scene(cfg, samples=spp)
+    mean, rgb8, st = oracle_py.RefMeshOracle(sc.max_depth).render_pixels(sc, SEED, pixels=px)
+    return mean, rgb8, st["rays"], st["tests"]
+
+
+def meshes():
+    """needs oracle/_ref/libref_mesh_d*.so; config 5's tiles run on every core"""
+    import multiprocessing as mp
+    out = {}
+    rng = np.random.default_rng(7)
+    for cfg, picks in [(3, 16), (5, 6)]:
+        sc = S.build_scene(cfg)
+        tx, ty = (sc.width + 7) // 8, (sc.height + 7) // 8
+        total = tx * ty
+        if cfg == 3:
+            tiles = np.sort(rng.choice(total, size=picks, replace=False)).astype(np.uint32)
+        else:
+            # first tile, last tile (x = W-1 = 3839: the camera quotient's extreme), and tiles on the mesh
+            cx, cy = tx // 2, ty // 2
+            tiles = np.array(sorted({0, total - 1, cy * tx + cx, (cy - 40) * tx + cx + 30, (cy + 35) * tx + cx - 50,
+                                     (cy + 110) * tx + cx + 3}), dtype=np.uint32)
+        px = tile_pixels(sc.width, sc.height, tiles)
+        n_proc = min(os.cpu_count() or 1, 16)
+        parts = [px[i::n_proc] for i in range(n_proc)]
+        with mp.get_context("spawn").Pool(n_proc) as pool:
+            res = pool.map(_mesh_job, [(cfg, sc.samples, p) for p in parts])
+        mean = np.zeros((len(px), 3))
+        rgb8 = np.zeros((len(px), 3), dtype=np.uint8)
+        for i, (m, b, _, _) in enumerate(res):
+            mean[i::n_proc] = m
+            rgb8[i::n_proc] = b
+        tag = f"c{cfg}_s{sc.samples}"
+        out[tag + "_tiles"] = tiles
+        out[tag + "_mean"] = mean
+        out[tag + "_rgb8"] = rgb8
+        out[tag + "_stats"] = np.array([sum(r[2] for r in res), sum(r[3] for r in res)])
+        out[tag + "_dims"] = np.array([sc.width, sc.height, sc.samples, sc.max_depth])
+        print(tag, "tiles", tiles.tolist(), "stats", out[tag + "_stats"].tolist(), flush=True)
+        # per-sample traces
+        ref = oracle_py.RefMeshOracle(sc.max_depth)
+        keys = np.stack([rng.integers(0, sc.width, 256), rng.integers(0, sc.height, 256),
+                         rng.integers(0, sc.samples, 256)], axis=1).astype(np.uint32)
+        if cfg == 5:  # half of them through the middle of the frame, where the mesh is
+            keys[:128, 0] = rng.integers(sc.width // 2 - 400, sc.width // 2 + 400, 128)
+            keys[:128, 1] = rng.integers(sc.height // 2 - 400, sc.height // 2 + 400, 128)
+        rgb = np.zeros((256, 3))
+        stats = np.zeros((256, 3), dtype=np.int64)
+        for k, (x, y, s_) in enumerate(keys):
+            c, st = ref.trace_sample(sc, int(x), int(y), int(s_), SEED)
+            rgb[k] = c
+            stats[k] = (st["rays"], st["tests"], st["draws"])
+        out[f"c{cfg}_keys"] = keys
+        out[f"c{cfg}_rgb"] = rgb
+        out[f"c{cfg}_stats"] = stats
+    # textured, checkered triangle soup (duplicates, degenerates, two meshes): both integrators
+    sc = mesh_soup_scene()
+    ref = oracle_py.RefMeshOracle(sc.max_depth)
+    for integ in ("path", "whitted"):
+        mean, rgb8, st = ref.render_pixels(sc, SEED, integrator=integ)
+        out[f"soup_{integ}_mean"] = mean
+        out[f"soup_{integ}_rgb8"] = rgb8
+        out[f"soup_{integ}_stats"] = np.array([st["rays"], st["tests"]])
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "meshes":
+        assert oracle_py.ref_mesh_available(), "build oracle/_ref first (make oracle, needs /root/reference)"
+        np.savez_compressed(os.path.join(HERE, "meshes.npz"), **meshes())
+        print("meshes.npz", os.path.getsize(os.path.join(HERE, "meshes.npz")), "bytes")
+        return
     assert oracle_py.ref_available(), "build oracle/_ref first (make oracle, needs /root/reference)"
     np.savez_compressed(os.path.join(HERE, "primitives.npz"), **primitives(oracle_py.RefOracle(5)))
     np.savez_compressed(os.path.join(HERE, "frames.npz"), **frames())

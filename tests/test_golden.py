@@ -171,3 +171,61 @@ def test_whitted_sample_traces(pt, whitted):
         assert np.array_equal(c, rgb)
         assert [got["rays"], got["tests"], got["draws"]] == st.tolist()
         assert got["draws"] == 2  # the camera jitter only
+
+
+# ---- meshes.npz: the reference's compiled trace_path() + its revived mesh scan (ref_harness.c) ----
+
+def _tile_px(w, h, tiles):
+    from util import tile_pixels
+    return tile_pixels(w, h, tiles)
+
+
+def test_mesh_golden_config3_tiles(pt):
+    """config 3 at its full 1920x1080 x 256 spp: all 16 golden tiles"""
+    from rt_amd import scene as S
+    fr = np.load(os.path.join(GOLD, "meshes.npz"), allow_pickle=False)
+    w, h, spp, depth = [int(v) for v in fr["c3_s256_dims"]]
+    sc = S.build_scene(3)
+    assert (sc.width, sc.height, sc.samples, sc.max_depth) == (w, h, spp, depth)
+    mean, rgb8, st = pt.render_pixels(sc, SEED, pixels=_tile_px(w, h, fr["c3_s256_tiles"]))
+    assert np.array_equal(mean, fr["c3_s256_mean"]) and np.array_equal(rgb8, fr["c3_s256_rgb8"])
+    assert [st["rays"], st["tests"]] == fr["c3_s256_stats"].tolist()
+    sc.free()
+
+
+def test_mesh_golden_config5_pixels(pt):
+    """config 5 at its full 3840x2160 x 4096 spp (10,240 triangles): three golden pixels, one of them in
+    the last tile (x = W-1); a whole tile is ~1.3e10 primitive tests, which the GPU test renders"""
+    from rt_amd import scene as S
+    fr = np.load(os.path.join(GOLD, "meshes.npz"), allow_pickle=False)
+    w, h, spp, depth = [int(v) for v in fr["c5_s4096_dims"]]
+    sc = S.build_scene(5)
+    assert (sc.width, sc.height, sc.samples, sc.max_depth) == (w, h, spp, depth)
+    px = _tile_px(w, h, fr["c5_s4096_tiles"])
+    pick = np.array([7, 2 * 64 + 30, len(px) - 1])
+    mean, rgb8, _ = pt.render_pixels(sc, SEED, pixels=px[pick])
+    assert np.array_equal(mean, fr["c5_s4096_mean"][pick]) and np.array_equal(rgb8, fr["c5_s4096_rgb8"][pick])
+    assert px[-1] == w * h - 1
+    sc.free()
+
+
+@pytest.mark.parametrize("cfg", [3, 5])
+def test_mesh_golden_samples(pt, cfg):
+    from rt_amd import scene as S
+    fr = np.load(os.path.join(GOLD, "meshes.npz"), allow_pickle=False)
+    sc = S.build_scene(cfg)
+    for (x, y, s), rgb, st in zip(fr[f"c{cfg}_keys"], fr[f"c{cfg}_rgb"], fr[f"c{cfg}_stats"]):
+        c, got = pt.trace_sample(sc, int(x), int(y), int(s), SEED)
+        assert np.array_equal(c, rgb)
+        assert [got["rays"], got["tests"], got["draws"]] == st.tolist()
+    sc.free()
+
+
+@pytest.mark.parametrize("integ", ["path", "whitted"])
+def test_mesh_golden_soup_frames(pt, integ):
+    from util import mesh_soup_scene
+    fr = np.load(os.path.join(GOLD, "meshes.npz"), allow_pickle=False)
+    sc = mesh_soup_scene()
+    mean, rgb8, st = pt.render_pixels(sc, SEED, integrator=integ)
+    assert np.array_equal(mean, fr[f"soup_{integ}_mean"]) and np.array_equal(rgb8, fr[f"soup_{integ}_rgb8"])
+    assert [st["rays"], st["tests"]] == fr[f"soup_{integ}_stats"].tolist()

@@ -22,12 +22,13 @@ def gpu():
     return G
 
 
-def _full(gpu, pt, sc, seed=SEED, integrator="path"):
+def _full(gpu, pt, sc, seed=SEED, integrator="path", hdr=False):
     gs = gpu.GpuScene(sc)
     img, img8, st = gs.render_image(seed, integrator=integrator)
     mean, rgb8, ost = pt.render_pixels(sc, seed, integrator=integrator)
     assert st["samples"] == sc.width * sc.height * sc.samples
-    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"config {sc.config} {integrator}")
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"config {sc.config} {integrator}",
+                  hdr=hdr)
     gs.close()
     return st
 
@@ -465,13 +466,13 @@ def _random_scene(seed, with_mesh, n_tris, extra_flags=()):
 
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_sphere_scenes(gpu, pt, seed):
-    _full(gpu, pt, _random_scene(seed, False, 0))
+    _full(gpu, pt, _random_scene(seed, False, 0), hdr=True)  # emitters up to 1e3, "fresnel" weights beyond 1
 
 
 @pytest.mark.parametrize("seed,n_tris", [(s, n) for s, n in zip(range(16, 28), [3, 10, 40, 120, 250, 300, 400, 700, 1000, 60, 500, 2000])])
 def test_fuzz_mesh_scenes(gpu, pt, seed, n_tris):
     """small meshes go through the flat filter, larger ones (> 256 primitives) through the hierarchy"""
-    _full(gpu, pt, _random_scene(seed, True, n_tris))
+    _full(gpu, pt, _random_scene(seed, True, n_tris), hdr=True)
 
 
 def test_obj_file_through_render_ex(gpu, pt):
@@ -594,7 +595,7 @@ def test_whitted_fuzz(gpu, pt, seed):
     both = (abi.M_REFLECTION | abi.M_REFRACTION, abi.M_REFLECTION | abi.M_REFRACTION | abi.M_CHECKERED,
             abi.M_REFRACTION | abi.M_CHECKERED)
     n_tris = [0, 0, 0, 0, 0, 0, 5, 40, 200, 300, 600, 1500][seed - 40]
-    _full(gpu, pt, _random_scene(seed, n_tris > 0, n_tris, extra_flags=both), integrator="whitted")
+    _full(gpu, pt, _random_scene(seed, n_tris > 0, n_tris, extra_flags=both), integrator="whitted", hdr=True)
 
 
 def test_whitted_through_the_host_api_and_cli(gpu, pt, tmp_path):
@@ -767,3 +768,220 @@ def test_many_samples_per_pixel(gpu, pt):
     torch.cuda.synchronize()
     assert torch.equal(full, img) and torch.equal(full8, img8)
     gs.close()
+
+
+# ---- triangle meshes against the compiled reference (tests/golden/meshes.npz: the reference's
+# ---- compiled trace_path() + its commented-out mesh scan revived around its compiled primitives)
+
+@pytest.mark.parametrize("tag,cfg", [("c3_s256", 3), ("c5_s4096", 5)])
+def test_golden_mesh_tiles_full_size(gpu, tag, cfg):
+    """BASELINE configs[2] at its full 1920x1080 x 256 spp (flat-filter triangle kernel) and configs[4]
+    at its full 3840x2160 x 4096 spp (10,240 triangles: hierarchy kernel, W-1 = 3839 camera quotient,
+    16 x 4096-job pools): each golden tile rendered on its own through render_tiles(first=t, count=1)"""
+    import torch
+    from rt_amd import scene as S
+    fr = np.load(GOLD + "/meshes.npz", allow_pickle=False)
+    w, h, spp, depth = [int(v) for v in fr[tag + "_dims"]]
+    sc = S.build_scene(cfg)
+    assert (sc.width, sc.height, sc.samples, sc.max_depth) == (w, h, spp, depth)
+    gs = gpu.GpuScene(sc)
+    got, got8 = [], []
+    stats = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for t in fr[tag + "_tiles"]:
+        tl, tl8, _ = gs.render_tiles(SEED, int(t), 1, 1, stats=stats)
+        got.append(tl[0])
+        got8.append(tl8[0])
+    torch.cuda.synchronize()
+    g = torch.stack(got).cpu().numpy().reshape(-1, 3)
+    g8 = torch.stack(got8).cpu().numpy().reshape(-1, 3)
+    st = stats.cpu().tolist()
+    ost = dict(rays=int(fr[tag + "_stats"][0]), tests=int(fr[tag + "_stats"][1]))
+    assert_parity(g, g8, dict(rays=st[0], tests=st[2]), fr[tag + "_mean"], fr[tag + "_rgb8"], ost, what=tag)
+    gs.close()
+    sc.free()
+
+
+@pytest.mark.parametrize("integ", ["path", "whitted"])
+def test_golden_mesh_soup_frames(gpu, integ):
+    """textured + checkered triangle soup with duplicated and degenerate triangles, two meshes, under
+    both integrators: the device reproduces the literal scan's hit.u / hit.v (those of the LAST
+    triangle the ray passes, TriLast in pt_kernel.hip) -- frames from the compiled reference"""
+    from util import mesh_soup_scene
+    fr = np.load(GOLD + "/meshes.npz", allow_pickle=False)
+    sc = mesh_soup_scene()
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(SEED, integrator=integ)
+    ost = dict(rays=int(fr[f"soup_{integ}_stats"][0]), tests=int(fr[f"soup_{integ}_stats"][1]))
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, fr[f"soup_{integ}_mean"], fr[f"soup_{integ}_rgb8"], ost,
+                  what=f"mesh soup {integ}")
+    gs.close()
+
+
+@pytest.mark.parametrize("integ", ["path", "whitted"])
+def test_checkered_mesh_through_the_hierarchy(gpu, pt, integ):
+    """the same rule in the hierarchy kernels (> 256 primitives): with M_CHECKERED materials and
+    triangles the walk may not prune by the closest hit, every passing triangle matters"""
+    from util import mesh_soup_scene
+    sc = mesh_soup_scene(seed=13, n_tris=420, width=56, height=40, samples=3, max_depth=5)
+    assert sc.n_objects + sc.n_triangles > 256
+    _full(gpu, pt, sc, integrator=integ)
+
+
+# ---- the reference's primitive known-answers on the DEVICE (tests/golden/primitives.npz) ----
+
+def _selftest_intersect(kind, rays, prims, near_R):
+    import ctypes as C
+    from rt_amd import abi
+    shim = abi.load_shim()
+    n = len(rays)
+    rays = np.ascontiguousarray(rays, dtype=np.float64)
+    prims = np.ascontiguousarray(prims, dtype=np.float64)
+    hit = np.zeros(n, dtype=np.uint8)
+    tuv = np.zeros((n, 3))
+    keep = np.zeros((n, 3), dtype=np.uint64)
+    rc = shim.rt_hip_selftest_intersect(kind, rays.ctypes.data, prims.ctypes.data, n, C.c_double(near_R),
+                                        hit.ctypes.data, tuv.ctypes.data, keep.ctypes.data, 0)
+    assert rc == 0, shim.rt_hip_last_error()
+    return hit, tuv, keep
+
+
+@pytest.mark.parametrize("near_R", [64.0, 3.0e4])
+def test_device_sphere_known_answers(gpu, pt, near_R):
+    """1,100 (ray, sphere) cases generated by the reference's compiled intersect_sphere() -- grazing,
+    origin inside / on the surface, t ~ EPSILON, radius-1e4 walls (raytracer.c:77-118) -- through the
+    kernel's exact_sphere: hit flags and t BIT-equal.  And the conservative phase-1 filter, in all
+    three forms, over all 64 x 1,100 (ray, sphere) pairs of the blocks: it never drops a pair the
+    exact test accepts."""
+    pr = np.load(GOLD + "/primitives.npz", allow_pickle=False)
+    rays, cen, rad = pr["sph_ray"], pr["sph_center"], pr["sph_radius"]
+    n = len(rays)
+    hit, tuv, keep = _selftest_intersect(0, rays, np.concatenate([cen, rad[:, None]], axis=1), near_R)
+    assert np.array_equal(hit, pr["sph_hit"])
+    on = hit.astype(bool)
+    assert np.array_equal(tuv[on, 0], pr["sph_t"][on]), "t of accepted sphere hits differs from the compiled reference"
+    assert (tuv[~on, 0] == np.finfo(np.float64).max).all()
+    inside = (rays[:, :3] ** 2).sum(axis=1) <= near_R * near_R
+    dropped_total = 0
+    for i in range(n):
+        b = (i // 64) * 64
+        for j in range(b, min(b + 64, n)):
+            ok, _ = pt.intersect_sphere(rays[i], cen[j], rad[j])
+            for f in range(3):
+                kept = (int(keep[i, f]) >> (j - b)) & 1
+                assert kept or not ok, f"filter form {f} dropped sphere {j} for ray {i}, which the exact test accepts"
+                dropped_total += (not kept) and f == 0
+            if not inside[i]:
+                assert all((int(keep[i, f]) >> (j - b)) & 1 for f in range(3))  # far origins skip the filter
+    assert dropped_total > 0.5 * n * 64 * 0.5, "the filter should reject most non-hitting pairs"
+
+
+@pytest.mark.parametrize("near_R", [64.0, 3.0e4])
+def test_device_triangle_known_answers(gpu, pt, near_R):
+    """700 (ray, triangle) cases from the reference's compiled intersect_triangle() -- aimed at edges /
+    vertices, parallel to the plane (raytracer.c:120-174) -- through the kernel's exact_triangle: hit
+    flags, t and the texture coordinates blended from its barycentrics BIT-equal; the filter (bounding
+    spheres) never drops an accepted pair."""
+    pr = np.load(GOLD + "/primitives.npz", allow_pickle=False)
+    rays, verts = pr["tri_ray"], pr["tri_verts"].reshape(-1, 3, 5)
+    n = len(rays)
+    pos = verts[:, :, :3].reshape(n, 9)
+    hit, tuv, keep = _selftest_intersect(1, rays, pos, near_R)
+    assert np.array_equal(hit, pr["tri_hit"])
+    on = hit.astype(bool)
+    assert np.array_equal(tuv[on, 0], pr["tri_tuv"][on, 0])
+    # raytracer.c:154-167: tex = (st0 * (1 - u - v) + st1 * u) + st2 * v, as the render kernels blend it
+    u, v = tuv[:, 1], tuv[:, 2]
+    st = verts[:, :, 3:]
+    w0 = 1 - u - v
+    tex = (st[:, 0] * w0[:, None] + st[:, 1] * u[:, None]) + st[:, 2] * v[:, None]
+    assert np.array_equal(tex[on], pr["tri_tuv"][on, 1:])
+    n_kept = 0
+    for i in range(n):
+        b = (i // 64) * 64
+        for j in range(b, min(b + 64, n)):
+            ok, _ = pt.intersect_triangle(rays[i], pr["tri_verts"][j])
+            assert int(keep[i, 0]) == 2 ** 64 - 1  # the sign-test form is for spheres only
+            for f in (1, 2):
+                kept = (int(keep[i, f]) >> (j - b)) & 1
+                assert kept or not ok, f"filter form {f} dropped triangle {j} for ray {i}, which the exact test accepts"
+                n_kept += kept
+    if near_R < 100:  # (at near_R = 3e4 the d2 tolerance, 32 e near_R^2 ~ 1.7e3, lets nearly every pair through)
+        assert n_kept < 0.8 * 2 * n * 64
+
+
+def test_device_intersect_selftest_edge_cases(gpu):
+    """ragged counts (not a multiple of the 64-case block), a single case, n = 0"""
+    pr = np.load(GOLD + "/primitives.npz", allow_pickle=False)
+    rays, cen, rad = pr["sph_ray"], pr["sph_center"], pr["sph_radius"]
+    full = _selftest_intersect(0, rays, np.concatenate([cen, rad[:, None]], axis=1), 64.0)
+    for n in (1, 63, 65, 130):
+        part = _selftest_intersect(0, rays[:n], np.concatenate([cen[:n], rad[:n, None]], axis=1), 64.0)
+        assert np.array_equal(part[0], full[0][:n]) and np.array_equal(part[1], full[1][:n])
+    _selftest_intersect(0, rays[:0], np.zeros((0, 4)), 64.0)
+
+
+def test_two_cameras_of_one_scene_on_two_streams(gpu):
+    """The camera-dependent tables (filter thresholds, fp32 hierarchy boxes: functions of near_R) are
+    kept per (scene, near_R) and immutable once built, so launches of ONE scene with different cameras
+    on different streams cannot disturb each other: concurrent == sequential, bit for bit.  More
+    cameras than table sets (8) exercises the recycling path."""
+    import torch
+    from rt_amd import scene as S
+    for cfg, w, h, spp in [(4, 160, 96, 8), (5, 96, 56, 2)]:
+        sc = S.build_scene(cfg, w, h, spp)
+        gs = gpu.GpuScene(sc)
+        total = gpu.n_tiles(w, h)
+        cams = [S.make_camera(w, h, (3.0 * k - 12, 2.0 * (k % 3), 50.0 - 4 * k), (0, 0, 0)) for k in range(11)]
+        seq = []
+        for cam in cams:
+            t, t8, st = gs.render_tiles(SEED, 0, 1, total, camera=cam)
+            torch.cuda.synchronize()
+            seq.append((t.clone(), t8.clone(), st.clone()))
+        assert not torch.equal(seq[0][0], seq[1][0])
+        gs.close()
+        gs = gpu.GpuScene(sc)  # fresh table cache
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        out = []
+        for k, cam in enumerate(cams):
+            with torch.cuda.stream(streams[k % 3]):
+                out.append(gs.render_tiles(SEED, 0, 1, total, camera=cam))
+        torch.cuda.synchronize()
+        for (t, t8, st), (a, a8, ast) in zip(out, seq):
+            assert torch.equal(t, a) and torch.equal(t8, a8) and torch.equal(st, ast)
+        gs.close()
+        sc.free()
+
+
+def test_nan_samples_poison_the_pixel_in_every_kernel_family(gpu):
+    """A sample that turns NaN must make its pixel NaN (float) / 255 (byte: CLAMP(NaN) = 1,
+    raytracer.c:218) whichever kernel family renders the scene: the pooled kernels sum samples as
+    integers and flag NaN samples apart (finish_pixels), the static ones sum in fp64.  The scene: the
+    camera sits at the centre of a sphere so small that the hit point rounds onto the centre, the
+    normal is normalize(0) = 0 * inf = NaN.  (The reference itself stops there: assert(m > 0) in
+    vec3_normalize, vector.h:56 -- which is why this test has no oracle side.)"""
+    import torch
+    from rt_amd import abi, scene as S
+    c = (1.0e9, 1.0e9, 1.0e9)
+    base = [dict(flags=abi.M_DEFAULT, radius=2.0e-8, center=c, color=(0.5, 0.4, 0.3), emission=(0.3, 0.2, 0.1)),
+            dict(flags=abi.M_DEFAULT, radius=5.0, center=(0, 0, 0), color=(0.7, 0.7, 0.7))]
+    glass = dict(flags=abi.M_REFRACTION, radius=1.0, center=(-3.0e9, 5.0e9, 0), color=(0.9, 0.9, 0.9))  # never reached
+    results = []
+    for objs, chunks in ((base, 1), (base, 2), (base + [glass], 1)):
+        sc = S.custom_scene(objs, 24, 16, 2, 4, c, (0, 0, 0))
+        gs = gpu.GpuScene(sc)
+        assert ("_refr" in gs.kernel_name()) == (len(objs) == 3)
+        total = gpu.n_tiles(24, 16)
+        t, t8, st = gs.render_tiles(SEED, 0, 1, total, chunks=chunks, samples=2 if chunks == 1 else 4)
+        torch.cuda.synchronize()
+        results.append((t.cpu().numpy(), t8.cpu().numpy(), st.cpu().tolist()))
+        gs.close()
+    pooled, chunked, static = results
+    nan = np.isnan(pooled[0])
+    assert nan.any() and not nan.all(), "the scene should give both NaN and finite pixels"
+    assert (pooled[1][nan] == 255).all()
+    assert np.array_equal(nan, np.isnan(static[0])), "pooled and static kernels disagree on which pixels are NaN"
+    assert np.allclose(pooled[0][~nan], static[0][~nan], rtol=1e-6, atol=0) and np.array_equal(pooled[1], static[1])
+    assert pooled[2][:2] == static[2][:2]  # rays, casts (tests differ: the static scene has one more sphere)
+    # chunked render of 4 spp: flags travel through the workspace; more samples, more NaN pixels
+    nan4 = np.isnan(chunked[0])
+    assert nan4.any() and (chunked[1][nan4] == 255).all() and (nan4 | ~nan).all()

@@ -22,16 +22,17 @@ def tile_pixels(width, height, tiles):
     return np.array(out, dtype=np.uint32)
 
 
-def assert_parity(gpu_img, gpu_img8, gpu_stats, mean, rgb8, stats, what=""):
-    """gpu_img: (...,3) float32 linear; mean: same pixels, float64 oracle"""
+def assert_parity(gpu_img, gpu_img8, gpu_stats, mean, rgb8, stats, what="", hdr=False):
+    """gpu_img: (...,3) float32 linear; mean: same pixels, float64 oracle.
+    The bar is the north star's ABSOLUTE 1e-4 per-channel RMS.  hdr=True (the fuzz scenes only, which
+    ask for it explicitly) scales it with the largest value compared: a float32 framebuffer cannot
+    hold 1e-4 absolute for the 1e5..1e6 radiances the reference's "fresnel" weights and HDR emitters
+    produce there (6e-8 relative = 0.06 absolute at 1e6)."""
     g = np.asarray(gpu_img, dtype=np.float64).reshape(-1, 3)
     m = np.asarray(mean).reshape(-1, 3)
     assert g.shape == m.shape
     rms = channel_rms(g, m)
-    # the north-star bar is absolute and presumes O(1) radiance; a float32 framebuffer cannot hold
-    # it for the 1e5..1e6 values the reference's "fresnel" weights produce in some fuzz scenes
-    # (6e-8 relative = 0.06 absolute at 1e6), so the bar scales with the largest value compared
-    rms_tol = RMS_TOL * max(1.0, float(np.abs(m).max()))
+    rms_tol = RMS_TOL * (max(1.0, float(np.abs(m).max())) if hdr else 1.0)
     assert (rms <= rms_tol).all(), f"{what}: per-channel RMS {rms} > {rms_tol}"
     # much tighter than the north-star bar: only the float32 store (6e-8 relative) and the
     # fixed-point pixel sums of pt_render_tiles (absolute resolution <= (depth+2) * max

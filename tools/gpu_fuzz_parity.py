@@ -31,7 +31,7 @@ for k in range(first, first + count):
             continue
         mean, rgb8, ost = pt.render_pixels(sc, 1666943821 + k, integrator=integrator)
         try:
-            assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"scene {k} {integrator}")
+            assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"scene {k} {integrator}", hdr=True)
         except AssertionError as e:
             bad += 1
             print("FAIL", e)

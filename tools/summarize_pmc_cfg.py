@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Collects tools/gpu_pmc_cfg.sh's outputs (gpurun_out/cfg<C>_<tag>/) into profiles/<tag>_c<C>_*:
+the bench JSON line, rocprofv3 --stats summary and a PMC summary of the dominant render kernel.
+usage: python tools/summarize_pmc_cfg.py r02a 5"""
+import collections, csv, glob, json, os, shutil, sys
+tag, cfg_n = sys.argv[1], int(sys.argv[2])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D, P = os.path.join(ROOT, "gpurun_out", f"cfg{cfg_n}_{tag}"), os.path.join(ROOT, "profiles")
+bench = json.loads(open(f"{D}/bench.log").read().strip().splitlines()[-1])
+kernel = bench["roofline"]["kernel"]
+vals = collections.OrderedDict()
+for f in sorted(glob.glob(f"{D}/pmc_*/*/*_counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        if row["Kernel_Name"] != kernel:
+            continue
+        vals.setdefault(row["Counter_Name"], []).append(
+            (float(row["Counter_Value"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6))
+casts = bench["ray_bounces_per_step"]
+v = vals
+ms = v["SQ_INSTS_VALU"][-1][1]
+clk = v["GRBM_GUI_ACTIVE"][-1][0] / 8 / (v["GRBM_GUI_ACTIVE"][-1][1] * 1e-3)
+busy = v["SQ_ACTIVE_INST_VALU"][-1][0] * 4 / 1024 / (v["GRBM_GUI_ACTIVE"][-1][0] / 8)
+util = v["SQ_THREAD_CYCLES_VALU"][-1][0] / (v["SQ_ACTIVE_INST_VALU"][-1][0] * 64)
+fetch_kb, write_kb = v["FETCH_SIZE"][-1][0], v["WRITE_SIZE"][-1][0]
+traffic = (2 * fetch_kb + write_kb) * 1024
+cfg = bench["config"]
+lines = [
+    f"kernel {kernel}, {cfg['workload']}, per launch",
+    f"kernel time              {ms:.2f} ms",
+    f"effective clock          {clk / 1e9:.3f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)",
+    f"VALU busy                {busy * 100:.1f} % (SQ_ACTIVE_INST_VALU [quad-cycles] * 4 / 1024 SIMDs / cycles; >= 100 % = saturated)",
+    f"VALU lane utilisation    {util * 100:.1f} % (SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64))",
+    f"VALU wave-instructions   {v['SQ_INSTS_VALU'][-1][0]:.4g} = {v['SQ_INSTS_VALU'][-1][0] / casts * 64:.0f} per 64 ray-bounces",
+    f"LDS wave-instructions    {v['SQ_INSTS_LDS'][-1][0]:.4g} = {v['SQ_INSTS_LDS'][-1][0] / casts * 64:.0f} per 64 ray-bounces",
+    f"SALU wave-instructions   {v['SQ_INSTS_SALU'][-1][0]:.4g} = {v['SQ_INSTS_SALU'][-1][0] / casts * 64:.0f} per 64 ray-bounces",
+    f"HBM read  (FETCH_SIZE)   {fetch_kb:.1f} KB; x2 (gfx950 correction for wide coalesced streams) = {2 * fetch_kb / 1024:.2f} MB",
+    f"HBM write (WRITE_SIZE)   {write_kb / 1024:.2f} MB (algorithmic output: {15 * cfg['width'] * cfg['height'] / 1e6:.2f} MB)",
+    f"HBM traffic              {traffic / 1e6:.1f} MB per launch -> {traffic / (ms * 1e-3) / 1e9:.3f} GB/s = {traffic / (ms * 1e-3) / 8e12:.2e} of 8 TB/s",
+    "", "raw counters (value (kernel ms)), separate rocprofv3 --pmc passes:"]
+lines += [f"{k:24s} " + "  ".join("%.5g (%.2f ms)" % x for x in vv) for k, vv in vals.items()]
+pre = f"{P}/{tag}_c{cfg_n}"
+open(f"{pre}_pmc.txt", "w").write("\n".join(lines) + "\n")
+json.dump({"kernel": kernel, "config": cfg_n, "width": cfg["width"], "height": cfg["height"], "spp": cfg["spp"],
+           "n_gpus": 1, "traffic_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+           "valu_busy": busy, "lane_utilisation": util, "valu_instr_per_64_bounces": v["SQ_INSTS_VALU"][-1][0] / casts * 64,
+           "effective_clock_ghz": clk / 1e9,
+           "method": "rocprofv3 --pmc, one counter group per pass with --kernel-trace only (tools/gpu_pmc_cfg.sh); traffic = "
+                     "(2*FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md",
+           "source": f"profiles/{tag}_c{cfg_n}_pmc.txt"}, open(f"{P}/pmc_c{cfg_n}.json", "w"), indent=1)
+json.dump(bench, open(f"{pre}_bench.json", "w"))
+st = glob.glob(f"{D}/prof/*/*_kernel_stats.csv")[0]
+shutil.copy(st, f"{pre}_kernel_stats.csv")
+print("\n".join(lines[:12]))
