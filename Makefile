@@ -56,3 +56,10 @@ clean:
 	$(MAKE) -C $(ROOT)oracle clean
 
 .PHONY: all shim shim-diag host oracle clean
+
+# development: alternative builds of the shim for A/B runs (tools/gpu_ab.py), e.g.
+#   make variant NAME=tri4 DEFS="-DPT_MIN_WAVES_TRI=4"   ->  raytracer.c_amd/csrc/variants/librt_hip_tri4.so
+variant:
+	@mkdir -p $(CSRC)/variants
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o $(CSRC)/variants/librt_hip_$(NAME).so $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl
+.PHONY: variant

@@ -15,15 +15,26 @@ barrier + synchronize, MAX over ranks.
 
 The JSON line also carries
   roofline      fp64-VALU roofline of the render kernel (the binding roof of this branchy
-                fp64 path, BASELINE.md section 4) from HIP-event kernel times measured here;
+                fp64 path) from HIP-event kernel times measured here.
+                `achieved` counts SURVEY section 8d's ALGORITHMIC flops (what the reference's
+                scan would execute), not executed fp64 instructions -- the kernel's packed-fp32
+                filter skips most exact tests -- so the hardware-true statement rides along:
+                VALU busy / lane utilisation / VALU instructions per 64 ray-bounces from the
+                committed PMC pass of this configuration (profiles/pmc_c<N>.json);
   roofline_hbm  the same launch against the HBM roof (reported because the north star asks
                 for it; ~1e-5 by construction);
   cpu_baseline  the reference's own compiled trace_path()/intersect() (oracle/_ref) timed on
-                this host's cores over a bounded sample of the same frame (rank 0, N = 1 only).
+                this host's cores over a bounded sample of the same frame (rank 0, N = 1 only);
+  configs       (N = 1) the other BASELINE configurations on the same GPU: 1, 2, 3 at full size,
+                5 at a stated reduced spp -- ms per frame, ray-bounces/s, kernel, model fraction;
+  phase_ms, ranks_seen, rank_kernel_ms, host_path   (N > 1) where a frame's time goes, how many
+                ranks RCCL really connected, and the single-process C path
+                (rt_hip_render_image over N devices) timed in a child process.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,23 +44,59 @@ sys.path.insert(0, os.path.join(ROOT, "raytracer.c_amd"))
 SEED = 1666943821            # reference main.c:182
 PEAK_FP64_TFLOPS = 39.3      # 256 CU x 4 SIMD x 16 fp64 lanes x 2.4 GHz, one op per lane-slot (no FMA credit)
 PEAK_HBM_GBS = 8000.0
+FLOPS_NOTE = ("algorithmic model flops (SURVEY 8d: 17 per sphere test + 40 per triangle test + 120 per ray-bounce, no FMA "
+              "credit), NOT executed fp64 instructions: the packed-fp32 filter / the hierarchy skip most exact tests, so "
+              "`frac` says how fast the reference's work gets done, not how full the fp64 pipe is; see valu_busy / "
+              "lane_utilisation for the hardware-true picture")
 
 
-def measured_traffic(config, width, height, spp, world):
-    """HBM bytes per launch from the committed PMC passes (profiles/), when this run is the
-    profiled configuration; None otherwise (PMC counters cannot be collected from inside)."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_c4.json")))
-        if (rec["config"], rec["width"], rec["height"], rec["spp"], rec["n_gpus"]) == (config, width, height, spp, world):
-            return rec["traffic_bytes_per_launch"]
-    except Exception:
-        pass
+def committed_pmc(config, width, height, spp, world):
+    """The committed PMC summary of this exact configuration (profiles/pmc_c<N>.json, written by
+    tools/summarize_pmc*.py from separate rocprofv3 --pmc passes), or None: PMC counters cannot be
+    collected from inside the benchmark process."""
+    for name in (f"pmc_c{config}.json", "traffic_c4.json" if config == 4 else None):
+        if not name:
+            continue
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if (rec["config"], rec["width"], rec["height"], rec["spp"], rec["n_gpus"]) == (config, width, height, spp, world):
+                rec["file"] = "profiles/" + name
+                return rec
+        except Exception:
+            pass
     return None
 
 
 def flops_per_ray(n_spheres, n_triangles):
     """SURVEY.md section 8d counting convention (add/sub/mul/div/sqrt = 1, no FMA credit)."""
     return 17.0 * n_spheres + 40.0 * n_triangles + 120.0
+
+
+def host_cpus():
+    """(logical CPUs of the host, CPUs this process may use): the second is what a worker pool
+    should be sized by -- the scheduler affinity mask capped by the cgroup CPU quota."""
+    nproc = os.cpu_count() or 1
+    usable = nproc
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    try:  # cgroup v2
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return nproc, usable, quota
 
 
 # ---- CPU baseline: the compiled reference on a bounded sample -----------------------------
@@ -69,10 +116,10 @@ def _cpu_worker(args):
     return casts, st["rays"]
 
 
-def cpu_baseline(config, width, height, spp, depth, n_meshes, budget_tiles):
+def cpu_baseline(config, width, height, spp, depth, n_meshes, budget_tiles, workers):
     """Times the CPU checker on `budget_tiles` 8x8 tiles spread evenly over the frame at full
-    spp, one single-threaded process per core (processes, not threads: the reference's global
-    counters make its threads slower)."""
+    spp, one single-threaded process per usable core (processes, not threads: the reference's
+    global counters make its threads slower)."""
     import multiprocessing as mp
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -89,7 +136,8 @@ def cpu_baseline(config, width, height, spp, depth, n_meshes, budget_tiles):
                 if x0 + c < width and y0 + r < height:
                     px.append((y0 + r) * width + x0 + c)
     px = np.array(px, dtype=np.uint32)
-    cores = min(os.cpu_count() or 1, 64)
+    nproc, usable, quota = host_cpus()
+    cores = workers or usable
     chunks = [px[i::cores] for i in range(cores)]  # interleaved: even load
     jobs = [(config, width, height, spp, depth, ch, kind) for ch in chunks if len(ch)]
     ctx = mp.get_context("spawn")
@@ -100,8 +148,10 @@ def cpu_baseline(config, width, height, spp, depth, n_meshes, budget_tiles):
         dt = time.perf_counter() - t0
     casts = sum(r[0] for r in res)
     return {"value": casts / dt, "unit": "ray-bounces/s", "cores": len(jobs), "kind": kind,
+            "host_nproc": nproc, "host_usable_cpus": usable, "host_cgroup_cpu_quota": quota,
             "sample": f"{len(tiles)} of {total} 8x8 tiles ({len(px)} pixels) at full {spp} spp, "
-                      f"{len(jobs)} single-thread processes, {dt:.1f} s wall",
+                      f"{len(jobs)} single-thread processes (host: {nproc} logical CPUs, {usable} usable by this "
+                      f"process), {dt:.1f} s wall",
             "mpixel_samples_per_s": len(px) * spp / dt * 1e-6}
 
 
@@ -117,7 +167,7 @@ def cpu_as_shipped():
     sc = S.build_scene(4, 320, 180, 16, max_depth=5)
     small = S.build_scene(4, 160, 90, 16, max_depth=5)
     ref = oracle_py.RefOracle(5)
-    threads = min(os.cpu_count() or 1, 64)
+    threads = host_cpus()[1]
     devnull = os.open(os.devnull, os.O_WRONLY)       # render() prints a progress bar
     saved = os.dup(1)
     os.dup2(devnull, 1)
@@ -145,6 +195,102 @@ def cpu_as_shipped():
                                     f"threads, {dt_all:.1f} s (racy counters: the count is approximate)"}}
 
 
+# ---- the other configurations, one GPU -----------------------------------------------------
+
+def config_line(cfg, spp, steps, dev):
+    """One BASELINE configuration on this GPU: `steps` full frames, kernel time by HIP events."""
+    import torch
+    from rt_amd import abi, gpu as G, scene as S
+    sc = S.build_scene(cfg, samples=spp or None)
+    gs = G.GpuScene(sc, device=dev.index)
+    total = G.n_tiles(sc.width, sc.height)
+    chunks = gs.suggest_chunks(total)
+    tiles = torch.empty((total, abi.TILE_PIXELS, 3), dtype=torch.float32, device=dev)
+    tiles8 = torch.empty((total, abi.TILE_PIXELS, 3), dtype=torch.uint8, device=dev)
+    stats = torch.zeros(abi.NSTATS, dtype=torch.int64, device=dev)
+    gs.render_tiles(SEED, 0, 1, total, tiles, tiles8, stats, chunks=chunks)      # warm
+    torch.cuda.synchronize(dev)
+    stats.zero_()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        gs.render_tiles(SEED, 0, 1, total, tiles, tiles8, stats, chunks=chunks)
+        b.record()
+    torch.cuda.synchronize(dev)
+    ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    rays, casts, tests, samples = [int(v) / steps for v in stats.cpu().tolist()]
+    fr = flops_per_ray(sc.n_objects, sc.n_triangles)
+    line = {"config": cfg, "workload": f"BASELINE configs[{cfg - 1}]: {sc.width}x{sc.height}, {sc.samples} spp, "
+                                       f"{sc.n_objects} spheres + {sc.n_triangles} triangles, depth {sc.max_depth}",
+            "kernel": gs.kernel_name(), "kernel_ms": ms, "ray_bounces_per_s": casts / (ms * 1e-3),
+            "mpixel_samples_per_s": samples / (ms * 1e-3) * 1e-6, "rays_per_sample": rays / max(samples, 1),
+            "flops_per_ray_bounce": fr, "frac": casts * fr / (ms * 1e-3) * 1e-12 / PEAK_FP64_TFLOPS}
+    nominal = S.scene_info(cfg).samples
+    if sc.samples != nominal:
+        line["note"] = f"reduced spp: the configuration's own is {nominal}"
+    if sc.n_triangles > 256:
+        line["note"] = (line.get("note", "") + "; " if "note" in line else "") + \
+            "frac > 1 is expected: the hierarchy legitimately skips most of the model's O(N) triangle tests"
+    if ms < 0.3:
+        line["note"] = (line.get("note", "") + "; " if "note" in line else "") + "launch-bound at this size"
+    gs.close()
+    sc.free()
+    return line
+
+
+# ---- the single-process C path: rt_hip_render_image over N devices ---------------------------
+
+def host_path_main(args):
+    """Child mode (--host-path): ONE process drives N devices through rt_hip_render_image()
+    (grouped RCCL send/recv to device 0 inside the shim): what the C host's render() does."""
+    import torch  # noqa: F401  (one HIP runtime: load it before the shim)
+    from rt_amd import abi, gpu as G, scene as S
+    shim = abi.load_shim()
+    have = shim.rt_hip_device_count()
+    n = args.gpus
+    if have < n:
+        print(json.dumps({"host_path": {"error": f"{have} devices visible, {n} requested"}}))
+        return 0
+    sc = S.build_scene(args.config, args.width or None, args.height or None, args.spp or None)
+    out = {"n_devices": n, "workload": f"{sc.width}x{sc.height}, {sc.samples} spp"}
+    times, kernel_s = [], []
+    ref_img = None
+    for k in range(args.warmup + args.steps):
+        t0 = time.perf_counter()
+        img, img8, st, secs = G.render_image_host(sc, SEED, n_devices=n)
+        dt = time.perf_counter() - t0
+        if k >= args.warmup:
+            times.append(dt)
+            kernel_s.append(secs)
+        if ref_img is None:
+            ref_img = img
+    out["call_ms"] = [t * 1e3 for t in times]           # incl. scene upload, D2H of the frame, PCIe
+    out["kernel_ms"] = [t * 1e3 for t in kernel_s]      # render kernels, max over devices
+    out["ray_bounces_per_s"] = st["casts"] / min(times)
+    if n > 1:  # the assembled frame must equal the one-device frame bit for bit
+        one, _, st1, _ = G.render_image_host(sc, SEED, n_devices=1)
+        out["equals_one_device_frame"] = bool((one == ref_img).all()) and st1 == st
+    print(json.dumps({"host_path": out}), flush=True)
+    return 0
+
+
+def run_host_path_child(args, n, timeout_s=240):
+    cmd = [sys.executable, os.path.abspath(__file__), "--host-path", "--gpus", str(n), "--steps", "2", "--warmup", "1",
+           "--config", str(args.config), "--spp", str(args.spp), "--width", str(args.width), "--height", str(args.height)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        for ln in reversed(p.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)["host_path"]
+        return {"error": f"rc {p.returncode}: {(p.stderr or p.stdout)[-400:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout_s} s"}
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 # ---- main ------------------------------------------------------------------------------
 
 def main():
@@ -158,9 +304,15 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--chunks", type=int, default=0, help="sample chunks per tile (0 = rt_hip_suggest_chunks)")
     ap.add_argument("--shard", type=str, default="", help="dev: render only rank R of a W-way partition, 'R/W', on this one GPU")
-    ap.add_argument("--cpu-tiles", type=int, default=384, help="8x8 tiles of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-tiles", type=int, default=2048, help="8x8 tiles of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the CPU baseline (0 = the CPUs this process may use)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration array")
+    ap.add_argument("--c5-spp", type=int, default=64, help="spp of config 5 in the per-configuration array (its own: 4096)")
+    ap.add_argument("--host-path", action="store_true",
+                    help="single process: time rt_hip_render_image() over --gpus devices (the C host's path) and exit")
     args = ap.parse_args()
+    if args.host_path:
+        return host_path_main(args)
 
     import torch
     import torch.distributed as dist
@@ -187,6 +339,15 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    # a CPU-side group for waits during which the GPUs must stay idle (an RCCL barrier is a spinning kernel)
+    ctrl = dist.new_group(backend="gloo") if world > 1 else None
+
+    # how many ranks the backend really connected: an all-reduce of ones
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int32, device="cpu" if rehearse else dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
 
     sc = S.build_scene(args.config, args.width or None, args.height or None, args.spp or None)
     W, H, spp, depth = sc.width, sc.height, sc.samples, sc.max_depth
@@ -208,21 +369,22 @@ def main():
     if world > 1 and rank == 0:
         gathered = [torch.empty_like(tiles) for _ in range(world)]
         gathered8 = [torch.empty_like(tiles8) for _ in range(world)]
-    kernel_events = []
+    phase_events = []   # per timed step: (render start, render end, gather end, untile end)
 
     def step(timed):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()                                    # same stream the shim launches on
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()                                 # same stream the shim launches on
         gs.render_tiles(SEED, first, stride, count, tiles, tiles8, stats, chunks=chunks, workspace=workspace)
-        e1.record()
-        if timed:
-            kernel_events.append((e0, e1))
+        ev[1].record()
         # RCCL over xGMI when world > 1: the one exchange of the path
         parts, parts8 = D.gather_tiles(tiles, tiles8, rank, world, gathered, gathered8, via_cpu=rehearse)
+        ev[2].record()
         if rank == 0:
             for r, f, s_, c in D.segments(W, H, world):
                 gs.untile(parts[r], parts8[r], f, s_, c, image, image8)
+        ev[3].record()
+        if timed:
+            phase_events.append(ev)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -241,28 +403,34 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)],
-                           dtype=torch.float64, device=dev)
-    tot = stats.clone()
-    if rehearse:
-        t, kern_ms, tot = t.cpu(), kern_ms.cpu(), tot.cpu()
+    n_ev = max(len(phase_events), 1)
+    phases = [sum(ev[k].elapsed_time(ev[k + 1]) for ev in phase_events) / n_ev for k in range(3)]  # render, gather, untile
+    cdev = "cpu" if rehearse else dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    ph = torch.tensor(phases, dtype=torch.float64, device=cdev)
+    tot = stats.clone().to(cdev)
+    per_rank = [ph.clone() for _ in range(world)] if world > 1 else [ph]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, ph)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    kern_s = float(kern_ms.item()) * 1e-3
+    rank_phase = [[float(v) for v in p.cpu().tolist()] for p in per_rank]
+    kern_s = max(p[0] for p in rank_phase) * 1e-3
     rays, casts, tests, samples = [int(v) for v in tot.cpu().tolist()]
 
+    rc = 0
     if rank == 0:
         steps = max(args.steps, 1)
         casts_per_step = casts / steps
         fr = flops_per_ray(sc.n_objects, sc.n_triangles)
-        # dominant kernel = pt_render_tiles; its work per launch on the slowest rank ~ 1/world of the frame
+        # dominant kernel; its work per launch on the slowest rank ~ 1/world of the frame
         launch_casts = casts_per_step / world
         achieved_tflops = launch_casts * fr / kern_s * 1e-12 if kern_s > 0 else 0.0
         alg_bytes = (12 + 3) * W * H / world + 88 * sc.n_objects + 72 * sc.n_triangles
+        pmc = committed_pmc(args.config, W, H, spp, world)
+        pmc_source = (f"committed PMC pass ({pmc.get('source', pmc['file'])}; rocprofv3 --pmc, separate passes; "
+                      "FETCH_SIZE doubled per the gfx950 correction)") if pmc else None
         out = {
             "metric": "ray-bounces/sec", "value": casts / elapsed, "unit": "ray-bounces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -280,32 +448,67 @@ def main():
             "intersection_tests_per_s": tests / elapsed,
             "roofline": {"bound": "valu_fp64", "kernel": gs.kernel_name(), "achieved": achieved_tflops,
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_TFLOPS,
-                         "traffic": measured_traffic(args.config, W, H, spp, world), "flops_per_ray_bounce": fr,
-                         "kernel_ms": kern_s * 1e3,
+                         "flops": FLOPS_NOTE, "flops_per_ray_bounce": fr, "kernel_ms": kern_s * 1e3,
+                         "traffic": pmc["traffic_bytes_per_launch"] if pmc else None, "traffic_source": pmc_source,
+                         "valu_busy": pmc.get("valu_busy") if pmc else None,
+                         "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
+                         "valu_instr_per_64_bounces": pmc.get("valu_instr_per_64_bounces") if pmc else None,
+                         "source": pmc_source,
                          "note": "branchy fp64 scalar-per-lane math: neither HBM nor MFMA binds it "
-                                 "(BASELINE.md section 4); algorithmic flops, no FMA credit"},
-            "roofline_hbm": {"bound": "hbm", "kernel": "pt_render_tiles",
+                                 "(BASELINE.md section 4); kernel_ms by HIP events on the launch stream"},
+            "roofline_hbm": {"bound": "hbm", "kernel": gs.kernel_name(),
                              "achieved": alg_bytes / kern_s * 1e-9 if kern_s > 0 else 0.0, "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": (alg_bytes / kern_s * 1e-9 / PEAK_HBM_GBS) if kern_s > 0 else 0.0,
-                             "traffic": measured_traffic(args.config, W, H, spp, world),
-                             "traffic_source": "profiles/traffic_c4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                             "traffic": pmc["traffic_bytes_per_launch"] if pmc else None, "traffic_source": pmc_source,
                              "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if world > 1:
+            out["ranks_seen"] = ranks_seen
+            out["phase_ms"] = {"render": max(p[0] for p in rank_phase), "gather": max(p[1] for p in rank_phase),
+                               "untile": rank_phase[0][2],
+                               "note": "HIP events per rank around each phase, averaged over the timed steps; render / "
+                                       "gather = max over ranks (a rank's gather includes waiting for the slowest "
+                                       "renderer), untile = rank 0"}
+            out["rank_kernel_ms"] = {"min": min(p[0] for p in rank_phase), "max": max(p[0] for p in rank_phase),
+                                     "per_rank": [p[0] for p in rank_phase]}
+            if ranks_seen != args.gpus:
+                out["error"] = f"the backend connected {ranks_seen} ranks, --gpus asked for {args.gpus}"
+                rc = 3
+        if world == 1 and not args.no_configs and not args.shard:
+            lines = []
+            for cfg, cspp in ((1, 0), (2, 0), (3, 0), (5, args.c5_spp)):
+                if cfg == args.config:
+                    continue
+                try:
+                    lines.append(config_line(cfg, cspp, 3, dev))
+                except Exception as exc:
+                    lines.append({"config": cfg, "error": repr(exc)})
+            out["configs"] = lines
         if world == 1 and args.cpu_tiles > 0:
             try:
                 if args.config == 4:
                     out["cpu_as_shipped"] = cpu_as_shipped()
-                out["cpu_baseline"] = cpu_baseline(args.config, W, H, spp, depth, sc.n_meshes, args.cpu_tiles)
+                out["cpu_baseline"] = cpu_baseline(args.config, W, H, spp, depth, sc.n_meshes, args.cpu_tiles, args.cpu_workers)
             except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "ray-bounces/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {exc}"}
+
+    # N > 1 on real GPUs: the single-process C path (rt_hip_render_image over N devices, grouped RCCL
+    # send/recv inside the shim) in a child of rank 0 while every rank idles at the barrier below -- so it
+    # runs whenever more than one GPU is present.  A failure or time-out is reported, never fatal.
+    if world > 1 and not rehearse and os.environ.get("RT_BENCH_HOST_PATH", "1") != "0":
+        if rank == 0:
+            out["host_path"] = run_host_path_child(args, world)
+        dist.barrier(group=ctrl)
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     gs.close()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

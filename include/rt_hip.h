@@ -208,7 +208,7 @@ void rt_hip_set_cancel_flag(const volatile int *flag);
 
 /* Renders width x height on n_devices GPUs of this process (tiles interleaved
  * over devices, tile buffers gathered onto device 0 with RCCL when
- * n_devices > 1), then copies to the host.  h_image_rgb (w*h*3 floats) and
+ * n_devices > 1), then copies to the host.  Calls are serialised (one frame at a time).  h_image_rgb (w*h*3 floats) and
  * h_image_rgb8 (w*h*3 bytes) may each be NULL.  h_stats: RT_HIP_NSTATS values,
  * overwritten.  kernel_seconds: device time of the render kernels (max over
  * devices), may be NULL.  params->tile_* are ignored. */
@@ -216,6 +216,13 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
                         size_t n_meshes, const RtHipCamera *camera, const RtHipParams *params,
                         int n_devices, float *h_image_rgb, uint8_t *h_image_rgb8, uint64_t *h_stats,
                         double *kernel_seconds);
+
+/* rt_hip_render_image() keeps what it built -- per-device scenes, streams, tile buffers, the RCCL
+ * communicators -- and reuses it while the device count, the image size and the scene's bytes
+ * stay the same (a caller rendering frame after frame re-creates nothing).  This releases it;
+ * rt_hip_cache_builds() counts how often a context had to be (re)built (for tests). */
+void rt_hip_release_cache(void);
+uint64_t rt_hip_cache_builds(void);
 
 #ifdef __cplusplus
 }

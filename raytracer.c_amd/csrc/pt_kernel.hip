@@ -51,6 +51,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pt_device.h"
 #include "rt_rng.h"
@@ -347,6 +348,15 @@ __device__ __forceinline__ bool bvh_probe(const float *__restrict__ nodes, uint3
  * leaves reached usually hold the closest hit and min_t prunes what lies behind it.  Leaves
  * run the exact fp64 triangle test; with the (t, index) tie rule the outcome does not depend
  * on the visiting order. */
+/* the per-lane traversal stacks: ONE array per workgroup, whichever instantiations of
+ * bvh_traverse a kernel contains (a function-local __shared__ array in the template would be
+ * allocated once per instantiation) */
+__device__ __forceinline__ uint32_t (*bvh_stack_lds())[PT_BLOCK]
+{
+  __shared__ uint32_t stack[PT_BVH_STACK][PT_BLOCK]; /* entry-major: conflict-free per wave */
+  return stack;
+}
+
 /* LAST / no_prune: scenes with M_CHECKERED materials and triangles need every triangle the ray
  * passes, not only those closer than the closest hit so far (TriLast): no pruning by min_t then. */
 template <bool LAST = false>
@@ -357,7 +367,7 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
                                              unsigned long long *diag_ptr, TriLast *last = nullptr,
                                              bool no_prune = false)
 {
-  __shared__ uint32_t stack[PT_BVH_STACK][PT_BLOCK]; /* entry-major: conflict-free per wave */
+  uint32_t (*const stack)[PT_BLOCK] = bvh_stack_lds();
   if (n_nodes == 0)
     return;
   const BvhRay R = bvh_ray(o, d);
@@ -1738,8 +1748,11 @@ PT_KERNEL_STATIC(pt_render_tiles_tri_big_refr, 1, true, true, true, false)
 
 /* cast_ray kernels: the static body with whitted_step, without a pending-ray stack (scenes with
  * a material that has both M_REFLECTION and M_REFRACTION take pt_whitted_tiles_mem) */
+#ifndef PT_MIN_WAVES_WHITTED
+#define PT_MIN_WAVES_WHITTED 4
+#endif
 #define PT_KERNEL_WHITTED(name, TRIS, FILT_LDS)                                              \
-  extern "C" __global__ __launch_bounds__(PT_BLOCK, 4) void name(const PtLaunch L)          \
+  extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_WHITTED) void name(const PtLaunch L) \
   {                                                                                         \
     render_tiles_static<1, false, true, TRIS, FILT_LDS, 1, true>(L);                        \
   }
@@ -2044,7 +2057,13 @@ hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float
 
 hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant)
 {
-  const size_t lds_bytes = pt_render_lds_bytes(launch.scene);
+  /* development knob: RT_HIP_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup, to measure how a
+   * kernel responds to fewer resident workgroups per CU */
+  static const size_t extra_lds = [] {
+    const char *e = getenv("RT_HIP_EXTRA_LDS");
+    return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)0;
+  }();
+  const size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
   typedef void (*Kernel)(const PtLaunch);
   static const Kernel family[19] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,

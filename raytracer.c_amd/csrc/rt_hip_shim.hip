@@ -435,6 +435,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
 int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes,
                       const RtHipCamera *camera, const RtHipParams *params, int n_devices, float *h_image_rgb,
                       uint8_t *h_image_rgb8, uint64_t *h_stats, double *kernel_seconds);
+void release_cache_impl();
+uint64_t cache_builds_impl();
 } // namespace
 
 extern "C" {
@@ -456,6 +458,10 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
     return fail(RT_HIP_ERUNTIME, "unexpected C++ exception in rt_hip_scene_create");
   }
 }
+
+void rt_hip_release_cache(void) { release_cache_impl(); }
+
+uint64_t rt_hip_cache_builds(void) { return cache_builds_impl(); }
 
 int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
                         size_t n_meshes, const RtHipCamera *camera, const RtHipParams *params,
@@ -975,6 +981,170 @@ int rt_hip_untile(const float *d_tiles_rgb, const uint8_t *d_tiles_rgb8, int32_t
 namespace
 {
 
+/* Everything rt_hip_render_image() needs between calls -- per device: the uploaded scene, a
+ * stream, timing events, the compact tile buffers, counters, the chunk workspace; on device 0 the
+ * gathered tiles and the row-major images; and the RCCL communicators -- is kept in one cached
+ * context and reused while the device count, the image size and the scene's bytes stay the same
+ * (an animation loop calling render() per frame re-creates nothing; ncclCommInitAll alone costs
+ * tens of milliseconds per call at 8 devices).  rt_hip_release_cache() drops it. */
+struct ImageCtx
+{
+  struct Dev
+  {
+    RtHipScene *scene = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    float *tiles = nullptr;
+    uint8_t *tiles8 = nullptr;
+    uint64_t *stats = nullptr;
+    void *ws = nullptr;
+    uint32_t count = 0;
+  };
+  int G = 0, W = 0, H = 0;
+  uint64_t scene_hash = 0;
+  std::vector<Dev> dev;
+  std::vector<ncclComm_t> comms;
+  float *all_tiles = nullptr, *image = nullptr;
+  uint8_t *all_tiles8 = nullptr, *image8 = nullptr;
+  uint64_t builds = 0; /* how many times a context was (re)built: exposed for tests */
+};
+ImageCtx g_ctx;
+std::mutex g_ctx_mutex;
+
+void ctx_release(ImageCtx &c)
+{
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  for (int g = 0; g < (int)c.dev.size(); g++)
+  {
+    (void)hipSetDevice(g);
+    ImageCtx::Dev &d = c.dev[g];
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    if (g < (int)c.comms.size() && c.comms[g]) (void)ncclCommDestroy(c.comms[g]);
+    if (d.t0) (void)hipEventDestroy(d.t0);
+    if (d.t1) (void)hipEventDestroy(d.t1);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    (void)hipFree(d.tiles);
+    (void)hipFree(d.tiles8);
+    (void)hipFree(d.stats);
+    (void)hipFree(d.ws);
+    rt_hip_scene_destroy(d.scene);
+  }
+  if (!c.dev.empty())
+  {
+    (void)hipSetDevice(0);
+    (void)hipFree(c.all_tiles);
+    (void)hipFree(c.all_tiles8);
+    (void)hipFree(c.image);
+    (void)hipFree(c.image8);
+  }
+  (void)hipSetDevice(prev);
+  const uint64_t builds = c.builds;
+  c = ImageCtx();
+  c.builds = builds;
+}
+
+/* FNV-1a over everything that defines the scene */
+uint64_t scene_fingerprint(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes)
+{
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; i++)
+      h = (h ^ b[i]) * 1099511628211ull;
+  };
+  mix(&n_spheres, sizeof n_spheres);
+  mix(&n_meshes, sizeof n_meshes);
+  for (size_t i = 0; i < n_spheres; i++)
+  { /* field by field: struct padding is not part of the scene */
+    mix(&spheres[i].flags, sizeof spheres[i].flags);
+    mix(&spheres[i].radius, sizeof(double) * 10); /* radius, center, color, emission are contiguous doubles */
+  }
+  for (size_t m = 0; m < n_meshes; m++)
+  {
+    mix(&meshes[m].flags, sizeof meshes[m].flags);
+    mix(meshes[m].color, sizeof(double) * 6); /* color, emission */
+    mix(&meshes[m].num_triangles, sizeof meshes[m].num_triangles);
+    if (meshes[m].vertices)
+      mix(meshes[m].vertices, meshes[m].num_triangles * 3 * sizeof(RtHipVertex));
+  }
+  return h;
+}
+
+#define CTX_TRY(expr)                                                                               \
+  do                                                                                                \
+  {                                                                                                 \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+    {                                                                                               \
+      int c_ = fail(e_ == hipErrorOutOfMemory ? RT_HIP_ENOMEM : RT_HIP_ERUNTIME, "%s: %s", #expr,   \
+                    hipGetErrorString(e_));                                                         \
+      ctx_release(g_ctx);                                                                           \
+      (void)hipSetDevice(prev);                                                                     \
+      return c_;                                                                                    \
+    }                                                                                               \
+  } while (0)
+
+/* makes g_ctx fit this call (device count, image size, scene); caller holds g_ctx_mutex */
+int ctx_prepare(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes, int G, int W, int H,
+                int prev)
+{
+  const uint64_t fp = scene_fingerprint(spheres, n_spheres, meshes, n_meshes);
+  ImageCtx &c = g_ctx;
+  if (c.G == G && c.W == W && c.H == H && c.scene_hash == fp && (int)c.dev.size() == G)
+    return RT_HIP_OK;
+  ctx_release(c);
+  c.builds++;
+  c.dev.resize(G);
+  c.comms.assign(G, nullptr);
+  const uint32_t n_tiles = tiles_x_of(W) * tiles_y_of(H);
+  const size_t n_px = (size_t)W * H;
+  for (int g = 0; g < G; g++)
+  {
+    ImageCtx::Dev &d = c.dev[g];
+    d.count = (n_tiles > (uint32_t)g) ? (n_tiles - g + G - 1) / G : 0;
+    int rc = rt_hip_scene_create(spheres, n_spheres, meshes, n_meshes, g, &d.scene);
+    if (rc)
+    {
+      ctx_release(c);
+      (void)hipSetDevice(prev);
+      return rc;
+    }
+    CTX_TRY(hipSetDevice(g));
+    CTX_TRY(hipStreamCreate(&d.stream));
+    CTX_TRY(hipEventCreate(&d.t0));
+    CTX_TRY(hipEventCreate(&d.t1));
+    const size_t slots = d.count ? d.count : 1;
+    CTX_TRY(hipMalloc(&d.tiles, slots * 192 * sizeof(float)));
+    CTX_TRY(hipMalloc(&d.tiles8, slots * 192));
+    CTX_TRY(hipMalloc(&d.stats, RT_HIP_NSTATS * sizeof(uint64_t)));
+  }
+  CTX_TRY(hipSetDevice(0));
+  CTX_TRY(hipMalloc(&c.image, n_px * 3 * sizeof(float)));
+  CTX_TRY(hipMalloc(&c.image8, n_px * 3));
+  if (G > 1)
+  {
+    CTX_TRY(hipMalloc(&c.all_tiles, (size_t)n_tiles * 192 * sizeof(float)));
+    CTX_TRY(hipMalloc(&c.all_tiles8, (size_t)n_tiles * 192));
+    std::vector<int> ids(G);
+    for (int g = 0; g < G; g++)
+      ids[g] = g;
+    ncclResult_t nr = ncclCommInitAll(c.comms.data(), G, ids.data());
+    if (nr != ncclSuccess)
+    {
+      int code = fail(RT_HIP_ERUNTIME, "ncclCommInitAll: %s", ncclGetErrorString(nr));
+      ctx_release(c);
+      (void)hipSetDevice(prev);
+      return code;
+    }
+  }
+  c.G = G;
+  c.W = W;
+  c.H = H;
+  c.scene_hash = fp;
+  return RT_HIP_OK;
+}
+
 int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes,
                       const RtHipCamera *camera, const RtHipParams *params, int n_devices, float *h_image_rgb,
                       uint8_t *h_image_rgb8, uint64_t *h_stats, double *kernel_seconds)
@@ -991,48 +1161,17 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     return fail(RT_HIP_ENODEV, "asked for %d devices, %d available", n_devices, have);
   const int G = n_devices;
   const int W = params->width, H = params->height;
-  const uint32_t n_tiles = tiles_x_of(W) * tiles_y_of(H);
   const size_t n_px = (size_t)W * H;
 
-  struct Dev
-  {
-    RtHipScene *scene = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    float *tiles = nullptr;
-    uint8_t *tiles8 = nullptr;
-    uint64_t *stats = nullptr;
-    void *ws = nullptr;
-    uint32_t count = 0;
-  };
-  std::vector<Dev> dev(G);
-  std::vector<ncclComm_t> comms(G, nullptr);
-  float *all_tiles = nullptr, *image = nullptr;
-  uint8_t *all_tiles8 = nullptr, *image8 = nullptr;
+  std::lock_guard<std::mutex> lock(g_ctx_mutex); /* one frame at a time: the context is shared */
   int prev = 0;
   (void)hipGetDevice(&prev);
-
-  auto cleanup = [&]() {
-    for (int g = 0; g < G; g++)
-    {
-      (void)hipSetDevice(g);
-      if (comms[g]) (void)ncclCommDestroy(comms[g]);
-      if (dev[g].t0) (void)hipEventDestroy(dev[g].t0);
-      if (dev[g].t1) (void)hipEventDestroy(dev[g].t1);
-      if (dev[g].stream) (void)hipStreamDestroy(dev[g].stream);
-      (void)hipFree(dev[g].tiles);
-      (void)hipFree(dev[g].tiles8);
-      (void)hipFree(dev[g].stats);
-      (void)hipFree(dev[g].ws);
-      rt_hip_scene_destroy(dev[g].scene);
-    }
-    (void)hipSetDevice(0);
-    (void)hipFree(all_tiles);
-    (void)hipFree(all_tiles8);
-    (void)hipFree(image);
-    (void)hipFree(image8);
-    (void)hipSetDevice(prev);
-  };
+  rc = ctx_prepare(spheres, n_spheres, meshes, n_meshes, G, W, H, prev);
+  if (rc)
+    return rc;
+  ImageCtx &c = g_ctx;
+  std::vector<ImageCtx::Dev> &dev = c.dev;
+  /* a failure below leaves the cached context in an unknown state: drop it */
 #define IMG_TRY(expr)                                                                               \
   do                                                                                                \
   {                                                                                                 \
@@ -1041,7 +1180,8 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     {                                                                                               \
       int c_ = fail(e_ == hipErrorOutOfMemory ? RT_HIP_ENOMEM : RT_HIP_ERUNTIME, "%s: %s", #expr,   \
                     hipGetErrorString(e_));                                                         \
-      cleanup();                                                                                    \
+      ctx_release(g_ctx);                                                                           \
+      (void)hipSetDevice(prev);                                                                     \
       return c_;                                                                                    \
     }                                                                                               \
   } while (0)
@@ -1049,22 +1189,9 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   /* ---- launch every device's share ---- */
   for (int g = 0; g < G; g++)
   {
-    Dev &d = dev[g];
-    d.count = (n_tiles > (uint32_t)g) ? (n_tiles - g + G - 1) / G : 0;
-    rc = rt_hip_scene_create(spheres, n_spheres, meshes, n_meshes, g, &d.scene);
-    if (rc)
-    {
-      cleanup();
-      return rc;
-    }
+    ImageCtx::Dev &d = dev[g];
     IMG_TRY(hipSetDevice(g));
-    IMG_TRY(hipStreamCreate(&d.stream));
-    IMG_TRY(hipEventCreate(&d.t0));
-    IMG_TRY(hipEventCreate(&d.t1));
     const size_t slots = d.count ? d.count : 1;
-    IMG_TRY(hipMalloc(&d.tiles, slots * 192 * sizeof(float)));
-    IMG_TRY(hipMalloc(&d.tiles8, slots * 192));
-    IMG_TRY(hipMalloc(&d.stats, RT_HIP_NSTATS * sizeof(uint64_t)));
     IMG_TRY(hipMemsetAsync(d.stats, 0, RT_HIP_NSTATS * sizeof(uint64_t), d.stream));
     IMG_TRY(hipMemsetAsync(d.tiles, 0, slots * 192 * sizeof(float), d.stream));  /* unrendered tiles stay black, */
     IMG_TRY(hipMemsetAsync(d.tiles8, 0, slots * 192, d.stream));                 /* like the reference's memset  */
@@ -1081,7 +1208,7 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   {
     for (int g = 0; g < G; g++)
     {
-      Dev &d = dev[g];
+      ImageCtx::Dev &d = dev[g];
       const uint32_t k0 = (uint32_t)(((uint64_t)d.count * slab) / n_slabs);
       const uint32_t k1 = (uint32_t)(((uint64_t)d.count * (slab + 1)) / n_slabs);
       if (k1 == k0)
@@ -1098,7 +1225,8 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
                                        d.tiles8 + (size_t)k0 * 192, d.stats, d.stream);
       if (rc)
       {
-        cleanup();
+        ctx_release(g_ctx);
+        (void)hipSetDevice(prev);
         return rc;
       }
     }
@@ -1118,46 +1246,33 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     IMG_TRY(hipEventRecord(dev[g].t1, dev[g].stream));
   }
 
-  /* ---- gather on device 0 ---- */
+  /* ---- gather on device 0: grouped point-to-point, every sender straight to the root ---- */
   IMG_TRY(hipSetDevice(0));
-  IMG_TRY(hipMalloc(&image, n_px * 3 * sizeof(float)));
-  IMG_TRY(hipMalloc(&image8, n_px * 3));
   std::vector<size_t> first_slot(G, 0);
   for (int g = 1; g < G; g++)
     first_slot[g] = first_slot[g - 1] + dev[g - 1].count;
   if (G > 1)
   {
-    IMG_TRY(hipMalloc(&all_tiles, (size_t)n_tiles * 192 * sizeof(float)));
-    IMG_TRY(hipMalloc(&all_tiles8, (size_t)n_tiles * 192));
-    std::vector<int> ids(G);
-    for (int g = 0; g < G; g++)
-      ids[g] = g;
-    ncclResult_t nr = ncclCommInitAll(comms.data(), G, ids.data());
-    if (nr != ncclSuccess)
-    {
-      int c = fail(RT_HIP_ERUNTIME, "ncclCommInitAll: %s", ncclGetErrorString(nr));
-      cleanup();
-      return c;
-    }
-    nr = ncclGroupStart();
+    ncclResult_t nr = ncclGroupStart();
     for (int g = 1; g < G && nr == ncclSuccess; g++)
     {
       if (!dev[g].count)
         continue;
       const size_t nf = (size_t)dev[g].count * 192;
-      nr = ncclSend(dev[g].tiles, nf, ncclFloat, 0, comms[g], dev[g].stream);
-      if (nr == ncclSuccess) nr = ncclSend(dev[g].tiles8, nf, ncclUint8, 0, comms[g], dev[g].stream);
-      if (nr == ncclSuccess) nr = ncclRecv(all_tiles + first_slot[g] * 192, nf, ncclFloat, g, comms[0], dev[0].stream);
-      if (nr == ncclSuccess) nr = ncclRecv(all_tiles8 + first_slot[g] * 192, nf, ncclUint8, g, comms[0], dev[0].stream);
+      nr = ncclSend(dev[g].tiles, nf, ncclFloat, 0, c.comms[g], dev[g].stream);
+      if (nr == ncclSuccess) nr = ncclSend(dev[g].tiles8, nf, ncclUint8, 0, c.comms[g], dev[g].stream);
+      if (nr == ncclSuccess) nr = ncclRecv(c.all_tiles + first_slot[g] * 192, nf, ncclFloat, g, c.comms[0], dev[0].stream);
+      if (nr == ncclSuccess) nr = ncclRecv(c.all_tiles8 + first_slot[g] * 192, nf, ncclUint8, g, c.comms[0], dev[0].stream);
     }
     ncclResult_t ne = ncclGroupEnd();
     if (nr == ncclSuccess)
       nr = ne;
     if (nr != ncclSuccess)
     {
-      int c = fail(RT_HIP_ERUNTIME, "RCCL gather: %s", ncclGetErrorString(nr));
-      cleanup();
-      return c;
+      int code = fail(RT_HIP_ERUNTIME, "RCCL gather: %s", ncclGetErrorString(nr));
+      ctx_release(g_ctx);
+      (void)hipSetDevice(prev);
+      return code;
     }
   }
   /* scatter each device's segment into the row-major image (device 0) */
@@ -1165,12 +1280,13 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   {
     if (!dev[g].count)
       continue;
-    const float *src = (g == 0) ? dev[0].tiles : all_tiles + first_slot[g] * 192;
-    const uint8_t *src8 = (g == 0) ? dev[0].tiles8 : all_tiles8 + first_slot[g] * 192;
-    rc = rt_hip_untile(src, src8, W, H, (uint32_t)g, (uint32_t)G, dev[g].count, image, image8, dev[0].stream);
+    const float *src = (g == 0) ? dev[0].tiles : c.all_tiles + first_slot[g] * 192;
+    const uint8_t *src8 = (g == 0) ? dev[0].tiles8 : c.all_tiles8 + first_slot[g] * 192;
+    rc = rt_hip_untile(src, src8, W, H, (uint32_t)g, (uint32_t)G, dev[g].count, c.image, c.image8, dev[0].stream);
     if (rc)
     {
-      cleanup();
+      ctx_release(g_ctx);
+      (void)hipSetDevice(prev);
       return rc;
     }
   }
@@ -1183,9 +1299,9 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   /* ---- results ---- */
   IMG_TRY(hipSetDevice(0));
   if (h_image_rgb)
-    IMG_TRY(hipMemcpy(h_image_rgb, image, n_px * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    IMG_TRY(hipMemcpy(h_image_rgb, c.image, n_px * 3 * sizeof(float), hipMemcpyDeviceToHost));
   if (h_image_rgb8)
-    IMG_TRY(hipMemcpy(h_image_rgb8, image8, n_px * 3, hipMemcpyDeviceToHost));
+    IMG_TRY(hipMemcpy(h_image_rgb8, c.image8, n_px * 3, hipMemcpyDeviceToHost));
   double worst = 0;
   uint64_t sums[RT_HIP_NSTATS] = {0, 0, 0, 0};
   for (int g = 0; g < G; g++)
@@ -1204,11 +1320,23 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     memcpy(h_stats, sums, sizeof sums);
   if (kernel_seconds)
     *kernel_seconds = worst;
-  cleanup();
+  (void)hipSetDevice(prev);
 #undef IMG_TRY
   if (cancelled)
     return fail(RT_HIP_ECANCELLED, "render cancelled: the image holds the tiles finished so far");
   return RT_HIP_OK;
+}
+
+void release_cache_impl()
+{
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  ctx_release(g_ctx);
+}
+
+uint64_t cache_builds_impl()
+{
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  return g_ctx.builds;
 }
 
 } // namespace

@@ -64,7 +64,7 @@ def _worker(rank, world, port, w, h, spp, out_path, mode="gather"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,w,h", [(2, 40, 24), (3, 37, 21)])
+@pytest.mark.parametrize("world,w,h", [(2, 40, 24), (3, 37, 21), (8, 45, 27)])  # 8 ranks, ragged image: 6 x 4 = 24 tiles, 3 per rank
 def test_gather_assembles_the_frame(tmp_path, world, w, h):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")

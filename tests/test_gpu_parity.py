@@ -682,7 +682,7 @@ def test_bench_two_ranks_rehearsal(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--config", "2", "--spp", "4", "--steps", "1", "--warmup", "1", "--cpu-tiles", "0"]
+    common = ["--config", "2", "--spp", "4", "--steps", "1", "--warmup", "1", "--cpu-tiles", "0", "--no-configs"]
     env = dict(os.environ, RT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(root, "bench.py"),
@@ -700,6 +700,34 @@ def test_bench_two_ranks_rehearsal(gpu):
     assert d2["ray_count_per_step"] == d1["ray_count_per_step"]
     assert d2["ray_bounces_per_step"] == d1["ray_bounces_per_step"]
     assert "REHEARSAL" in d2["config"]["parallelism"]
+    # the N > 1 diagnostics: ranks the backend connected, where a frame's time goes, per-rank kernel times
+    assert d2["ranks_seen"] == 2 and set(d2["phase_ms"]) >= {"render", "gather", "untile"}
+    assert len(d2["rank_kernel_ms"]["per_rank"]) == 2 and d2["rank_kernel_ms"]["min"] > 0
+    assert "ranks_seen" not in d1 and d1["roofline"]["kernel"] == "pt_render_tiles"
+
+
+def test_bench_host_path_and_config_array(gpu):
+    """`bench.py --host-path`: one process through rt_hip_render_image() (the C host's path; with
+    --gpus N > 1 it drives N devices and RCCL inside the shim -- one device here); and the
+    per-configuration array of the default N = 1 run"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--host-path", "--gpus", "1", "--config", "2",
+                         "--spp", "4", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert hp.returncode == 0, hp.stderr[-2000:]
+    d = json.loads([ln for ln in hp.stdout.splitlines() if ln.startswith("{")][0])["host_path"]
+    assert d["n_devices"] == 1 and len(d["call_ms"]) == 2 and d["ray_bounces_per_s"] > 0
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "1", "--steps", "1", "--warmup", "1",
+                          "--cpu-tiles", "0", "--c5-spp", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
+    got = {c["config"]: c for c in d["configs"]}
+    assert set(got) == {2, 3, 4, 5} or set(got) == {2, 3, 5}
+    assert got[3]["kernel"] == "pt_render_tiles_tri" and got[5]["kernel"] == "pt_render_tiles_tri_big"
+    assert all("error" not in c and c["kernel_ms"] > 0 and c["ray_bounces_per_s"] > 0 for c in got.values())
 
 
 def test_mesh_hierarchy_partitions_and_chunks_are_bit_invariant(gpu):
@@ -985,3 +1013,30 @@ def test_nan_samples_poison_the_pixel_in_every_kernel_family(gpu):
     # chunked render of 4 spp: flags travel through the workspace; more samples, more NaN pixels
     nan4 = np.isnan(chunked[0])
     assert nan4.any() and (chunked[1][nan4] == 255).all() and (nan4 | ~nan).all()
+
+
+def test_render_image_reuses_its_context_between_frames(gpu, pt):
+    """rt_hip_render_image() (what render() of the C host calls per frame) keeps scenes, streams,
+    buffers and communicators while device count, image size and scene bytes are unchanged"""
+    from rt_amd import abi, scene as S
+    shim = abi.load_shim()
+    shim.rt_hip_release_cache()
+    b0 = shim.rt_hip_cache_builds()
+    sc = S.build_scene(2, 72, 40, 4)
+    a = gpu.render_image_host(sc, SEED)
+    b = gpu.render_image_host(sc, SEED)
+    assert shim.rt_hip_cache_builds() == b0 + 1, "second frame of the same scene must not rebuild"
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    c = gpu.render_image_host(sc, SEED + 1)   # another seed: same context
+    assert shim.rt_hip_cache_builds() == b0 + 1 and not np.array_equal(a[0], c[0])
+    sc2 = S.build_scene(2, 72, 40, 4)
+    sc2.objects[1].radius *= 1.5              # one byte of the scene changes: rebuilt, and rendered correctly
+    d = gpu.render_image_host(sc2, SEED)
+    assert shim.rt_hip_cache_builds() == b0 + 2
+    mean, rgb8, ost = pt.render_pixels(sc2, SEED)
+    assert_parity(d[0], d[1], d[2], mean, rgb8, ost, what="rebuilt context")
+    e = gpu.render_image_host(sc, SEED, samples=8)   # other spp, same scene as the first: rebuilt once more (scene differs from sc2)
+    assert shim.rt_hip_cache_builds() == b0 + 3
+    shim.rt_hip_release_cache()
+    f = gpu.render_image_host(sc, SEED)
+    assert np.array_equal(a[0], f[0]) and shim.rt_hip_cache_builds() == b0 + 4
