@@ -190,8 +190,9 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
  * positions); h_rays = n x 6 (origin, direction).  Case i = ray i against primitive i:
  * h_hit[i] 0/1 and h_tuv[3i..] = t (DBL_MAX on a miss) and, for triangles, the barycentric
  * u, v (a texture coordinate is st0 (1-u-v) + st1 u + st2 v, raytracer.c:154-167).
- * h_keep[3i + f], f = 0..2: 64-bit masks of the filter's three forms (sign tests from LDS --
- * spheres only, all ones for triangles; compares from LDS; compares by scalar loads) for ray i
+ * h_keep[3i + f], f = 0..2: 64-bit masks of the filter's three forms (f = 0: spheres, sign tests
+ * from LDS; triangles, the per-lane fp32 Moeller-Trumbore pre-test that follows the bounding-sphere
+ * filter in small scenes; f = 1: compares from LDS; f = 2: compares by scalar loads) for ray i
  * against the 64 primitives of its block [64 (i/64), +64): bit j set = primitive 64 (i/64) + j
  * is kept.  The filter is built for ray origins within near_R (rays beyond keep everything),
  * as rt_hip_render_tiles builds it per launch.  |centre|, |radius| <= 1e17. */

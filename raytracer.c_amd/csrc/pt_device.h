@@ -9,7 +9,7 @@
  *       The first four doubles of the sphere records are what the exact test and the
  *       normal use; they are staged in LDS per workgroup (scenes beyond the 24 KiB staging
  *       budget read the compact copy geom4 from memory instead).
- *   filt       [ceil(entries/2)] x 5 f32x2       : cx cy cz r2_hi neg_tol, two primitives per
+ *   filt       [ceil(entries/2)] x 5 f32x2 (+ [n_triangles] x 16 f32, see pt_filt_bytes) : cx cy cz r2_hi neg_tol, two primitives per
  *       f32x2 -- the packed-fp32 phase-1 filter table (pt_build_filter).  Its thresholds depend
  *       on the camera distance (near_R), so the shim keeps one table set per (scene, near_R),
  *       built once and immutable afterwards; read with wave-uniform indices, i.e. through
@@ -61,7 +61,14 @@
 #define PT_BVH_STACK 24       /* per-lane traversal stack (LDS): tree depth limit */
 #define PT_GEOM_STRIDE 4     /* LDS doubles per sphere: cx cy cz r2 */
 #define PT_FILT_STRIDE 5     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
+#define PT_TRI32_STRIDE 16    /* floats per triangle of the fp32 pre-test table: v0 e1 e2 (9), Ea KU KV KT (4), pad (3) */
 #define PT_ENTRY_SRC_STRIDE 6 /* HBM doubles per primitive: cx cy cz R2 |c| Rb (bounding data, fp64) */
+
+/* parked-walk kernels (pt_render_tiles_tri_queued*): bytes of ring per wave in the workspace, slots
+ * (workgroups) per XCD the pool provides: 32 CUs x at most 5 resident workgroups, with slack */
+#define PT_PARK_WAVE_BYTES 32768u
+#define PT_PARK_SLOTS_PER_XCD 192u
+#define PT_PARK_XCDS 8u
 
 #define PT_ACC_WS_WORDS (PT_TILE_PIXELS * 3 + 3) /* chunked renders: u64 per tile in the workspace: 192 sums + 3 NaN masks */
 
@@ -92,6 +99,7 @@ struct PtSceneView
   uint32_t any_refract, n_bvh_nodes; /* n_bvh_nodes == 0: the scene has no triangles */
   uint32_t wide_range;               /* a centre or radius beyond 1e17: fp32 sums could overflow */
   uint32_t any_mirror_glass;         /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children per hit */
+  uint32_t bvh_depth;                /* inner nodes on the longest root-to-leaf path: the traversal stack a lane needs */
 };
 
 /* Small scenes keep the filter table in LDS and (sphere-only ones) use the sign-test form of
@@ -110,6 +118,24 @@ __host__ __device__
 static inline bool pt_filter_in_lds(const PtSceneView &sc)
 {
   return (uint64_t)sc.n_spheres + sc.n_triangles <= PT_FILT_LDS_MAX && !sc.wide_range && pt_geom_in_lds(sc);
+}
+
+/* The filter buffer of a small scene (pt_filter_in_lds) holds two tables: the pair table of
+ * phase 1 (PT_FILT_STRIDE f32x2 per primitive pair, + the look-ahead pair), then, 16-byte aligned,
+ * the fp32 triangle table of the per-lane pre-test (PT_TRI32_STRIDE floats per triangle). */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint32_t pt_filt_pair_slots(uint32_t n_entries)
+{ /* f32x2 slots of the pair table, rounded up to a 16-byte boundary */
+  return (PT_FILT_STRIDE * ((n_entries + 1u) / 2u + 1u) + 1u) & ~1u;
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline size_t pt_filt_bytes(uint32_t n_spheres, uint32_t n_triangles)
+{
+  return (size_t)pt_filt_pair_slots(n_spheres + n_triangles) * 8u + (size_t)n_triangles * PT_TRI32_STRIDE * 4u;
 }
 
 struct PtCamera
@@ -138,6 +164,11 @@ struct PtLaunch
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
   uint32_t sample_chunks; /* workgroups per tile: each renders 1/sample_chunks of the samples */
   uint32_t integrator;    /* 0 trace_path (raytracer.c:482-554), 1 cast_ray (:556-641) */
+  /* parked-walk kernels: workspace of PT_PARK_XCDS x park_slots_per_xcd slots x 4 waves x PT_PARK_WAVE_BYTES and
+   * one in-use flag per slot (zero between launches); nullptr: walk in the lanes */
+  char *park_ws;
+  uint32_t *park_flags;
+  uint32_t park_slots_per_xcd;
   unsigned long long *acc_ws;        /* sample_chunks > 1: tile_count x 192 fixed-point sums, then tile_count x 3 NaN masks */
   float *tiles_rgb;
   uint8_t *tiles_rgb8;
@@ -153,8 +184,8 @@ hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant);
 hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream);
 hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,
-                                        float *filt, uint32_t n, double near_R, double filt_shift, uint8_t *hit,
-                                        double *tuv, unsigned long long *keep, hipStream_t stream);
+                                        float *filt, float *tri32, uint32_t n, double near_R, double filt_shift,
+                                        uint8_t *hit, double *tuv, unsigned long long *keep, hipStream_t stream);
 hipError_t pt_launch_untile(const float *tiles_rgb, const uint8_t *tiles_rgb8, int width, int height,
                             uint32_t tile_first, uint32_t tile_stride, uint32_t tile_count, float *image_rgb,
                             uint8_t *image_rgb8, hipStream_t stream);

@@ -359,15 +359,16 @@ __device__ __forceinline__ uint32_t (*bvh_stack_lds())[PT_BLOCK]
 
 /* LAST / no_prune: scenes with M_CHECKERED materials and triangles need every triangle the ray
  * passes, not only those closer than the closest hit so far (TriLast): no pruning by min_t then. */
-template <bool LAST = false>
+template <bool LAST = false, bool OWN_STACK = false>
 __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, uint32_t n_nodes,
                                              const uint32_t *__restrict__ tri_order, const double *tri_geom,
                                              uint32_t n_sph, bool far_origin, const V3 &o, const V3 &d,
                                              double &min_t, int &best, double &bary_u, double &bary_v,
                                              unsigned long long *diag_ptr, TriLast *last = nullptr,
-                                             bool no_prune = false)
+                                             bool no_prune = false, uint32_t (*stack)[PT_BLOCK] = nullptr)
 {
-  uint32_t (*const stack)[PT_BLOCK] = bvh_stack_lds();
+  if (!OWN_STACK) /* default: the workgroup's static array (the queued kernels pass their own, sized by the tree) */
+    stack = bvh_stack_lds();
   if (n_nodes == 0)
     return;
   const BvhRay R = bvh_ray(o, d);
@@ -572,6 +573,51 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
   cand_hi = far_origin ? valid_hi : (cand_hi & valid_hi);
 }
 
+/* Per-lane fp32 pre-test of one triangle candidate (small scenes: the flat filter passes a
+ * triangle through its bounding sphere, which is loose -- a ray near a cube passes the spheres of
+ * most of its 12 triangles; measured on config 3: 6.9 exact tests per wave trip for 1.7 candidates
+ * per ray).  Moeller-Trumbore in fp32 with every accept/reject widened by a bound on the fp32
+ * error, so it can only keep extra triangles, never drop one the exact test accepts:
+ *   a = e1.(d x e2), U = s.(d x e2), V = d.(s x e1), T = e2.(s x e1), s = o - v0;
+ *   the exact test accepts iff |a| >= 1e-8, 0 <= U/a <= 1, V/a >= 0, (U+V)/a <= 1, T/a > 1e-8.
+ * With e = 2^-24, |d| <= 1.0001, |s| <= S := near_R + |v0| (rays from farther out skip the filter
+ * altogether), inputs rounded to fp32 and fused 3-term products:
+ *   |a32 - a| <= 12 e |e1||e2|,  |U32 - U| <= 14 e S |e2|,  |V32 - V| <= 15 e S |e1|,
+ *   |T32 - T| <= 15 e S |e1||e2|;
+ * the table stores Ea = 16 e |e1||e2|, KU = 20 e S |e2|, KV = 20 e S |e1|, KT = 20 e S |e1||e2|
+ * (rounded up; >= 25 % slack over the bounds, which also swallows the reference's own fp64
+ * rounding, ~1e-16 of the same magnitudes).  If |a32| <= Ea the sign of a is not certain: keep.
+ * Otherwise, with everything multiplied by sign(a): drop iff U < -KU, or U > |a| + Ea + KU, or
+ * V < -KV, or U + V > |a| + Ea + KU + KV, or T < -KT -- each a certain violation of one of the
+ * exact test's conditions.  NaNs compare false: kept.  Triangles whose products could overflow
+ * fp32 get Ea = +inf in the table: always kept. */
+__device__ __forceinline__ bool tri_may_hit32(const float4 *__restrict__ rec, float ox, float oy, float oz, float dx,
+                                              float dy, float dz)
+{
+  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+  const float v0x = r0.x, v0y = r0.y, v0z = r0.z, e1x = r0.w, e1y = r1.x, e1z = r1.y, e2x = r1.z, e2y = r1.w, e2z = r2.x;
+  const float Ea = r2.y, KU = r2.z, KV = r2.w, KT = r3.x;
+  const float hx = __builtin_fmaf(dy, e2z, -(dz * e2y)), hy = __builtin_fmaf(dz, e2x, -(dx * e2z)),
+              hz = __builtin_fmaf(dx, e2y, -(dy * e2x));
+  const float a = __builtin_fmaf(e1z, hz, __builtin_fmaf(e1y, hy, e1x * hx));
+  const float sx = ox - v0x, sy = oy - v0y, sz = oz - v0z;
+  float U = __builtin_fmaf(sz, hz, __builtin_fmaf(sy, hy, sx * hx));
+  const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y)), qy = __builtin_fmaf(sz, e1x, -(sx * e1z)),
+              qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
+  float V = __builtin_fmaf(dz, qz, __builtin_fmaf(dy, qy, dx * qx));
+  float T = __builtin_fmaf(e2z, qz, __builtin_fmaf(e2y, qy, e2x * qx));
+  const float abs_a = fabsf(a);
+  if (!(abs_a > Ea))
+    return true; /* near-parallel, or NaN: the sign of a is not certain */
+  const uint32_t sgn = __float_as_uint(a) & 0x80000000u;
+  U = __uint_as_float(__float_as_uint(U) ^ sgn);
+  V = __uint_as_float(__float_as_uint(V) ^ sgn);
+  T = __uint_as_float(__float_as_uint(T) ^ sgn);
+  const float lim = abs_a + Ea;
+  const bool drop = (U < -KU) | (U > lim + KU) | (V < -KV) | (U + V > lim + KU + KV) | (T < -KT);
+  return !drop;
+}
+
 template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true, bool LAST = false>
 __device__ __forceinline__ void scan_filtered(const double *geom, const double *tri_geom,
                                               const f32x2 *__restrict__ filt, double near_R2, uint32_t n_sph,
@@ -579,7 +625,8 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
                                               int &best, double &bary_u, double &bary_v,
                                               unsigned long long *diag_ptr, const float *bvh_nodes = nullptr,
                                               uint32_t n_bvh_nodes = 0, const uint32_t *bvh_tri = nullptr,
-                                              double filt_shift = 0.0, TriLast *last = nullptr, bool no_prune = false)
+                                              double filt_shift = 0.0, TriLast *last = nullptr, bool no_prune = false,
+                                              const float4 *tri32 = nullptr)
 {
   /* with a hierarchy the flat filter covers the spheres only */
   if (BVH)
@@ -610,13 +657,45 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
     uint32_t cand_lo, cand_hi;
     filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, ox, oy, oz, dx, dy, dz, far_origin, cand_lo, cand_hi);
+    /* triangle candidates of this chunk: bits from entry n_sph on */
+    uint32_t tri_lo = 0, tri_hi = 0;
+    if (TRIS && !BVH)
+    {
+      const uint32_t first_tri_bit = n_sph > base ? min(n_sph - base, 64u) : 0u;
+      const uint32_t m_lo = first_tri_bit >= 32u ? 0u : (0xFFFFFFFFu << first_tri_bit);
+      const uint32_t m_hi = first_tri_bit >= 64u ? 0u : (first_tri_bit > 32u ? (0xFFFFFFFFu << (first_tri_bit - 32u)) : 0xFFFFFFFFu);
+      tri_lo = cand_lo & m_lo;
+      tri_hi = cand_hi & m_hi;
+      cand_lo &= ~m_lo; /* what is left in cand_*: sphere candidates */
+      cand_hi &= ~m_hi;
+      if (FILT_LDS && !far_origin)
+      {
+        /* ---- phase 1b: per-lane fp32 pre-test of the lane's own triangle candidates (tri_may_hit32) ---- */
+        uint32_t keep_lo = 0, keep_hi = 0, w_lo = tri_lo, w_hi = tri_hi;
+        while (w_lo | w_hi)
+        {
+          const bool in_lo = w_lo != 0;
+          const uint32_t word = in_lo ? w_lo : w_hi;
+          const uint32_t bit = (uint32_t)__builtin_ctz(word);
+          const uint32_t cleared = word & (word - 1u);
+          w_lo = in_lo ? cleared : 0u;
+          w_hi = in_lo ? w_hi : cleared;
+          const uint32_t t = base + bit + (in_lo ? 0u : 32u) - n_sph;
+          const bool may = tri_may_hit32(tri32 + (PT_TRI32_STRIDE / 4) * (size_t)t, ox, oy, oz, dx.x, dy.x, dz.x);
+          keep_lo |= (in_lo && may) ? (1u << bit) : 0u;
+          keep_hi |= (!in_lo && may) ? (1u << bit) : 0u;
+        }
+        tri_lo = keep_lo;
+        tri_hi = keep_hi;
+      }
+    }
 #ifdef PT_DIAG
     {
       /* exactness check of the filter: any primitive it dropped that the exact test accepts? */
       uint32_t violations = 0;
       for (uint32_t k = 0; k < chunk; k++)
       {
-        const bool kept = k < 32 ? ((cand_lo >> k) & 1u) : ((cand_hi >> (k - 32u)) & 1u);
+        const bool kept = k < 32 ? (((cand_lo | tri_lo) >> k) & 1u) : (((cand_hi | tri_hi) >> (k - 32u)) & 1u);
         double t_probe = 1.7976931348623157e308, pu = 0, pv = 0;
         int b_probe = -1;
         const uint32_t i = base + k;
@@ -629,15 +708,15 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       for (int off = 32; off > 0; off >>= 1)
         violations += (uint32_t)__shfl_xor((int)violations, off);
       DIAG(12, violations);
-      const uint32_t mine = (uint32_t)(__popc(cand_lo) + __popc(cand_hi));
-      DIAG(2, wave_max_u32(mine)); /* wave-level phase-2 iterations */
+      const uint32_t mine = (uint32_t)(__popc(cand_lo) + __popc(cand_hi) + __popc(tri_lo) + __popc(tri_hi));
+      DIAG(2, wave_max_u32((uint32_t)(__popc(cand_lo) + __popc(cand_hi))) + wave_max_u32((uint32_t)(__popc(tri_lo) + __popc(tri_hi)))); /* wave-level phase-2 iterations */
       uint32_t tot = mine;
       for (int off = 32; off > 0; off >>= 1)
         tot += (uint32_t)__shfl_xor((int)tot, off);
       DIAG(3, tot);                /* lane-level candidates */
     }
 #endif
-    /* ---- phase 2: the exact test on each lane's own candidates, in index order ---- */
+    /* ---- phase 2: the exact test on each lane's own candidates, in index order: spheres ... ---- */
     while (cand_lo | cand_hi)
     {
       /* lowest set bit of the 64-bit mask, branch-free */
@@ -648,11 +727,23 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       cand_lo = in_lo ? cleared : 0u;
       cand_hi = in_lo ? cand_hi : cleared;
       const uint32_t i = base + k;
-      if (!TRIS || BVH || i < n_sph)
-        exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
-      else
-        exact_triangle<false, LAST>(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v, last);
+      exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
     }
+    /* then its triangle candidates (all of higher index than any sphere: the scan order holds).  Two
+     * loops, not one with a branch inside: a wave holding both kinds would pay for both tests in
+     * every iteration */
+    if (TRIS && !BVH)
+      while (tri_lo | tri_hi)
+      {
+        const bool in_lo = tri_lo != 0;
+        const uint32_t word = in_lo ? tri_lo : tri_hi;
+        const uint32_t k = (uint32_t)__builtin_ctz(word) + (in_lo ? 0u : 32u);
+        const uint32_t cleared = word & (word - 1u);
+        tri_lo = in_lo ? cleared : 0u;
+        tri_hi = in_lo ? tri_hi : cleared;
+        const uint32_t i = base + k;
+        exact_triangle<false, LAST>(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v, last);
+      }
   }
   if (BVH && WALK) /* WALK = false: the caller walks the hierarchy itself, later (render_tiles_pooled) */
     bvh_traverse<LAST>(bvh_nodes, n_bvh_nodes, bvh_tri, tri_geom, n_sph, far_origin, o, d, min_t, best, bary_u, bary_v,
@@ -672,6 +763,7 @@ struct SceneCtx
   const uint32_t *tri_object;
   const f32x2 *filt;      /* HBM: ceil(n_entries/2) x PT_FILT_STRIDE packed-fp32 filter pairs */
   const f32x2 *filt_lds;  /* LDS copy of it when the scene is small (PT_FILT_LDS_MAX), else nullptr */
+  const float4 *tri32;    /* LDS: the fp32 triangle table of the pre-test (small scenes with triangles), else nullptr */
   const float *bvh_nodes; /* HBM: triangle hierarchy of large meshes (n_bvh_nodes may be 0) */
   const uint32_t *bvh_tri;
   uint32_t n_bvh_nodes;
@@ -717,7 +809,8 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   if (FILT_LDS)
   {
     filt_lds = reinterpret_cast<f32x2 *>(mat + PT_MAT_STRIDE * (size_t)n_mat);
-    const uint32_t n_slots = PT_FILT_STRIDE * ((n_entries + 1u) / 2u + 1u); /* + the look-ahead pair */
+    /* the pair table (+ the look-ahead pair) and, behind it, the fp32 triangle table */
+    const uint32_t n_slots = pt_filt_pair_slots(n_entries) + sc.n_triangles * (PT_TRI32_STRIDE / 2);
     const f32x2 *src = reinterpret_cast<const f32x2 *>(sc.filt);
     for (uint32_t k = threadIdx.x; k < n_slots; k += PT_BLOCK)
       filt_lds[k] = src[k];
@@ -740,6 +833,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.tri_object = sc.tri_object;
   ctx.filt = reinterpret_cast<const f32x2 *>(sc.filt);
   ctx.filt_lds = filt_lds;
+  ctx.tri32 = FILT_LDS ? reinterpret_cast<const float4 *>(filt_lds + pt_filt_pair_slots(n_entries)) : nullptr;
   ctx.bvh_nodes = sc.bvh_nodes;
   ctx.bvh_tri = sc.bvh_tri;
   ctx.n_bvh_nodes = sc.n_bvh_nodes;
@@ -922,7 +1016,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       else
         scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0, CHECKER && TRIS>(
             S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o, d, H.min_t, H.best,
-            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv);
+            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv, S.tri32);
     }
     if (MODE == 1)
       return false;
@@ -1118,7 +1212,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
     scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, true, TRIS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2,
                                                                  S.n_sph, S.n_sph + S.n_tri, o, d, min_t, best, bary_u,
                                                                  bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri,
-                                                                 S.filt_shift, &last, S.stale_uv);
+                                                                 S.filt_shift, &last, S.stale_uv, S.tri32);
     if (best >= 0)
     {
       const V3 p = v_add(o, v_scale(d, min_t));
@@ -1148,7 +1242,8 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
       int blocker = -1;
       scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
                                                        S.n_sph + S.n_tri, p, ldir, shadow_t, blocker, su, sv, diag_ptr,
-                                                       S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift);
+                                                       S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, nullptr, false,
+                                                       S.tri32);
       const double lit = blocker >= 0 ? 0.0 : 1.0;
 
       if (flags & PT_FLAG_CHECKER)
@@ -1337,7 +1432,7 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 template <bool CHECKER, bool TRIS, bool FILT_LDS, bool GEOM_LDS>
 __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ float out_f[PT_TILE_PIXELS * 3];
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
@@ -1614,6 +1709,534 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   }
 }
 
+/* ---- hierarchy scenes: pooled samples + PARKED walks (pt_render_tiles_tri_big[_chk]) ---------
+ *
+ * Scenes with a triangle hierarchy (more than PT_FILT_LDS_MAX primitives).  The pooled body above
+ * makes a ray that can reach the mesh WAIT in its lane until enough lanes wait, then walks the
+ * hierarchy with the waiting lanes only: the lanes in between idle (loop occupancy 55 % on config
+ * 5) and a walk batch holds ~32 rays whose lengths range from 2 to 25 visits (12 % of the lanes
+ * busy inside walks; profiles/r02a_c5_pmc.txt: 30 % VALU lane utilisation overall).  Here such a
+ * ray is PARKED instead: its state (origin, direction, throughput, RNG state, flat-scan result:
+ * 96 bytes) goes to a per-wave ring in global memory and its lane takes the next job at once.
+ * When PT_PARK_WALK rays are parked the whole wave turns to walking them: every lane takes a ray
+ * from the ring, and a lane whose walk ends takes the next one (the walk lengths average out
+ * over the ~2-4 rays a lane gets through), node visits and leaf tests batched apart
+ * ("while-while" with refill).  Walked rays are picked up by idle lanes ahead of fresh camera
+ * samples and continue with the shading half of trace_step.  None of this can change a value: a
+ * sample depends on its (seed, pixel, sample) stream alone, per-pixel sums are integers.
+ *
+ * The ring: PT_PARK_Q entries per wave, field-major (consecutive entries of one field are
+ * consecutive addresses), positions [head, head + n_done) hold walked rays, then n_new parked
+ * ones; all three counters are wave-uniform.  It lives in a workspace slot the workgroup takes
+ * from a pool at entry and returns at exit (pt_park_acquire): the pool is partitioned by XCD
+ * (HW_REG_XCC_ID of the running wave, not an assumption about placement), so every owner a slot
+ * ever has sits behind the same L2 -- plain stores, L1-bypassing loads, no cache write-backs.
+ * Radiance is added to the pixel's fixed-point sum term by term (P.Ls is flushed every trip),
+ * so a parked ray carries no partial radiance. */
+#ifndef PT_PARK_Q
+#define PT_PARK_Q 256u /* ring entries per wave (a power of two) */
+#endif
+#ifndef PT_PARK_WALK
+#define PT_PARK_WALK 190u /* parked rays that turn the wave to walking (measured at 4K x 256 spp: 32: 664 ms, 64: 553, 128: 529, 190: 521) */
+#endif
+#ifndef PT_LEAF_BATCH
+#define PT_LEAF_BATCH 24u /* lanes holding a leaf that trigger a round of exact triangle tests */
+#endif
+#define PT_PARK_F64_FIELDS 13u /* o xyz, d xyz, T xyz, rng, min_t, (M_CHECKERED kernels: last u, v) */
+#define PT_PARK_U32_FIELDS 4u  /* best, depth << 6 | pixel slot, (last index), pad */
+static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * (PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u), "ring bytes per wave");
+static_assert((PT_PARK_Q & (PT_PARK_Q - 1u)) == 0u && PT_PARK_WALK + 64u <= PT_PARK_Q, "ring size");
+
+struct ParkRing
+{
+  double *f;   /* [PT_PARK_F64_FIELDS][PT_PARK_Q] */
+  uint32_t *u; /* [PT_PARK_U32_FIELDS][PT_PARK_Q] */
+};
+
+/* ring loads bypass the vector L1 (agent-scope relaxed = `sc1`): a slot's earlier owner on this CU
+ * may have left lines of it there */
+__device__ __forceinline__ double ring_ld(const ParkRing &r, uint32_t field, uint32_t e)
+{
+  return __longlong_as_double((long long)__hip_atomic_load(
+      reinterpret_cast<unsigned long long *>(r.f + field * PT_PARK_Q + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ V3 ring_ld3(const ParkRing &r, uint32_t field, uint32_t e)
+{
+  return {ring_ld(r, field, e), ring_ld(r, field + 1u, e), ring_ld(r, field + 2u, e)};
+}
+__device__ __forceinline__ uint32_t ring_ldu(const ParkRing &r, uint32_t field, uint32_t e)
+{
+  return __hip_atomic_load(r.u + field * PT_PARK_Q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ring_st(const ParkRing &r, uint32_t field, uint32_t e, double v) { r.f[field * PT_PARK_Q + e] = v; }
+__device__ __forceinline__ void ring_st3(const ParkRing &r, uint32_t field, uint32_t e, const V3 &v)
+{
+  ring_st(r, field, e, v.x);
+  ring_st(r, field + 1u, e, v.y);
+  ring_st(r, field + 2u, e, v.z);
+}
+
+/* The workgroup's workspace slot, or 0xFFFFFFFF when there is none (no workspace, or -- a sizing
+ * bug, never seen -- every slot of this XCD taken after a bounded search: the kernel then walks in
+ * the lanes, slower but correct, rather than spin).  Thread 0 only. */
+__device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
+{
+  if (L.park_ws == nullptr || L.park_slots_per_xcd == 0u)
+    return 0xFFFFFFFFu;
+  /* s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, width 4): the XCD this wave runs on */
+  const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+  const uint32_t per = L.park_slots_per_xcd;
+  uint32_t *flags = L.park_flags + xcc * per;
+  uint32_t i = ((blockIdx.x * 2654435761u) >> 7) % per;
+  for (uint32_t probes = 0; probes < 64u * per; probes++)
+  {
+    if (atomicCAS(&flags[i], 0u, 1u) == 0u)
+      return xcc * per + i;
+    i = (i + 1u == per) ? 0u : i + 1u;
+    if ((probes & 15u) == 15u)
+      __builtin_amdgcn_s_sleep(8);
+  }
+  return 0xFFFFFFFFu;
+}
+
+/* The wave walks the n_new parked rays at ring positions first, first + 1, ... (see the header
+ * comment): refill, then either one node visit for the lanes that hold an inner node or the exact
+ * triangle tests of the lanes that hold a leaf, until every ray has its result in the ring. */
+/* own: this lane could not park its ray (ring full, or no workspace) and walks it from its own
+ * registers here, alongside the parked ones -- the correctness path, not the fast one. */
+template <bool CHECKER>
+__device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &ring, uint32_t first, uint32_t n_new,
+                                            uint32_t (*stack)[PT_BLOCK], unsigned long long *diag_ptr, bool own,
+                                            const V3 &own_o, const V3 &own_d, HitRec &own_hit)
+{
+  /* parked state written by this wave's lanes (plain stores) must have reached L2 before other
+   * lanes load it: workgroup-scope release = s_waitcnt vmcnt(0) */
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  uint32_t next = 0; /* rays handed to lanes so far (wave-uniform) */
+  bool have = own;
+  uint32_t e = 0, sp = 0, ref = 0;
+  V3 wo = own_o, wd = own_d;
+  double wmin_t = own_hit.min_t, bu = 0, bv = 0;
+  int wbest = own_hit.best;
+  bool far_origin = !(v_dot(wo, wo) <= S.near_R2);
+  BvhRay R = bvh_ray(wo, wd);
+  TriLast last = {-1, 0, 0};
+  const bool no_prune = CHECKER && S.stale_uv;
+  for (;;)
+  {
+    const unsigned long long need = __ballot(!have);
+    if (need != 0 && next < n_new)
+    {
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      if (!have && next + rank < n_new)
+      {
+        e = (first + next + rank) & (PT_PARK_Q - 1u);
+        wo = ring_ld3(ring, 0u, e);
+        wd = ring_ld3(ring, 3u, e);
+        wmin_t = ring_ld(ring, 10u, e);
+        wbest = (int)ring_ldu(ring, 0u, e);
+        R = bvh_ray(wo, wd);
+        far_origin = !(v_dot(wo, wo) <= S.near_R2);
+        sp = 0;
+        ref = 0; /* the root */
+        last.idx = -1;
+        have = true;
+      }
+      next = min(n_new, next + (uint32_t)__popcll(need));
+    }
+    const unsigned long long active = __ballot(have);
+    if (active == 0)
+      break; /* every ray walked: the one exit, reached by all lanes together */
+    const bool at_leaf = have && (ref & PT_BVH_LEAF_FLAG) != 0u;
+    const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+    const uint32_t n_inner = (uint32_t)__popcll(active) - n_leaf;
+    bool finished = false;
+    if (n_inner != 0u && n_leaf < PT_LEAF_BATCH)
+    {
+      if (have && !at_leaf)
+      {
+        DIAG(13, 1);
+        DIAG_LANES(15);
+        bool hit0, hit1;
+        float tn0, tn1;
+        uint32_t r0, r1;
+        bvh_test_children(S.bvh_nodes, ref, R, far_origin, no_prune ? 3.4028234663852886e38f : __double2float_ru(wmin_t), hit0,
+                          hit1, tn0, tn1, r0, r1);
+        if (hit0 && hit1)
+        {
+          const bool zero_first = !(tn1 < tn0);
+          stack[sp][threadIdx.x] = zero_first ? r1 : r0;
+          sp++;
+          ref = zero_first ? r0 : r1;
+        }
+        else if (hit0 || hit1)
+          ref = hit0 ? r0 : r1;
+        else if (sp == 0)
+          finished = true;
+        else
+        {
+          sp--;
+          ref = stack[sp][threadIdx.x];
+        }
+      }
+    }
+    else if (at_leaf)
+    {
+      const uint32_t first_tri = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
+      for (uint32_t k = 0; k < count; k++)
+      {
+        DIAG(14, 1);
+        const uint32_t t = S.bvh_tri[first_tri + k];
+        exact_triangle<true, CHECKER>(S.tri + 9 * (size_t)t, S.n_sph + t, wo, wd, wmin_t, wbest, bu, bv, &last);
+      }
+      if (sp == 0)
+        finished = true;
+      else
+      {
+        sp--;
+        ref = stack[sp][threadIdx.x];
+      }
+    }
+    if (finished)
+    {
+      if (own)
+      {
+        own_hit.min_t = wmin_t;
+        own_hit.best = wbest;
+        if (CHECKER)
+          own_hit.last = last;
+        own = false;
+      }
+      else
+      {
+        ring_st(ring, 10u, e, wmin_t);
+        ring.u[0u * PT_PARK_Q + e] = (uint32_t)wbest;
+        if (CHECKER)
+        {
+          ring.u[2u * PT_PARK_Q + e] = (uint32_t)last.idx;
+          ring_st(ring, 11u, e, last.u);
+          ring_st(ring, 12u, e, last.v);
+        }
+      }
+      have = false;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* results in L2 before anyone resumes them */
+}
+
+template <bool CHECKER>
+__device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
+{
+  constexpr bool TRIS = true, FILT_LDS = false;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ float out_f[PT_TILE_PIXELS * 3];
+  __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
+  __shared__ unsigned long long wg_stats[2];
+  __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3];
+  __shared__ unsigned long long pix_nan[3];
+  __shared__ unsigned long long pix_key[PT_TILE_PIXELS];
+  __shared__ double q_dir[PT_BLOCK / 64][3 * 64];
+  __shared__ unsigned long long q_rng[PT_BLOCK / 64][64];
+  __shared__ uint32_t q_pix[PT_BLOCK / 64][64];
+  __shared__ uint32_t park_slot_lds;
+
+  const SceneCtx S = stage_scene<true, FILT_LDS>(L, lds);
+  /* the traversal stacks follow the staged scene in dynamic LDS: one entry per tree level and lane */
+  uint32_t (*const stack)[PT_BLOCK] = reinterpret_cast<uint32_t (*)[PT_BLOCK]>(
+      lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes)));
+  if (threadIdx.x < 2)
+    wg_stats[threadIdx.x] = 0;
+  if (threadIdx.x < 3)
+    pix_nan[threadIdx.x] = 0;
+  if (threadIdx.x < PT_TILE_PIXELS * 3)
+    pix_sum[threadIdx.x] = 0;
+  if (threadIdx.x < PT_TILE_PIXELS)
+  {
+    const uint32_t t0 = L.tile_first + (blockIdx.x % L.tile_count) * L.tile_stride;
+    const uint32_t kx = (t0 % L.tiles_x) * PT_TILE + (threadIdx.x & 7u), ky = (t0 / L.tiles_x) * PT_TILE + (threadIdx.x >> 3);
+    pix_key[threadIdx.x] = rt_rng_pixel_key(L.seed, ky * (uint32_t)L.width + kx);
+  }
+  if (threadIdx.x == 0)
+    park_slot_lds = pt_park_acquire(L);
+  __syncthreads();
+
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t slot = blockIdx.x % L.tile_count, chunk = blockIdx.x / L.tile_count;
+  const uint32_t tile = L.tile_first + slot * L.tile_stride;
+  const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE + 2u * wave;
+  const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
+  const uint32_t vrows = ty0 >= (uint32_t)L.height ? 0u : min(2u, (uint32_t)L.height - ty0);
+  const uint32_t n_valid = vcols * vrows;
+  const uint32_t spp = (uint32_t)L.samples;
+  const uint32_t s_begin = (uint32_t)(((uint64_t)chunk * spp) / L.sample_chunks);
+  const uint32_t s_end = (uint32_t)(((uint64_t)(chunk + 1u) * spp) / L.sample_chunks);
+  const uint32_t pool = n_valid * (s_end - s_begin);
+  const CameraRegs cam = load_camera(L);
+  const uint32_t park_slot = park_slot_lds;
+  const bool ring_ok = park_slot != 0xFFFFFFFFu;
+  ParkRing ring;
+  {
+    char *base = L.park_ws + ((size_t)(ring_ok ? park_slot : 0u) * (PT_BLOCK / 64) + wave) * PT_PARK_WAVE_BYTES;
+    ring.f = reinterpret_cast<double *>(base);
+    ring.u = reinterpret_cast<uint32_t *>(base + (size_t)PT_PARK_Q * PT_PARK_F64_FIELDS * 8u);
+  }
+
+  Path P;
+  P.o = {0, 0, 0};
+  P.d = {0, 0, 1};
+  P.T = {1, 1, 1};
+  P.Ls = {0, 0, 0};
+  P.rng = 1;
+  P.depth = 0;
+  uint32_t n_rays = 0, n_casts = 0;
+  HitRec hit;
+  hit.min_t = 0;
+  hit.bary_u = 0;
+  hit.bary_v = 0;
+  hit.best = -1;
+  hit.depth_ok = false;
+  hit.need_dir = false;
+  hit.dir_slot = 0;
+  hit.dir_scale = 1.0;
+  hit.last.idx = -1;
+  hit.last.u = 0;
+  hit.last.v = 0;
+  uint32_t next_job = 0, made_jobs = 0; /* wave-uniform, as in render_tiles_pooled */
+  uint32_t head = 0, n_done = 0, n_new = 0; /* the ring (wave-uniform) */
+  uint32_t pix_slot = 0;
+  bool busy = false;
+  int stack_n = 0;
+  unsigned long long *diag_ptr = L.stats;
+  (void)diag_ptr;
+  const uint32_t lane = threadIdx.x & 63u;
+  double *const qd = q_dir[wave];
+  unsigned long long *const qr = q_rng[wave];
+  uint32_t *const qp = q_pix[wave];
+
+  for (;;)
+  {
+    /* ---- idle lanes take work: walked rays first (that frees the ring), then camera samples ---- */
+    unsigned long long idle = __ballot(!busy);
+    bool resumed = false;
+    if (idle != 0 && n_done != 0u)
+    {
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      const uint32_t take = min((uint32_t)__popcll(idle), n_done);
+      if (!busy && rank < take)
+      {
+        const uint32_t e = (head + rank) & (PT_PARK_Q - 1u);
+        P.o = ring_ld3(ring, 0u, e);
+        P.d = ring_ld3(ring, 3u, e);
+        P.T = ring_ld3(ring, 6u, e);
+        P.rng = (uint64_t)__double_as_longlong(ring_ld(ring, 9u, e));
+        hit.min_t = ring_ld(ring, 10u, e);
+        hit.best = (int)ring_ldu(ring, 0u, e);
+        const uint32_t dp = ring_ldu(ring, 1u, e);
+        P.depth = (int)(dp >> 6);
+        pix_slot = dp & 63u;
+        if (CHECKER)
+        {
+          hit.last.idx = (int)ring_ldu(ring, 2u, e);
+          hit.last.u = ring_ld(ring, 11u, e);
+          hit.last.v = ring_ld(ring, 12u, e);
+        }
+        P.Ls = {0, 0, 0};
+        hit.depth_ok = true;
+        hit.need_dir = false;
+        busy = true;
+        resumed = true;
+      }
+      head = (head + take) & (PT_PARK_Q - 1u);
+      n_done -= take;
+      idle = __ballot(!busy);
+    }
+    while (idle != 0 && next_job < pool)
+    {
+      if (next_job == made_jobs)
+      {
+        const uint32_t job = made_jobs + lane;
+        if (job < pool)
+        {
+          DIAG(6, 1);
+          DIAG_LANES(7);
+          uint32_t idx, s;
+          if (n_valid == 16)
+          {
+            idx = job & 15u;
+            s = job >> 4;
+          }
+          else
+          {
+            s = job / n_valid;
+            idx = job - s * n_valid;
+          }
+          const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
+          const uint32_t col = idx - row * vcols;
+          const uint32_t slot_in_tile = (2u * wave + row) * PT_TILE + col;
+          Path Q;
+          start_sample(Q, cam, pix_key[slot_in_tile], tx0 + col, ty0 + row, s_begin + s);
+          qd[lane] = Q.d.x;
+          qd[64 + lane] = Q.d.y;
+          qd[128 + lane] = Q.d.z;
+          qr[lane] = Q.rng;
+          qp[lane] = slot_in_tile;
+        }
+        made_jobs = min(made_jobs + 64u, pool);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      const uint32_t job = next_job + rank;
+      if (!busy && job < made_jobs)
+      {
+        const uint32_t q = job & 63u;
+        P.o = cam.pos;
+        P.d = {qd[q], qd[64 + q], qd[128 + q]};
+        P.rng = qr[q];
+        pix_slot = qp[q];
+        P.T = {1, 1, 1};
+        P.Ls = {0, 0, 0};
+        P.depth = 0;
+        hit.need_dir = false;
+        busy = true;
+      }
+      next_job = min(next_job + (uint32_t)__popcll(idle), made_jobs);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      idle = __ballot(!busy);
+    }
+    /* nobody holds a ray: the pool is dry and no walked ray is left (an idle lane would have taken
+     * it).  Parked rays, if any, are walked in this trip; otherwise this is the one exit. */
+    const bool drained = __ballot(busy) == 0;
+    if (drained && n_new == 0u)
+      break;
+
+    /* ---- first half of trace_path(): depth test + flat scan over the spheres, then the probe ---- */
+    const bool stepping = busy && !hit.need_dir && !resumed;
+    bool want_walk = false;
+    if (stepping)
+    {
+      DIAG(0, 1);
+      DIAG_LANES(1);
+      n_rays++;
+      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+      const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
+      want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
+                                            (CHECKER && S.stale_uv) ? S.t_start : hit.min_t);
+    }
+    /* ---- rays that can reach the mesh are parked; their lanes are idle from here on ---- */
+    const unsigned long long wants = __ballot(want_walk);
+    bool parked = false;
+    if (wants != 0)
+    {
+      if (ring_ok)
+      {
+        const uint32_t space = PT_PARK_Q - n_done - n_new;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
+        if (want_walk && rank < space)
+        {
+          const uint32_t e = (head + n_done + n_new + rank) & (PT_PARK_Q - 1u);
+          ring_st3(ring, 0u, e, P.o);
+          ring_st3(ring, 3u, e, P.d);
+          ring_st3(ring, 6u, e, P.T);
+          ring_st(ring, 9u, e, __longlong_as_double((long long)P.rng));
+          ring_st(ring, 10u, e, hit.min_t);
+          ring.u[0u * PT_PARK_Q + e] = (uint32_t)hit.best;
+          ring.u[1u * PT_PARK_Q + e] = ((uint32_t)P.depth << 6) | pix_slot;
+          parked = true;
+          busy = false;
+        }
+        n_new += min((uint32_t)__popcll(wants), space);
+      }
+    }
+    /* ---- the wave turns to walking: enough rays parked, nothing else to do, or a ray that found no
+     * room in the ring (it is walked from its lane's registers, in the same pass) ---- */
+    const bool walk_own = want_walk && !parked;
+    if (n_new >= PT_PARK_WALK || drained || __ballot(walk_own) != 0)
+    {
+      walk_parked<CHECKER>(S, ring, (head + n_done) & (PT_PARK_Q - 1u), n_new, stack, diag_ptr, walk_own, P.o, P.d, hit);
+      n_done += n_new;
+      n_new = 0u;
+    }
+
+    /* ---- second half: hit record, roulette, material -- for rays scanned now and not parked, and for
+     * walked rays resumed at the top of this trip ---- */
+    bool step_done = false;
+    if (busy && (stepping || resumed))
+      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+
+    /* ---- directions of diffuse hits (see render_tiles_pooled) ---- */
+    if (busy && hit.need_dir)
+    {
+      V3 q;
+      double len2;
+      bool again = true;
+      for (int round = 0; round < PT_DIR_ROUNDS && again; round++)
+      {
+        DIAG(10, 1);
+        DIAG_LANES(11);
+        again = rejection_round(P.rng, q, len2);
+      }
+      if (!again)
+      {
+        const double *m = S.mat + PT_MAT_STRIDE * hit.dir_slot;
+        V3 albedo = ld3(m + 1);
+        if (CHECKER)
+          albedo = v_scale(albedo, hit.dir_scale);
+        const V3 n = P.d;
+        double weight;
+        P.d = hemisphere_from_sample(q, len2, n, weight);
+        P.T = v_mul(P.T, v_scale(albedo, weight));
+        hit.need_dir = false;
+      }
+    }
+    if (busy)
+    {
+      /* this trip's radiance terms go to the pixel's fixed-point sum at once (integer adds commute and
+       * associate: the sum does not depend on the order or the grouping of the terms) */
+      if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
+      {
+        atomicAdd(&pix_sum[3 * pix_slot + 0], (unsigned long long)__double2ll_rn(P.Ls.x * L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 1], (unsigned long long)__double2ll_rn(P.Ls.y * L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 2], (unsigned long long)__double2ll_rn(P.Ls.z * L.acc_scale));
+        if ((int)(P.Ls.x != P.Ls.x) | (int)(P.Ls.y != P.Ls.y) | (int)(P.Ls.z != P.Ls.z))
+        {
+          if (P.Ls.x != P.Ls.x) atomicOr(&pix_nan[0], 1ull << pix_slot);
+          if (P.Ls.y != P.Ls.y) atomicOr(&pix_nan[1], 1ull << pix_slot);
+          if (P.Ls.z != P.Ls.z) atomicOr(&pix_nan[2], 1ull << pix_slot);
+        }
+        P.Ls = {0, 0, 0};
+      }
+      if (step_done)
+        busy = false;
+    }
+  }
+
+  if (n_rays)
+  {
+    atomicAdd(&wg_stats[0], (unsigned long long)n_rays);
+    atomicAdd(&wg_stats[1], (unsigned long long)n_casts);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && ring_ok)
+    atomicExch(&L.park_flags[park_slot], 0u); /* every wave is past its last ring access */
+
+  if (L.sample_chunks == 1)
+  {
+    finish_pixels(L, pix_sum, pix_nan, tile, out_f, out_b);
+    __syncthreads();
+    store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, true, true);
+  }
+  else
+  {
+    if (threadIdx.x < PT_TILE_PIXELS * 3 && pix_sum[threadIdx.x] != 0)
+      atomicAdd(&L.acc_ws[(size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x], pix_sum[threadIdx.x]);
+    if (threadIdx.x < 3 && pix_nan[threadIdx.x] != 0)
+      atomicOr(&L.acc_ws[(size_t)L.tile_count * (PT_TILE_PIXELS * 3) + (size_t)slot * 3 + threadIdx.x], pix_nan[threadIdx.x]);
+    store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, false, chunk == 0);
+  }
+}
+
 /* Kernel family pt_render_tiles[_tri][_big][_chk|_refr], picked by scene content
  * (pt_launch_render): "_tri" = scene has triangles; "_big" = the filter table is not in LDS
  * (more than PT_FILT_LDS_MAX primitives, or centres / radii beyond fp32's comfortable range):
@@ -1631,6 +2254,18 @@ PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, fal
 PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
 PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_TRI), false, true, true)
 PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, 4), false, true, false) /* 24 KB of traversal stacks: 4 workgroups per CU */
+/* the hierarchy kernels with parked walks; the pooled ones above stay selectable (RT_HIP_KERNEL_VARIANT=2) for A/B */
+#ifndef PT_MIN_WAVES_QUEUED
+#define PT_MIN_WAVES_QUEUED 4
+#endif
+extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED) void pt_render_tiles_tri_queued(const PtLaunch L)
+{
+  render_tiles_queued<false>(L);
+}
+extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_tri_queued_chk(const PtLaunch L)
+{
+  render_tiles_queued<true>(L);
+}
 PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK), true, false, true)
 PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK), true, false, false)
 PT_KERNEL(pt_render_tiles_tri_chk, __launch_bounds__(PT_BLOCK), true, true, true)
@@ -1648,7 +2283,7 @@ PT_KERNEL(pt_render_tiles_tri_big_chk, __launch_bounds__(PT_BLOCK), true, true, 
 template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int WHITTED, bool GEOM_LDS>
 __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
 {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ float out_f[PT_TILE_PIXELS * 3];
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
@@ -1830,15 +2465,16 @@ extern "C" __global__ __launch_bounds__(256) void pt_selftest_math(int op, const
  * pt_build_filter made of all n primitives for near_R, so block b's pairs are those of the 64
  * primitives of the block.  Every lane runs phase 1 over them with its own ray, in the three
  * forms the render kernels use, and stores the 64-bit keep masks:
- *   keep[3i + 0]  sign-test form from LDS (pt_render_tiles; spheres only, all ones for kind 1)
+ *   keep[3i + 0]  spheres: sign-test form from LDS (pt_render_tiles); triangles: the per-lane fp32
+ *                 Moeller-Trumbore pre-test (tri_may_hit32) instead
  *   keep[3i + 1]  compare form from LDS, push_keep_bit (pt_render_tiles_tri)
  *   keep[3i + 2]  compare form, table by scalar loads (the _big kernels)
  * bit j = ray i keeps primitive 64 b + j.  A test can so check 64 n (ray, primitive) pairs:
  * the filter must keep every pair the exact test accepts. */
 extern "C" __global__ __launch_bounds__(64) void pt_selftest_intersect(int kind, const double *rays, const double *prims,
-                                                                      const f32x2 *filt, uint32_t n, double near_R2,
-                                                                      double filt_shift, double t_start, uint8_t *hit,
-                                                                      double *tuv, unsigned long long *keep)
+                                                                      const f32x2 *filt, const float4 *tri32, uint32_t n,
+                                                                      double near_R2, double filt_shift, double t_start,
+                                                                      uint8_t *hit, double *tuv, unsigned long long *keep)
 {
   __shared__ f32x2 filt_lds[PT_FILT_STRIDE * 33]; /* 32 pairs + the look-ahead pair */
   const uint32_t base = blockIdx.x * 64u;
@@ -1867,6 +2503,13 @@ extern "C" __global__ __launch_bounds__(64) void pt_selftest_intersect(int kind,
     m0 = ((unsigned long long)hi << 32) | lo;
   }
   const FiltRay fr = filter_ray<false>(o, d, filt_shift, near_R2);
+  if (kind == 1)
+  { /* the per-lane fp32 pre-test (tri_may_hit32) of this ray against every triangle of the block */
+    m0 = 0;
+    for (uint32_t j = 0; j < chunk; j++)
+      if (fr.far_origin || tri_may_hit32(tri32 + (PT_TRI32_STRIDE / 4) * (size_t)(base + j), fr.ox, fr.oy, fr.oz, fr.dx.x, fr.dy.x, fr.dz.x))
+        m0 |= 1ull << j;
+  }
   filter_chunk<true, true>(filt_lds, 0u, chunk, fr.ox, fr.oy, fr.oz, fr.dx, fr.dy, fr.dz, fr.far_origin, lo, hi);
   m1 = ((unsigned long long)hi << 32) | lo;
   filter_chunk<false, false>(filt, base, chunk, fr.ox, fr.oy, fr.oz, fr.dx, fr.dy, fr.dz, fr.far_origin, lo, hi);
@@ -1925,6 +2568,34 @@ extern "C" __global__ __launch_bounds__(256) void pt_build_bvh(const double *bvh
     dst[13] = __uint_as_float(refs[1]);
     dst[14] = 0.f;
     dst[15] = 0.f;
+  }
+}
+
+/* The fp32 triangle table of tri_may_hit32 for one near_R: v0, e1, e2 rounded to nearest, the four
+ * thresholds formed in fp64 and rounded up. */
+extern "C" __global__ __launch_bounds__(256) void pt_build_tri32(const double *tri_geom, uint32_t n_tri, double near_R,
+                                                                float *out)
+{
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tri; t += gridDim.x * blockDim.x)
+  {
+    const double *g = tri_geom + 9 * (size_t)t;
+    float *f = out + PT_TRI32_STRIDE * (size_t)t;
+    for (int k = 0; k < 9; k++)
+      f[k] = (float)g[k];
+    const double e = 5.9604644775390625e-08;
+    const double l0 = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), l1 = sqrt(g[3] * g[3] + g[4] * g[4] + g[5] * g[5]),
+                 l2 = sqrt(g[6] * g[6] + g[7] * g[7] + g[8] * g[8]);
+    const double S = (near_R + l0) * 1.0001;
+    const double up = 1.0 + 4.0 * e;
+    double Ea = 16.0 * e * l1 * l2 * up, KU = 20.0 * e * S * l2 * up, KV = 20.0 * e * S * l1 * up, KT = 20.0 * e * S * l1 * l2 * up;
+    /* products near fp32's range (or non-finite input): the pre-test keeps the triangle whatever it computes */
+    if (!(S * l1 * l2 < 1e30) || !(l1 * l2 < 1e30))
+      Ea = __longlong_as_double(0x7FF0000000000000ll);
+    f[9] = __double2float_ru(Ea);
+    f[10] = __double2float_ru(KU);
+    f[11] = __double2float_ru(KV);
+    f[12] = __double2float_ru(KT);
+    f[13] = f[14] = f[15] = 0.f;
   }
 }
 
@@ -2000,7 +2671,7 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
   size_t doubles = PT_GEOM_STRIDE * (size_t)sc.n_spheres + PT_MAT_STRIDE * (size_t)(sc.n_spheres + sc.n_meshes);
   const size_t n_entries = (size_t)sc.n_spheres + sc.n_triangles;
   if (pt_filter_in_lds(sc))
-    doubles += PT_FILT_STRIDE * ((n_entries + 1) / 2 + 1); /* f32x2 = one double-sized slot */
+    doubles += pt_filt_pair_slots((uint32_t)n_entries) + (size_t)sc.n_triangles * (PT_TRI32_STRIDE / 2); /* f32x2 = one double-sized slot */
   return doubles * sizeof(double);
 }
 
@@ -2008,12 +2679,13 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
  * pt_launch_render, also reported by rt_hip_kernel_name for profiles and bench lines) */
 static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name)
 {
-  static const char *const names[19] = {
+  static const char *const names[21] = {
       "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
       "pt_render_tiles_chk",  "pt_render_tiles_big_chk",  "pt_render_tiles_tri_chk",  "pt_render_tiles_tri_big_chk",
       "pt_render_tiles_refr", "pt_render_tiles_big_refr", "pt_render_tiles_tri_refr", "pt_render_tiles_tri_big_refr",
       "pt_render_tiles_v0",   "pt_whitted_tiles",         "pt_whitted_tiles_big",     "pt_whitted_tiles_tri",
-      "pt_whitted_tiles_tri_big", "pt_render_tiles_mem",  "pt_whitted_tiles_mem"};
+      "pt_whitted_tiles_tri_big", "pt_render_tiles_mem",  "pt_whitted_tiles_mem",
+      "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk"};
   const bool tris = scene.n_triangles != 0;
   const bool big = !pt_filter_in_lds(scene);
   const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
@@ -2025,6 +2697,8 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
     which = cast_ray ? 18 : 17;
   else if (variant == 0 && !refr && !cast_ray)
     which = 12;
+  else if ((which == 3 || which == 7) && variant != 2)
+    which = which == 3 ? 19 : 20; /* hierarchy scenes: parked walks (variant 2 keeps the lane-waiting pooled kernels) */
   if (name)
     *name = names[which];
   return which;
@@ -2052,6 +2726,9 @@ hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float
   if (n_nodes)
     hipLaunchKernelGGL(pt_build_bvh, dim3(min(1024u, (n_nodes + 255u) / 256u)), dim3(256), 0, stream, scene.bvh_src,
                        n_nodes, near_R, bvh_nodes);
+  if (scene.n_triangles != 0 && pt_filter_in_lds(scene)) /* small scenes: the pre-test table behind the pair table */
+    hipLaunchKernelGGL(pt_build_tri32, dim3((scene.n_triangles + 255u) / 256u), dim3(256), 0, stream, scene.tri_geom,
+                       scene.n_triangles, near_R, filt + 2 * (size_t)pt_filt_pair_slots(n_entries));
   return hipGetLastError();
 }
 
@@ -2063,16 +2740,19 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
     const char *e = getenv("RT_HIP_EXTRA_LDS");
     return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)0;
   }();
-  const size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
+  size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[19] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
+  static const Kernel family[21] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
                                     pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr,
                                     pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
-                                    pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem};
+                                    pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem,
+                                    pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk};
   const int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr);
   const Kernel kernel = family[which];
-  static size_t lds_allowed[19] = {0}; /* raised once per process if a scene needs > 64 KiB */
+  if (which >= 19) /* per-lane traversal stacks sized by the tree, after the staged scene */
+    lds_bytes += (size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * sizeof(uint32_t);
+  static size_t lds_allowed[21] = {0}; /* raised once per process if a scene needs > 64 KiB */
   size_t &allowed = lds_allowed[which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {
@@ -2095,15 +2775,17 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
 }
 
 hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,
-                                        float *filt, uint32_t n, double near_R, double filt_shift, uint8_t *hit,
-                                        double *tuv, unsigned long long *keep, hipStream_t stream)
+                                        float *filt, float *tri32, uint32_t n, double near_R, double filt_shift,
+                                        uint8_t *hit, double *tuv, unsigned long long *keep, hipStream_t stream)
 {
   if (n == 0)
     return hipSuccess;
   hipLaunchKernelGGL(pt_build_filter, dim3(min(1024u, (n + 255u) / 256u)), dim3(256), 0, stream, entry_src, n, near_R, filt);
+  if (kind == 1)
+    hipLaunchKernelGGL(pt_build_tri32, dim3((n + 255u) / 256u), dim3(256), 0, stream, prims, n, near_R, tri32);
   hipLaunchKernelGGL(pt_selftest_intersect, dim3((n + 63u) / 64u), dim3(64), 0, stream, kind, rays, prims,
-                     reinterpret_cast<const f32x2 *>(filt), n, near_R * near_R, filt_shift, 1.7976931348623157e308, hit,
-                     tuv, keep);
+                     reinterpret_cast<const f32x2 *>(filt), reinterpret_cast<const float4 *>(tri32), n, near_R * near_R,
+                     filt_shift, 1.7976931348623157e308, hit, tuv, keep);
   return hipGetLastError();
 }
 

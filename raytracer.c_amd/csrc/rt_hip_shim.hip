@@ -51,6 +51,10 @@ struct RtHipScene
   mutable std::vector<TableSet> tables;
   mutable uint64_t table_clock = 0;
   size_t filt_bytes = 0, bvh_nodes_bytes = 0;
+  /* workspace of the parked-walk kernels (scenes with a triangle hierarchy), allocated at the first
+   * launch that can use it: in-use flags, then the rings (pt_device.h) */
+  mutable char *park_ws = nullptr;
+  mutable bool park_tried = false;
   void *blob = nullptr; /* one device allocation holding every array */
   double reach = 0;     /* >= |p| for every point p on a primitive of ordinary size (radius < 1000) */
   double max_emission = 0; /* max |emission component| over all materials */
@@ -284,12 +288,13 @@ struct BvhBuild
   }
 };
 
-/* development switch: RT_HIP_KERNEL_VARIANT=0 selects the literal single-phase scan */
+/* development switch: RT_HIP_KERNEL_VARIANT=0 selects the literal single-phase scan, 2 the pooled
+ * (lane-waiting) kernels for hierarchy scenes instead of the parked-walk ones */
 int kernel_variant()
 {
   static const int v = [] {
     const char *e = getenv("RT_HIP_KERNEL_VARIANT");
-    return (e && e[0] == '0') ? 0 : 1;
+    return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); /* 2: hierarchy scenes on the lane-waiting pooled kernels */
   }();
   return v;
 }
@@ -618,7 +623,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   const size_t off_tobj = off_ttex + pad(ttex.size() * 8);
   const size_t off_filt = off_tobj + pad(tobj.size() * 4);
   /* + 1 pair: the scan's software pipeline reads one pair past the end */
-  const size_t filt_bytes = ((n_spheres + n_tri + 1) / 2 + 1) * (size_t)PT_FILT_STRIDE * 2 * sizeof(float);
+  const size_t filt_bytes = pt_filt_bytes((uint32_t)n_spheres, (uint32_t)n_tri);
   const size_t off_bvh_src = off_filt + pad(filt_bytes);
   const size_t off_bvh_nodes = off_bvh_src + pad(bvh.nodes.size() * 8);
   const size_t off_bvh_tri = off_bvh_nodes + pad(n_bvh_nodes * PT_BVH_NODE_WORDS * 4);
@@ -662,6 +667,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.bvh_nodes = reinterpret_cast<float *>(base + off_bvh_nodes);
   sc->view.bvh_tri = reinterpret_cast<const uint32_t *>(base + off_bvh_tri);
   sc->view.n_bvh_nodes = (uint32_t)n_bvh_nodes;
+  sc->view.bvh_depth = (uint32_t)bvh.depth;
   sc->filt_bytes = filt_bytes;
   sc->bvh_nodes_bytes = n_bvh_nodes * PT_BVH_NODE_WORDS * 4;
   sc->view.material = reinterpret_cast<const double *>(base + off_mat);
@@ -707,6 +713,7 @@ void rt_hip_scene_destroy(RtHipScene *scene)
         (void)hipFree(t.bvh_nodes);
       }
     }
+    (void)hipFree(scene->park_ws);
     (void)hipFree(scene->blob);
   }
   delete scene;
@@ -846,6 +853,36 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
 
   DeviceScope scope(scene->device);
   HIP_TRY(scope.status);
+  if (scene->view.n_bvh_nodes != 0 && !cast_ray)
+  {
+    /* parked-walk workspace: flags (zeroed once; the kernels leave them zero) + rings.  Without it the
+     * kernel still renders, walking in the lanes. */
+    std::lock_guard<std::mutex> lock(scene->table_mutex);
+    if (!scene->park_tried)
+    {
+      scene->park_tried = true;
+      const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD;
+      const size_t flag_bytes = (n_slots * sizeof(uint32_t) + 255) & ~(size_t)255;
+      char *ws = nullptr;
+      if (hipMalloc(&ws, flag_bytes + n_slots * (PT_BLOCK / 64) * (size_t)PT_PARK_WAVE_BYTES) == hipSuccess)
+      {
+        /* the flags must be zero before a kernel on ANY stream looks at them */
+        if (hipMemset(ws, 0, flag_bytes) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess)
+          scene->park_ws = ws;
+        else
+          (void)hipFree(ws);
+      }
+      else
+        (void)hipGetLastError();
+    }
+    if (scene->park_ws)
+    {
+      const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD;
+      L.park_flags = reinterpret_cast<uint32_t *>(scene->park_ws);
+      L.park_ws = scene->park_ws + ((n_slots * sizeof(uint32_t) + 255) & ~(size_t)255);
+      L.park_slots_per_xcd = PT_PARK_SLOTS_PER_XCD;
+    }
+  }
   size_t slot = 0;
   rc = acquire_tables(scene, L.near_R, static_cast<hipStream_t>(stream), &L.scene.filt, &L.scene.bvh_nodes, &slot);
   if (rc)
@@ -918,9 +955,10 @@ int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_pr
     const size_t filt_bytes = (n_blocks * 32 + 1) * (size_t)PT_FILT_STRIDE * 2 * sizeof(float);
     const size_t b_rays = 6 * n * 8, b_prims = rec * n * 8, b_entry = entry.size() * 8, b_tuv = 3 * n * 8, b_keep = 3 * n * 8;
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_tri32 = kind == 1 ? n * PT_TRI32_STRIDE * sizeof(float) : 0;
     const size_t o_rays = 0, o_prims = o_rays + pad(b_rays), o_entry = o_prims + pad(b_prims), o_filt = o_entry + pad(b_entry),
-                 o_tuv = o_filt + pad(filt_bytes), o_keep = o_tuv + pad(b_tuv), o_hit = o_keep + pad(b_keep),
-                 total = o_hit + pad(n);
+                 o_tri32 = o_filt + pad(filt_bytes), o_tuv = o_tri32 + pad(b_tri32), o_keep = o_tuv + pad(b_tuv),
+                 o_hit = o_keep + pad(b_keep), total = o_hit + pad(n);
     DeviceScope scope(device);
     HIP_TRY(scope.status);
     char *d = nullptr;
@@ -934,7 +972,7 @@ int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_pr
     if (e == hipSuccess)
       e = pt_launch_selftest_intersect(kind, reinterpret_cast<double *>(d + o_rays), reinterpret_cast<double *>(d + o_prims),
                                        reinterpret_cast<double *>(d + o_entry), reinterpret_cast<float *>(d + o_filt),
-                                       (uint32_t)n, near_R, filt_shift, reinterpret_cast<uint8_t *>(d + o_hit),
+                                       reinterpret_cast<float *>(d + o_tri32), (uint32_t)n, near_R, filt_shift, reinterpret_cast<uint8_t *>(d + o_hit),
                                        reinterpret_cast<double *>(d + o_tuv), reinterpret_cast<unsigned long long *>(d + o_keep),
                                        nullptr);
     if (e == hipSuccess) e = hipMemcpy(h_hit, d + o_hit, n, hipMemcpyDeviceToHost);
