@@ -1487,6 +1487,9 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   uint32_t n_rays = 0, n_casts = 0;
   /* kernels with a triangle hierarchy postpone its walks (see the loop) */
   constexpr bool DEFER_MESH = TRIS && !FILT_LDS;
+  /* small-mesh kernels keep throughput and radiance in LDS across the scan (see the loop) */
+  constexpr bool PARK_T = TRIS && FILT_LDS && !CHECKER;
+  __shared__ double t_park[PARK_T ? 6 : 1][PARK_T ? PT_BLOCK : 1];
   HitRec hit;
   hit.min_t = 0;
   hit.bary_u = 0;
@@ -1622,6 +1625,31 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       trip++;
       if (stepping && !mesh_wait)
         step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+    }
+    else if (PARK_T)
+    {
+      /* small-mesh kernels: the scan (filter, fp32 pre-test, exact sphere and triangle tests) needs
+       * every register it can get and touches neither the throughput nor the gathered radiance, so
+       * both sit in LDS while it runs (the compiler otherwise spills ten registers to scratch around
+       * it): trace_path() in its two halves, as in the hierarchy kernels */
+      if (stepping)
+      {
+        DIAG(0, 1);
+        DIAG_LANES(1);
+        n_rays++;
+        t_park[0][threadIdx.x] = P.T.x;
+        t_park[1][threadIdx.x] = P.T.y;
+        t_park[2][threadIdx.x] = P.T.z;
+        t_park[3][threadIdx.x] = P.Ls.x;
+        t_park[4][threadIdx.x] = P.Ls.y;
+        t_park[5][threadIdx.x] = P.Ls.z;
+        asm volatile("" ::: "memory"); /* no store-to-load forwarding: the values must leave the registers */
+        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+        asm volatile("" ::: "memory");
+        P.T = {t_park[0][threadIdx.x], t_park[1][threadIdx.x], t_park[2][threadIdx.x]};
+        P.Ls = {t_park[3][threadIdx.x], t_park[4][threadIdx.x], t_park[5][threadIdx.x]};
+        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+      }
     }
     else if (stepping)
     {
@@ -2383,18 +2411,24 @@ PT_KERNEL_STATIC(pt_render_tiles_tri_big_refr, 1, true, true, true, false)
 
 /* cast_ray kernels: the static body with whitted_step, without a pending-ray stack (scenes with
  * a material that has both M_REFLECTION and M_REFRACTION take pt_whitted_tiles_mem) */
+/* Launch bounds measured on the MI355X (1920x1080 x 64 spp, ms at 4 / 3 / 2 waves per SIMD): spheres
+ * (config 4) 8.2 / 8.4 / 9.4; small mesh (config 3) 6.2 / 5.2 / 6.5; hierarchy (config 5, 4K x 8 spp)
+ * 8.6 / 8.1 / 8.9.  None of the three is free of scratch below 2 waves (228-308 B at 4, 44-156 B at 3). */
 #ifndef PT_MIN_WAVES_WHITTED
 #define PT_MIN_WAVES_WHITTED 4
 #endif
-#define PT_KERNEL_WHITTED(name, TRIS, FILT_LDS)                                              \
-  extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_WHITTED) void name(const PtLaunch L) \
+#ifndef PT_MIN_WAVES_WHITTED_TRI
+#define PT_MIN_WAVES_WHITTED_TRI 3
+#endif
+#define PT_KERNEL_WHITTED(name, WAVES, TRIS, FILT_LDS)                                       \
+  extern "C" __global__ __launch_bounds__(PT_BLOCK, WAVES) void name(const PtLaunch L)      \
   {                                                                                         \
     render_tiles_static<1, false, true, TRIS, FILT_LDS, 1, true>(L);                        \
   }
-PT_KERNEL_WHITTED(pt_whitted_tiles, false, true)
-PT_KERNEL_WHITTED(pt_whitted_tiles_big, false, false)
-PT_KERNEL_WHITTED(pt_whitted_tiles_tri, true, true)
-PT_KERNEL_WHITTED(pt_whitted_tiles_tri_big, true, false)
+PT_KERNEL_WHITTED(pt_whitted_tiles, PT_MIN_WAVES_WHITTED, false, true)
+PT_KERNEL_WHITTED(pt_whitted_tiles_big, PT_MIN_WAVES_WHITTED, false, false)
+PT_KERNEL_WHITTED(pt_whitted_tiles_tri, PT_MIN_WAVES_WHITTED_TRI, true, true)
+PT_KERNEL_WHITTED(pt_whitted_tiles_tri_big, PT_MIN_WAVES_WHITTED_TRI, true, false)
 #undef PT_KERNEL_WHITTED
 
 /* Scenes whose sphere geometry + materials exceed the LDS staging budget (pt_geom_in_lds: more
