@@ -1767,6 +1767,12 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 #ifndef PT_PARK_WALK
 #define PT_PARK_WALK 190u /* parked rays that turn the wave to walking (measured at 4K x 256 spp: 32: 664 ms, 64: 553, 128: 529, 190: 521) */
 #endif
+#ifndef PT_STAGE
+#define PT_STAGE 32u /* walked rays copied from the ring to LDS at a time (<= 64) */
+#endif
+#ifndef PT_REFILL_BATCH
+#define PT_REFILL_BATCH 16u /* free lanes that trigger a refill from the ring inside a walk phase */
+#endif
 #ifndef PT_LEAF_BATCH
 #define PT_LEAF_BATCH 24u /* lanes holding a leaf that trigger a round of exact triangle tests */
 #endif
@@ -1852,8 +1858,10 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
   const bool no_prune = CHECKER && S.stale_uv;
   for (;;)
   {
+    /* refill in batches: every refill is a memory round trip the whole wave waits for, so free lanes
+     * wait until PT_REFILL_BATCH of them are free (or nobody has a ray left) */
     const unsigned long long need = __ballot(!have);
-    if (need != 0 && next < n_new)
+    if (next < n_new && ((uint32_t)__popcll(need) >= PT_REFILL_BATCH || need == ~0ull))
     {
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
       if (!have && next + rank < n_new)
@@ -1967,6 +1975,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   __shared__ unsigned long long q_rng[PT_BLOCK / 64][64];
   __shared__ uint32_t q_pix[PT_BLOCK / 64][64];
   __shared__ uint32_t park_slot_lds;
+  /* walked rays on their way back into lanes: PT_STAGE at a time are copied from the ring into LDS
+   * (one memory round trip for the batch) and handed out from there -- a few idle lanes taking them
+   * straight from the ring would put that round trip at the head of every trip */
+  constexpr uint32_t STAGE_F = CHECKER ? 13u : 11u, STAGE_U = CHECKER ? 3u : 2u;
+  __shared__ double st_f[PT_BLOCK / 64][STAGE_F][PT_STAGE];
+  __shared__ uint32_t st_u[PT_BLOCK / 64][STAGE_U][PT_STAGE];
 
   const SceneCtx S = stage_scene<true, FILT_LDS>(L, lds);
   /* the traversal stacks follow the staged scene in dynamic LDS: one entry per tree level and lane */
@@ -2031,6 +2045,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   hit.last.v = 0;
   uint32_t next_job = 0, made_jobs = 0; /* wave-uniform, as in render_tiles_pooled */
   uint32_t head = 0, n_done = 0, n_new = 0; /* the ring (wave-uniform) */
+  uint32_t n_stage = 0, stage_off = 0;      /* walked rays staged in LDS: ring positions head .. head + n_stage (wave-uniform) */
   uint32_t pix_slot = 0;
   bool busy = false;
   int stack_n = 0;
@@ -2046,27 +2061,44 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     /* ---- idle lanes take work: walked rays first (that frees the ring), then camera samples ---- */
     unsigned long long idle = __ballot(!busy);
     bool resumed = false;
-    if (idle != 0 && n_done != 0u)
+    while (idle != 0 && n_done != 0u)
     {
+      if (n_stage == 0u)
+      {
+        /* stage the next walked rays: lane l copies ring entry head + l */
+        const uint32_t k = min(PT_STAGE, n_done);
+        if (lane < k)
+        {
+          const uint32_t e = (head + lane) & (PT_PARK_Q - 1u);
+          for (uint32_t f = 0; f < STAGE_F; f++)
+            st_f[wave][f][lane] = ring_ld(ring, f, e);
+          for (uint32_t f = 0; f < STAGE_U; f++)
+            st_u[wave][f][lane] = ring_ldu(ring, f, e);
+        }
+        n_stage = k;
+        stage_off = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-      const uint32_t take = min((uint32_t)__popcll(idle), n_done);
+      const uint32_t take = min((uint32_t)__popcll(idle), n_stage);
       if (!busy && rank < take)
       {
-        const uint32_t e = (head + rank) & (PT_PARK_Q - 1u);
-        P.o = ring_ld3(ring, 0u, e);
-        P.d = ring_ld3(ring, 3u, e);
-        P.T = ring_ld3(ring, 6u, e);
-        P.rng = (uint64_t)__double_as_longlong(ring_ld(ring, 9u, e));
-        hit.min_t = ring_ld(ring, 10u, e);
-        hit.best = (int)ring_ldu(ring, 0u, e);
-        const uint32_t dp = ring_ldu(ring, 1u, e);
+        const uint32_t q = stage_off + rank;
+        P.o = {st_f[wave][0][q], st_f[wave][1][q], st_f[wave][2][q]};
+        P.d = {st_f[wave][3][q], st_f[wave][4][q], st_f[wave][5][q]};
+        P.T = {st_f[wave][6][q], st_f[wave][7][q], st_f[wave][8][q]};
+        P.rng = (uint64_t)__double_as_longlong(st_f[wave][9][q]);
+        hit.min_t = st_f[wave][10][q];
+        hit.best = (int)st_u[wave][0][q];
+        const uint32_t dp = st_u[wave][1][q];
         P.depth = (int)(dp >> 6);
         pix_slot = dp & 63u;
         if (CHECKER)
         {
-          hit.last.idx = (int)ring_ldu(ring, 2u, e);
-          hit.last.u = ring_ld(ring, 11u, e);
-          hit.last.v = ring_ld(ring, 12u, e);
+          hit.last.idx = (int)st_u[wave][CHECKER ? 2 : 0][q];
+          hit.last.u = st_f[wave][CHECKER ? 11 : 0][q];
+          hit.last.v = st_f[wave][CHECKER ? 12 : 0][q];
         }
         P.Ls = {0, 0, 0};
         hit.depth_ok = true;
@@ -2074,8 +2106,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         busy = true;
         resumed = true;
       }
+      stage_off += take;
+      n_stage -= take;
       head = (head + take) & (PT_PARK_Q - 1u);
       n_done -= take;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       idle = __ballot(!busy);
     }
     while (idle != 0 && next_job < pool)
