@@ -307,7 +307,7 @@ def main():
     ap.add_argument("--cpu-tiles", type=int, default=2048, help="8x8 tiles of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the CPU baseline (0 = the CPUs this process may use)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration array")
-    ap.add_argument("--c5-spp", type=int, default=64, help="spp of config 5 in the per-configuration array (its own: 4096)")
+    ap.add_argument("--c5-spp", type=int, default=256, help="spp of config 5 in the per-configuration array (its own: 4096)")
     ap.add_argument("--host-path", action="store_true",
                     help="single process: time rt_hip_render_image() over --gpus devices (the C host's path) and exit")
     args = ap.parse_args()

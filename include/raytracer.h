@@ -4,7 +4,7 @@
  * A caller written against gue-ni/raytracer.c's raytracer.h (its main.c, its
  * test.c) compiles and links against this header + libraytracer_amd.so
  * unchanged: every struct below has the reference's field order, size and
- * offsets (checked against the compiled reference in tests/test_layout.py:
+ * offsets (checked against the compiled reference in tests/test_oracle_ref.py:
  * Object 88 B, Camera 96 B, Options 56 B, Ray 48 B, Hit 80 B, Vertex 40 B), and
  * every function the reference's raytracer.o exports is exported here with
  * the same signature (reference raytracer.h:135-164).

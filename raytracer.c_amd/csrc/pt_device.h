@@ -95,6 +95,8 @@ struct PtSceneView
   const double *bvh_src;
   float *bvh_nodes;
   const uint32_t *bvh_tri;
+  const double *tri_geom_leaf; /* n_triangles x 9: tri_geom in LEAF order (entry k belongs to triangle bvh_tri[k]), so a leaf's
+                                * triangles are contiguous and their loads do not wait for the index load */
   uint32_t n_spheres, n_meshes, n_triangles, any_checker;
   uint32_t any_refract, n_bvh_nodes; /* n_bvh_nodes == 0: the scene has no triangles */
   uint32_t wide_range;               /* a centre or radius beyond 1e17: fp32 sums could overflow */

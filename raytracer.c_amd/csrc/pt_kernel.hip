@@ -766,6 +766,7 @@ struct SceneCtx
   const float4 *tri32;    /* LDS: the fp32 triangle table of the pre-test (small scenes with triangles), else nullptr */
   const float *bvh_nodes; /* HBM: triangle hierarchy of large meshes (n_bvh_nodes may be 0) */
   const uint32_t *bvh_tri;
+  const double *tri_leaf; /* HBM: tri geometry in leaf order (pt_device.h) */
   uint32_t n_bvh_nodes;
   double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
   double filt_shift;      /* tol_max of the sign-test filter form (scan_filtered) */
@@ -836,6 +837,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.tri32 = FILT_LDS ? reinterpret_cast<const float4 *>(filt_lds + pt_filt_pair_slots(n_entries)) : nullptr;
   ctx.bvh_nodes = sc.bvh_nodes;
   ctx.bvh_tri = sc.bvh_tri;
+  ctx.tri_leaf = sc.tri_geom_leaf;
   ctx.n_bvh_nodes = sc.n_bvh_nodes;
   ctx.near_R2 = L.near_R2;
   ctx.filt_shift = L.filt_shift;
@@ -1753,8 +1755,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
  * samples and continue with the shading half of trace_step.  None of this can change a value: a
  * sample depends on its (seed, pixel, sample) stream alone, per-pixel sums are integers.
  *
- * The ring: PT_PARK_Q entries per wave, field-major (consecutive entries of one field are
- * consecutive addresses), positions [head, head + n_done) hold walked rays, then n_new parked
+ * The ring: PT_PARK_Q entries of 128 bytes per wave, positions [head, head + n_done) hold walked rays, then n_new parked
  * ones; all three counters are wave-uniform.  It lives in a workspace slot the workgroup takes
  * from a pool at entry and returns at exit (pt_park_acquire): the pool is partitioned by XCD
  * (HW_REG_XCC_ID of the running wave, not an assumption about placement), so every owner a slot
@@ -1778,21 +1779,26 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 #endif
 #define PT_PARK_F64_FIELDS 13u /* o xyz, d xyz, T xyz, rng, min_t, (M_CHECKERED kernels: last u, v) */
 #define PT_PARK_U32_FIELDS 4u  /* best, depth << 6 | pixel slot, (last index), pad */
-static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * (PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u), "ring bytes per wave");
+static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * 128u && PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u <= 128u, "ring bytes per wave");
 static_assert((PT_PARK_Q & (PT_PARK_Q - 1u)) == 0u && PT_PARK_WALK + 64u <= PT_PARK_Q, "ring size");
 
+/* entry-major: an entry is 128 contiguous bytes (13 doubles, then 4 words), so a lane's park or
+ * resume touches one or two cache lines and the L2 merges its stores into whole-line write-backs */
+#define PT_PARK_ENTRY_F64 16u
 struct ParkRing
 {
-  double *f;   /* [PT_PARK_F64_FIELDS][PT_PARK_Q] */
-  uint32_t *u; /* [PT_PARK_U32_FIELDS][PT_PARK_Q] */
+  double *f; /* [PT_PARK_Q][16]: fields 0..12 */
+  uint32_t *u; /* the same memory as words: [PT_PARK_Q][32], fields at words 26..29 */
 };
+__device__ __forceinline__ uint32_t ring_fi(uint32_t field, uint32_t e) { return e * PT_PARK_ENTRY_F64 + field; }
+__device__ __forceinline__ uint32_t ring_ui(uint32_t field, uint32_t e) { return e * (2u * PT_PARK_ENTRY_F64) + 2u * PT_PARK_F64_FIELDS + field; }
 
 /* ring loads bypass the vector L1 (agent-scope relaxed = `sc1`): a slot's earlier owner on this CU
  * may have left lines of it there */
 __device__ __forceinline__ double ring_ld(const ParkRing &r, uint32_t field, uint32_t e)
 {
   return __longlong_as_double((long long)__hip_atomic_load(
-      reinterpret_cast<unsigned long long *>(r.f + field * PT_PARK_Q + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      reinterpret_cast<unsigned long long *>(r.f + ring_fi(field, e)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ V3 ring_ld3(const ParkRing &r, uint32_t field, uint32_t e)
 {
@@ -1800,9 +1806,10 @@ __device__ __forceinline__ V3 ring_ld3(const ParkRing &r, uint32_t field, uint32
 }
 __device__ __forceinline__ uint32_t ring_ldu(const ParkRing &r, uint32_t field, uint32_t e)
 {
-  return __hip_atomic_load(r.u + field * PT_PARK_Q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(r.u + ring_ui(field, e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void ring_st(const ParkRing &r, uint32_t field, uint32_t e, double v) { r.f[field * PT_PARK_Q + e] = v; }
+__device__ __forceinline__ void ring_st(const ParkRing &r, uint32_t field, uint32_t e, double v) { r.f[ring_fi(field, e)] = v; }
+__device__ __forceinline__ void ring_stu(const ParkRing &r, uint32_t field, uint32_t e, uint32_t v) { r.u[ring_ui(field, e)] = v; }
 __device__ __forceinline__ void ring_st3(const ParkRing &r, uint32_t field, uint32_t e, const V3 &v)
 {
   ring_st(r, field, e, v.x);
@@ -1923,7 +1930,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
       {
         DIAG(14, 1);
         const uint32_t t = S.bvh_tri[first_tri + k];
-        exact_triangle<true, CHECKER>(S.tri + 9 * (size_t)t, S.n_sph + t, wo, wd, wmin_t, wbest, bu, bv, &last);
+        exact_triangle<true, CHECKER>(S.tri_leaf + 9 * (size_t)(first_tri + k), S.n_sph + t, wo, wd, wmin_t, wbest, bu, bv, &last);
       }
       if (sp == 0)
         finished = true;
@@ -1946,10 +1953,10 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
       else
       {
         ring_st(ring, 10u, e, wmin_t);
-        ring.u[0u * PT_PARK_Q + e] = (uint32_t)wbest;
+        ring_stu(ring, 0u, e, (uint32_t)wbest);
         if (CHECKER)
         {
-          ring.u[2u * PT_PARK_Q + e] = (uint32_t)last.idx;
+          ring_stu(ring, 2u, e, (uint32_t)last.idx);
           ring_st(ring, 11u, e, last.u);
           ring_st(ring, 12u, e, last.v);
         }
@@ -2020,7 +2027,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   {
     char *base = L.park_ws + ((size_t)(ring_ok ? park_slot : 0u) * (PT_BLOCK / 64) + wave) * PT_PARK_WAVE_BYTES;
     ring.f = reinterpret_cast<double *>(base);
-    ring.u = reinterpret_cast<uint32_t *>(base + (size_t)PT_PARK_Q * PT_PARK_F64_FIELDS * 8u);
+    ring.u = reinterpret_cast<uint32_t *>(base);
   }
 
   Path P;
@@ -2205,8 +2212,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           ring_st3(ring, 6u, e, P.T);
           ring_st(ring, 9u, e, __longlong_as_double((long long)P.rng));
           ring_st(ring, 10u, e, hit.min_t);
-          ring.u[0u * PT_PARK_Q + e] = (uint32_t)hit.best;
-          ring.u[1u * PT_PARK_Q + e] = ((uint32_t)P.depth << 6) | pix_slot;
+          ring_stu(ring, 0u, e, (uint32_t)hit.best);
+          ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot);
           parked = true;
           busy = false;
         }

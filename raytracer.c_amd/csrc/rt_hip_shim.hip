@@ -610,6 +610,9 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
       return fail(RT_HIP_ELIMIT, "triangle hierarchy depth %d exceeds the traversal stack (%d)", bvh.depth, PT_BVH_STACK);
   }
   const size_t n_bvh_nodes = bvh.nodes.size() / PT_BVH_SRC_DOUBLES;
+  std::vector<double> tgeom_leaf(9 * bvh.order.size());
+  for (size_t k = 0; k < bvh.order.size(); k++)
+    memcpy(&tgeom_leaf[9 * k], &tgeom[9 * (size_t)bvh.order[k]], 9 * sizeof(double));
 
   /* ---- one device blob ---- */
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -627,7 +630,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   const size_t off_bvh_src = off_filt + pad(filt_bytes);
   const size_t off_bvh_nodes = off_bvh_src + pad(bvh.nodes.size() * 8);
   const size_t off_bvh_tri = off_bvh_nodes + pad(n_bvh_nodes * PT_BVH_NODE_WORDS * 4);
-  const size_t total = off_bvh_tri + pad(bvh.order.size() * 4) + 256;
+  const size_t off_tgeom_leaf = off_bvh_tri + pad(bvh.order.size() * 4);
+  const size_t total = off_tgeom_leaf + pad(tgeom_leaf.size() * 8) + 256;
 
   DeviceScope scope(device);
   HIP_TRY(scope.status);
@@ -655,6 +659,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   if (e == hipSuccess) e = up(off_tobj, tobj.data(), tobj.size() * 4);
   if (e == hipSuccess) e = up(off_bvh_src, bvh.nodes.data(), bvh.nodes.size() * 8);
   if (e == hipSuccess) e = up(off_bvh_tri, bvh.order.data(), bvh.order.size() * 4);
+  if (e == hipSuccess) e = up(off_tgeom_leaf, tgeom_leaf.data(), tgeom_leaf.size() * 8);
   if (e != hipSuccess)
   {
     (void)hipFree(sc->blob);
@@ -666,6 +671,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.bvh_src = reinterpret_cast<const double *>(base + off_bvh_src);
   sc->view.bvh_nodes = reinterpret_cast<float *>(base + off_bvh_nodes);
   sc->view.bvh_tri = reinterpret_cast<const uint32_t *>(base + off_bvh_tri);
+  sc->view.tri_geom_leaf = reinterpret_cast<const double *>(base + off_tgeom_leaf);
   sc->view.n_bvh_nodes = (uint32_t)n_bvh_nodes;
   sc->view.bvh_depth = (uint32_t)bvh.depth;
   sc->filt_bytes = filt_bytes;
