@@ -60,7 +60,7 @@
 #define PT_BVH_LEAF_FLAG 0x80000000u
 #define PT_BVH_STACK 24       /* per-lane traversal stack (LDS): tree depth limit */
 #define PT_GEOM_STRIDE 4     /* LDS doubles per sphere: cx cy cz r2 */
-#define PT_FILT_STRIDE 5     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol (phase-1 filter) */
+#define PT_FILT_STRIDE 6     /* HBM f32x2 per primitive PAIR: cx cy cz r2_hi neg_tol kq (phase-1 filter; kq = |c|^2 - r2_hi of the sign-test form) */
 #define PT_TRI32_STRIDE 16    /* floats per triangle of the fp32 pre-test table: v0 e1 e2 (9), Ea KU KV KT (4), pad (3) */
 #define PT_ENTRY_SRC_STRIDE 6 /* HBM doubles per primitive: cx cy cz R2 |c| Rb (bounding data, fp64) */
 
@@ -156,7 +156,7 @@ struct PtLaunch
    * they would occupy -- and spill -- vector registers): near_R^2, width-1, height-1 as the
    * reference forms them, (double)options->width - 1.0 (raytracer.c:203-204) */
   double near_R2, w_minus_1, h_minus_1;
-  double filt_shift; /* 10 e (max |c| + near_R): how far behind the origin the sign-test filter starts its ray */
+  double filt_shift; /* 12 e (max |c| + near_R): how far behind the origin the sign-test filter starts its ray */
   /* two constants passed in so that they live in SGPRs (as literals the compiler parks each in a
    * VGPR pair for the whole loop, and spilled them): BACKGROUND's component 10/255
    * (raytracer.h:46) and DBL_MAX, the initial min_t of intersect() (raytracer.c:396) */

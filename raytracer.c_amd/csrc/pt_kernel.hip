@@ -454,6 +454,8 @@ struct FiltRay
 {
   float ox, oy, oz;
   f32x2 dx, dy, dz;
+  /* sign-test form: o'.d, |o'|^2 and -2 o' of the pulled-back origin o' (see filter_chunk) */
+  float od, oo, m2ox, m2oy, m2oz;
   bool far_origin;
 };
 
@@ -467,6 +469,16 @@ __device__ __forceinline__ FiltRay filter_ray(const V3 &o, const V3 &d, double f
   r.dx = {(float)d.x, (float)d.x};
   r.dy = {(float)d.y, (float)d.y};
   r.dz = {(float)d.z, (float)d.z};
+  if (SHIFT)
+  {
+    r.od = __builtin_fmaf(r.oz, r.dz.x, __builtin_fmaf(r.oy, r.dy.x, r.ox * r.dx.x));
+    r.oo = __builtin_fmaf(r.oz, r.oz, __builtin_fmaf(r.oy, r.oy, r.ox * r.ox));
+    r.m2ox = -2.0f * r.ox;
+    r.m2oy = -2.0f * r.oy;
+    r.m2oz = -2.0f * r.oz;
+  }
+  else
+    r.od = r.oo = r.m2ox = r.m2oy = r.m2oz = 0.f;
   r.far_origin = !(v_dot(o, o) <= near_R2); /* also true for NaN */
   return r;
 }
@@ -476,28 +488,37 @@ __device__ __forceinline__ FiltRay filter_ray(const V3 &o, const V3 &d, double f
  * keep mask (bit k = primitive base + k survives).  The ray arrives in fp32, SHIFTed where the
  * sign-test form applies (see scan_filtered); far_origin lanes keep everything. */
 template <bool TRIS, bool FILT_LDS>
-__device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uint32_t base, uint32_t chunk, float ox,
-                                             float oy, float oz, f32x2 dx, f32x2 dy, f32x2 dz, bool far_origin,
+__device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uint32_t base, uint32_t chunk, const FiltRay &fr,
                                              uint32_t &cand_lo, uint32_t &cand_hi)
 {
   constexpr bool SHIFT = FILT_LDS && !TRIS;
+  const float ox = fr.ox, oy = fr.oy, oz = fr.oz;
+  const f32x2 dx = fr.dx, dy = fr.dy, dz = fr.dz;
+  const bool far_origin = fr.far_origin;
+  /* sign-test form: per-ray terms of the expanded products, both halves alike */
+  const f32x2 neg_od = {-fr.od, -fr.od}, oo = {fr.oo, fr.oo};
+  const f32x2 m2ox = {fr.m2ox, fr.m2ox}, m2oy = {fr.m2oy, fr.m2oy}, m2oz = {fr.m2oz, fr.m2oz};
   /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
   cand_lo = 0;
   cand_hi = 0;
   struct PairRec
   {
-    f32x2 cx, cy, cz, r2_hi, neg_tol;
+    f32x2 cx, cy, cz, r2_hi, neg_tol; /* sign-test form: r2_hi holds kq = |c|^2 - r2_hi instead, neg_tol is not read */
   };
   auto load_pair = [&](uint32_t pair) -> PairRec {
     const f32x2 *g = filt + PT_FILT_STRIDE * (size_t)((base >> 1) + pair);
+    if (SHIFT)
+      return {g[0], g[1], g[2], g[5], g[5]};
     return {g[0], g[1], g[2], g[3], g[4]};
   };
   auto filter_pair = [&](const PairRec &g, uint32_t &word, uint32_t shift) {
-    const f32x2 lx = g.cx - ox, ly = g.cy - oy, lz = g.cz - oz;
-    const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
     if (SHIFT)
     {
-      const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, __builtin_elementwise_fma(lx, lx, -g.r2_hi)));
+      /* the products expanded: tca' = c.d - o'.d and |c - o'|^2 - r2_hi = (|c|^2 - r2_hi) + |o'|^2 - 2 c.o', so the
+       * per-sphere work is two 3-term chains on c alone (8 packed ops per pair instead of 10; |c|^2 - r2_hi comes
+       * exact-then-rounded from the table, which also spares the walls' |L|^2 ~ 1e8 its fp32 rounding) */
+      const f32x2 tca = __builtin_elementwise_fma(g.cz, dz, __builtin_elementwise_fma(g.cy, dy, __builtin_elementwise_fma(g.cx, dx, neg_od)));
+      const f32x2 ll = __builtin_elementwise_fma(g.cz, m2oz, __builtin_elementwise_fma(g.cy, m2oy, __builtin_elementwise_fma(g.cx, m2ox, g.r2_hi + oo)));
       const f32x2 q = __builtin_elementwise_fma(tca, tca, -ll);
       /* pairs arrive in DESCENDING order: shifting sign bits in leaves bit k = primitive k;
        * a set bit means DROP here, the word is inverted after the loop */
@@ -505,6 +526,8 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
       word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.x) | __float_as_uint(q.x), 31);
       return;
     }
+    const f32x2 lx = g.cx - ox, ly = g.cy - oy, lz = g.cz - oz;
+    const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
     const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, lx * lx));
     const f32x2 d2 = __builtin_elementwise_fma(-tca, tca, ll);
     if (FILT_LDS)
@@ -637,11 +660,13 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
    *   - "tca < -tol": the filter's ray starts tol_max = filt_shift behind the real origin,
    *     o' = o - tol_max d.  That adds tol_max |d|^2 to every tca and leaves the distance of
    *     a centre from the ray's line, d2, where it was (to (1 - |d|^2) (2 tol tca + tol^2),
-   *     ~1e-14); with tol_max = 10 e (max |c| + near_R) >= every per-sphere tolerance,
-   *     tca >= 0 implies tca32' >= 0.9998 tol_max - 6.2 e (A + 1.0001 tol_max) > 0: sign clear.
-   *   - "d2 > r2_hi": the squared-length chain starts from -r2_hi, so that
-   *     q = tca^2 - (|L|^2 - r2_hi) = r2_hi - d2 and the reject is q < 0 (pt_build_filter
-   *     widens r2_hi for the three roundings that now see r2_hi).
+   *     ~1e-14); with tol_max = 12 e (max |c| + near_R), tca >= 0 implies
+   *     tca32' >= 0.9998 tol_max - 8.2 e (A + 1.0001 tol_max) > 0: sign clear.
+   *   - "d2 > r2_hi": q = tca'^2 - (|c - o'|^2 - r2_hi') = r2_hi' - d2 and the reject is q < 0.
+   *   Both come from products EXPANDED around the centre (filter_chunk): c.d - o'.d and
+   *   (|c|^2 - r2_hi') + |o'|^2 - 2 c.o', with the per-ray terms o'.d, |o'|^2, -2 o' formed once
+   *   (filter_ray) and |c|^2 - r2_hi' in the table; the error bound that r2_hi' is widened by
+   *   stands at pt_build_filter.
    * A NaN's sign is arbitrary: rays with non-finite o skip the filter (far_origin), rays with
    * non-finite d hit nothing in the exact test either, and scenes whose centres or radii are
    * outside fp32's comfortable range never use this form (pt_filter_in_lds). */
@@ -656,7 +681,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     const uint32_t chunk = min(64u, n_entries - base);
     /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
     uint32_t cand_lo, cand_hi;
-    filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, ox, oy, oz, dx, dy, dz, far_origin, cand_lo, cand_hi);
+    filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, fr, cand_lo, cand_hi);
     /* triangle candidates of this chunk: bits from entry n_sph on */
     uint32_t tri_lo = 0, tri_hi = 0;
     if (TRIS && !BVH)
@@ -1491,7 +1516,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   constexpr bool DEFER_MESH = TRIS && !FILT_LDS;
   /* small-mesh kernels keep throughput and radiance in LDS across the scan (see the loop) */
   constexpr bool PARK_T = TRIS && FILT_LDS && !CHECKER;
-  __shared__ double t_park[PARK_T ? 6 : 1][PARK_T ? PT_BLOCK : 1];
+  __shared__ double t_park[PARK_T ? 3 : 1][PARK_T ? PT_BLOCK : 1];
   HitRec hit;
   hit.min_t = 0;
   hit.bary_u = 0;
@@ -1631,9 +1656,9 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     else if (PARK_T)
     {
       /* small-mesh kernels: the scan (filter, fp32 pre-test, exact sphere and triangle tests) needs
-       * every register it can get and touches neither the throughput nor the gathered radiance, so
-       * both sit in LDS while it runs (the compiler otherwise spills ten registers to scratch around
-       * it): trace_path() in its two halves, as in the hierarchy kernels */
+       * every register it can get and does not touch the throughput, which sits in LDS while it runs
+       * (the compiler otherwise spills registers to scratch around it): trace_path() in its two halves,
+       * as in the hierarchy kernels */
       if (stepping)
       {
         DIAG(0, 1);
@@ -1642,14 +1667,10 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         t_park[0][threadIdx.x] = P.T.x;
         t_park[1][threadIdx.x] = P.T.y;
         t_park[2][threadIdx.x] = P.T.z;
-        t_park[3][threadIdx.x] = P.Ls.x;
-        t_park[4][threadIdx.x] = P.Ls.y;
-        t_park[5][threadIdx.x] = P.Ls.z;
         asm volatile("" ::: "memory"); /* no store-to-load forwarding: the values must leave the registers */
         (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
         asm volatile("" ::: "memory");
         P.T = {t_park[0][threadIdx.x], t_park[1][threadIdx.x], t_park[2][threadIdx.x]};
-        P.Ls = {t_park[3][threadIdx.x], t_park[4][threadIdx.x], t_park[5][threadIdx.x]};
         step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
       }
     }
@@ -1694,23 +1715,27 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     }
     if (busy)
     {
-      if (step_done)
+      /* This trip's radiance terms (emission of a hit that goes on, or what ends the path) go to the
+       * pixel's fixed-point sum at once: integer adds commute and associate, so the sum depends
+       * neither on which lane finishes first nor on how a sample's terms are grouped -- and no
+       * radiance lives in registers from one trip to the next. */
+      if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
-        /* sample done: add to the pixel's fixed-point sum (integer adds commute: the
-         * result does not depend on which lane finishes first) */
         atomicAdd(&pix_sum[3 * pix_slot + 0], (unsigned long long)__double2ll_rn(P.Ls.x * L.acc_scale));
         atomicAdd(&pix_sum[3 * pix_slot + 1], (unsigned long long)__double2ll_rn(P.Ls.y * L.acc_scale));
         atomicAdd(&pix_sum[3 * pix_slot + 2], (unsigned long long)__double2ll_rn(P.Ls.z * L.acc_scale));
-        /* a NaN sample (a ray through a degenerate normal, say) has no integer: flag the pixel, see finish_pixels */
+        /* a NaN term (a ray through a degenerate normal, say) has no integer: flag the pixel, see finish_pixels */
         if ((int)(P.Ls.x != P.Ls.x) | (int)(P.Ls.y != P.Ls.y) | (int)(P.Ls.z != P.Ls.z))
         {
           if (P.Ls.x != P.Ls.x) atomicOr(&pix_nan[0], 1ull << pix_slot);
           if (P.Ls.y != P.Ls.y) atomicOr(&pix_nan[1], 1ull << pix_slot);
           if (P.Ls.z != P.Ls.z) atomicOr(&pix_nan[2], 1ull << pix_slot);
         }
-        busy = false;
       }
+      if (step_done)
+        busy = false;
     }
+    P.Ls = {0, 0, 0};
   }
 
   if (n_rays)
@@ -2576,7 +2601,7 @@ extern "C" __global__ __launch_bounds__(64) void pt_selftest_intersect(int kind,
   if (kind == 0)
   {
     const FiltRay fs = filter_ray<true>(o, d, filt_shift, near_R2);
-    filter_chunk<false, true>(filt_lds, 0u, chunk, fs.ox, fs.oy, fs.oz, fs.dx, fs.dy, fs.dz, fs.far_origin, lo, hi);
+    filter_chunk<false, true>(filt_lds, 0u, chunk, fs, lo, hi);
     m0 = ((unsigned long long)hi << 32) | lo;
   }
   const FiltRay fr = filter_ray<false>(o, d, filt_shift, near_R2);
@@ -2587,9 +2612,9 @@ extern "C" __global__ __launch_bounds__(64) void pt_selftest_intersect(int kind,
       if (fr.far_origin || tri_may_hit32(tri32 + (PT_TRI32_STRIDE / 4) * (size_t)(base + j), fr.ox, fr.oy, fr.oz, fr.dx.x, fr.dy.x, fr.dz.x))
         m0 |= 1ull << j;
   }
-  filter_chunk<true, true>(filt_lds, 0u, chunk, fr.ox, fr.oy, fr.oz, fr.dx, fr.dy, fr.dz, fr.far_origin, lo, hi);
+  filter_chunk<true, true>(filt_lds, 0u, chunk, fr, lo, hi);
   m1 = ((unsigned long long)hi << 32) | lo;
-  filter_chunk<false, false>(filt, base, chunk, fr.ox, fr.oy, fr.oz, fr.dx, fr.dy, fr.dz, fr.far_origin, lo, hi);
+  filter_chunk<false, false>(filt, base, chunk, fr, lo, hi);
   m2 = ((unsigned long long)hi << 32) | lo;
   if (live)
   {
@@ -2695,12 +2720,29 @@ extern "C" __global__ __launch_bounds__(256) void pt_build_filter(const double *
        * carries -r2_hi as its addend (scan_filtered, SHIFT form: 3 e max(r2_hi, A^2)) */
       f[6] = (float)((src[3] + 32.0 * e * A * A) * (1.0 + 8.0 * e));
       f[8] = -(float)((src[5] + 10.0 * e * A) * (1.0 + 4.0 * e));
+      /* sign-test form (spheres, small scenes): kq = |c|^2 - r2_hi', formed in fp64 and rounded DOWN, with its
+       * own widening r2_hi' = R2 + 40 e A^2 + 8 e | |c|^2 - R2 |.  Bound behind it (e = 2^-24, A = |c| + near_R +
+       * tol_max, every input rounded to fp32, fused 3-term chains, o' the pulled-back origin):
+       *   tca32 = fma(cz,dz, fma(cy,dy, fma(cx,dx, -o'.d))):  |tca32 - tca'| <= 8.2 e A   (2 e |c| inputs, 3 e A chain,
+       *           5.1 e |o'| for o'.d);
+       *   ll32  = fma(cz,-2oz, fma(cy,-2oy, fma(cx,-2ox, kq + |o'|^2))):
+       *           |ll32 - (|c-o'|^2 - r2_hi')| <= e (5 |kq| + 9.1 |o'|^2 + 10 |c||o'|) <= 10 e A^2 + 5 e |kq|;
+       *   q32   = fma(tca32, tca32, -ll32):  |q32 - (r2_hi' - d2)| <= 2 A 8.2 e A + e A^2 + 10 e A^2 + 5 e |kq|
+       *           <= 28 e A^2 + 5 e |kq|  <  the widening (|kq| <= | |c|^2 - R2 | + 40 e A^2),
+       * so d2 <= R2 in exact arithmetic implies q32 >= 0: never a false drop (the PT_DIAG build re-checks every
+       * dropped sphere with the exact test: 0 violations). */
+      {
+        const double cc = src[4] * src[4]; /* |c| was rounded up by 1e-12: inside the slack */
+        const double widen = (40.0 * e * A * A + 8.0 * e * fabs(cc - src[3])) * (1.0 + 8.0 * e);
+        f[10] = __double2float_rd((cc - (src[3] + widen)) - 4.0 * e * fabs(cc - src[3]));
+      }
     }
     else
     { /* padding slot of an odd count: masked out by valid_lo / valid_hi in the scan */
       f[0] = f[2] = f[4] = 0.f;
       f[6] = -1.f;
       f[8] = 0.f;
+      f[10] = 0.f;
     }
   }
 }

@@ -821,7 +821,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     if (!(L.near_R < 1e15))
       return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.near_R);
     L.near_R2 = L.near_R * L.near_R;
-    L.filt_shift = 10.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
+    L.filt_shift = 12.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
     L.background = 10 / 255.0;
     L.t_start = 1.7976931348623157e308; /* DBL_MAX */
     L.w_minus_1 = (double)params->width - 1.0;
@@ -870,7 +870,11 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
       const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD;
       const size_t flag_bytes = (n_slots * sizeof(uint32_t) + 255) & ~(size_t)255;
       char *ws = nullptr;
-      if (hipMalloc(&ws, flag_bytes + n_slots * (PT_BLOCK / 64) * (size_t)PT_PARK_WAVE_BYTES) == hipSuccess)
+      /* RT_HIP_NO_PARK_WS=1 (tests): behave as if the allocation had failed */
+      const char *no_ws = getenv("RT_HIP_NO_PARK_WS");
+      if (no_ws && no_ws[0] == '1')
+        ;
+      else if (hipMalloc(&ws, flag_bytes + n_slots * (PT_BLOCK / 64) * (size_t)PT_PARK_WAVE_BYTES) == hipSuccess)
       {
         /* the flags must be zero before a kernel on ANY stream looks at them */
         if (hipMemset(ws, 0, flag_bytes) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess)
@@ -956,7 +960,7 @@ int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_pr
         return fail(RT_HIP_ELIMIT, "primitive %zu: centre beyond 1e17", i);
       max_center = std::fmax(max_center, e[4]);
     }
-    const double filt_shift = 10.0 * 5.9604644775390625e-08 * (max_center + near_R) * (1.0 + 1e-9); /* as rt_hip_render_tiles */
+    const double filt_shift = 12.0 * 5.9604644775390625e-08 * (max_center + near_R) * (1.0 + 1e-9); /* as rt_hip_render_tiles */
     const size_t n_blocks = (n + 63) / 64;
     const size_t filt_bytes = (n_blocks * 32 + 1) * (size_t)PT_FILT_STRIDE * 2 * sizeof(float);
     const size_t b_rays = 6 * n * 8, b_prims = rec * n * 8, b_entry = entry.size() * 8, b_tuv = 3 * n * 8, b_keep = 3 * n * 8;

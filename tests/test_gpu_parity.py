@@ -1042,3 +1042,27 @@ def test_render_image_reuses_its_context_between_frames(gpu, pt):
     shim.rt_hip_release_cache()
     f = gpu.render_image_host(sc, SEED)
     assert np.array_equal(a[0], f[0]) and shim.rt_hip_cache_builds() == b0 + 4
+
+
+def test_hierarchy_kernel_without_its_workspace(gpu, pt):
+    """the parked-walk kernels must render correctly when their ring workspace is missing (allocation
+    failure): every ray that can reach the mesh is then walked from its lane's registers"""
+    import os
+    from rt_amd import scene as S
+    sc = S.build_scene(5, 72, 40, 6)
+    os.environ["RT_HIP_NO_PARK_WS"] = "1"
+    try:
+        gs = gpu.GpuScene(sc)
+        assert gs.kernel_name() == "pt_render_tiles_tri_queued"
+        img, img8, st = gs.render_image(SEED)
+    finally:
+        del os.environ["RT_HIP_NO_PARK_WS"]
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="config 5 without ring workspace")
+    gs.close()
+    gs = gpu.GpuScene(sc)  # and with it: the same image, bit for bit
+    img2, img82, st2 = gs.render_image(SEED)
+    import torch
+    assert torch.equal(img, img2) and torch.equal(img8, img82) and st == st2
+    gs.close()
+    sc.free()
