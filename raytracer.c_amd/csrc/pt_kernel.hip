@@ -102,6 +102,19 @@ __device__ __forceinline__ double rnd_pm1(uint64_t &state)
   return __builtin_fma(draw31(state), 1.0 / 1073741824.0, -1.0);
 }
 
+/* One radiance term as the fixed-point integer that goes into a pixel's sum: RN(x * scale), in two's
+ * complement.  The launch picks the scale so that |x * scale| < 2^51 for every term a sample can
+ * produce (rt_hip_render_tiles_chunked), so the integer can be read off the mantissa: adding
+ * 1.5 * 2^52 rounds x * scale to an integer (round-to-nearest-even, as a conversion would) and leaves
+ * it, offset by the constant's bit pattern, in the sum's low bits -- one fp64 add and one 64-bit
+ * subtract instead of the ~10-instruction double -> int64 conversion sequence.  (NaN: any value; the
+ * pixel is flagged apart.) */
+__device__ __forceinline__ unsigned long long fixed_term(double x, double scale)
+{
+  const double magic = 6755399441055744.0; /* 1.5 * 2^52 */
+  return (unsigned long long)(__double_as_longlong(__builtin_fma(x, scale, magic)) - __double_as_longlong(magic));
+}
+
 /* raytracer.c:218-220 */
 __device__ __forceinline__ uint8_t tonemap(double x)
 {
@@ -1721,9 +1734,9 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
        * radiance lives in registers from one trip to the next. */
       if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
-        atomicAdd(&pix_sum[3 * pix_slot + 0], (unsigned long long)__double2ll_rn(P.Ls.x * L.acc_scale));
-        atomicAdd(&pix_sum[3 * pix_slot + 1], (unsigned long long)__double2ll_rn(P.Ls.y * L.acc_scale));
-        atomicAdd(&pix_sum[3 * pix_slot + 2], (unsigned long long)__double2ll_rn(P.Ls.z * L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 0], fixed_term(P.Ls.x, L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 1], fixed_term(P.Ls.y, L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 2], fixed_term(P.Ls.z, L.acc_scale));
         /* a NaN term (a ray through a degenerate normal, say) has no integer: flag the pixel, see finish_pixels */
         if ((int)(P.Ls.x != P.Ls.x) | (int)(P.Ls.y != P.Ls.y) | (int)(P.Ls.z != P.Ls.z))
         {
@@ -2292,9 +2305,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
        * associate: the sum does not depend on the order or the grouping of the terms) */
       if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
-        atomicAdd(&pix_sum[3 * pix_slot + 0], (unsigned long long)__double2ll_rn(P.Ls.x * L.acc_scale));
-        atomicAdd(&pix_sum[3 * pix_slot + 1], (unsigned long long)__double2ll_rn(P.Ls.y * L.acc_scale));
-        atomicAdd(&pix_sum[3 * pix_slot + 2], (unsigned long long)__double2ll_rn(P.Ls.z * L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 0], fixed_term(P.Ls.x, L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 1], fixed_term(P.Ls.y, L.acc_scale));
+        atomicAdd(&pix_sum[3 * pix_slot + 2], fixed_term(P.Ls.z, L.acc_scale));
         if ((int)(P.Ls.x != P.Ls.x) | (int)(P.Ls.y != P.Ls.y) | (int)(P.Ls.z != P.Ls.z))
         {
           if (P.Ls.x != P.Ls.x) atomicOr(&pix_nan[0], 1ull << pix_slot);

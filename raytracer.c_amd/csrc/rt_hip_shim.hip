@@ -832,14 +832,19 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   {
     /* Fixed-point scale of the per-pixel sums (pt_render_tiles): a sample's radiance is
      * sum_k T_k (.) e_k with throughput T <= 1 (albedo/prob <= 1, cos <= 1) over at most
-     * max_depth + 2 events, so |L| <= (max_depth + 2) * max(BACKGROUND, max emission); the
-     * sum of `samples` of them must stay below 2^62. */
-    const double per_sample = ((double)params->max_depth + 2.0) * std::fmax(10.0 / 255.0, scene->max_emission);
-    const double bound = per_sample * (double)params->samples * 1.01;
+     * max_depth + 2 events, so every term and every sample is bounded by
+     * (max_depth + 2) * max(BACKGROUND, max emission).  Two conditions on the power-of-two scale: the sum
+     * of `samples` samples stays below 2^62, and a single term stays below 2^51 -- the kernels read a
+     * term's integer off an fp64 mantissa (fixed_term in pt_kernel.hip). */
+    const double per_sample = ((double)params->max_depth + 2.0) * std::fmax(10.0 / 255.0, scene->max_emission) * 1.01;
+    const double bound = per_sample * (double)params->samples;
     if (!(bound > 0) || !(bound < 1e300))
       return fail(RT_HIP_EINVAL, "emission magnitudes give no finite radiance bound (%g)", bound);
-    int e = 0;
-    (void)std::frexp(4611686018427387904.0 / bound, &e); /* 2^62 / bound = m * 2^e, m in [0.5, 1) */
+    int e = 0, e1 = 0;
+    (void)std::frexp(4611686018427387904.0 / bound, &e);      /* 2^62 / bound = m * 2^e, m in [0.5, 1) */
+    (void)std::frexp(2251799813685248.0 / per_sample, &e1);   /* 2^51 / per_sample */
+    if (e1 < e)
+      e = e1;
     L.acc_scale = std::ldexp(1.0, e - 1);
     L.acc_inv_scale = std::ldexp(1.0, 1 - e);
   }
