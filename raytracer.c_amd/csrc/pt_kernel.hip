@@ -654,7 +654,9 @@ __device__ __forceinline__ bool tri_may_hit32(const float4 *__restrict__ rec, fl
   return !drop;
 }
 
-template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true, bool LAST = false>
+/* SPH_LDS (hierarchy kernels with parked walks): the flat filter covers the spheres only, and their part of the pair
+ * table is staged in LDS and used in the sign-test form, as in the sphere-only kernels. */
+template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true, bool LAST = false, bool SPH_LDS = false>
 __device__ __forceinline__ void scan_filtered(const double *geom, const double *tri_geom,
                                               const f32x2 *__restrict__ filt, double near_R2, uint32_t n_sph,
                                               uint32_t n_entries, const V3 &o, const V3 &d, double &min_t,
@@ -683,7 +685,8 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
    * A NaN's sign is arbitrary: rays with non-finite o skip the filter (far_origin), rays with
    * non-finite d hit nothing in the exact test either, and scenes whose centres or radii are
    * outside fp32's comfortable range never use this form (pt_filter_in_lds). */
-  constexpr bool SHIFT = FILT_LDS && !TRIS;
+  static_assert(!SPH_LDS || (BVH && !FILT_LDS), "SPH_LDS is the sphere filter of the hierarchy kernels");
+  constexpr bool SHIFT = (FILT_LDS && !TRIS) || SPH_LDS;
   const FiltRay fr = filter_ray<SHIFT>(o, d, filt_shift, near_R2);
   const float ox = fr.ox, oy = fr.oy, oz = fr.oz;
   const f32x2 dx = fr.dx, dy = fr.dy, dz = fr.dz;
@@ -694,7 +697,10 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     const uint32_t chunk = min(64u, n_entries - base);
     /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
     uint32_t cand_lo, cand_hi;
-    filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, fr, cand_lo, cand_hi);
+    if (SPH_LDS)
+      filter_chunk<false, true>(filt, base, chunk, fr, cand_lo, cand_hi);
+    else
+      filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, fr, cand_lo, cand_hi);
     /* triangle candidates of this chunk: bits from entry n_sph on */
     uint32_t tri_lo = 0, tri_hi = 0;
     if (TRIS && !BVH)
@@ -817,10 +823,11 @@ struct SceneCtx
 /* GEOM_LDS: sphere geometry and materials are staged in LDS (the pointers are LDS pointers at
  * compile time); otherwise the scene is beyond the staging budget (pt_geom_in_lds) and the
  * kernel reads them from memory.  Kernels pick the instantiation once, at entry. */
-template <bool GEOM_LDS, bool FILT_LDS>
+template <bool GEOM_LDS, bool FILT_LDS, bool SPH_FILT = false>
 __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
 {
   static_assert(GEOM_LDS || !FILT_LDS, "a filter table in LDS implies staged geometry");
+  static_assert(!SPH_FILT || (GEOM_LDS && !FILT_LDS), "SPH_FILT: the sphere pairs only, for the hierarchy kernels");
   const PtSceneView &sc = L.scene;
   const uint32_t n_sph = sc.n_spheres, n_mat = sc.n_spheres + sc.n_meshes;
   constexpr bool staged = GEOM_LDS;
@@ -845,6 +852,14 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
    * it through the constant cache. */
   const uint32_t n_entries = n_sph + sc.n_triangles;
   f32x2 *filt_lds = nullptr;
+  if (SPH_FILT)
+  { /* the pairs that cover the spheres (the last may carry the first triangle's bound: masked in the scan) */
+    filt_lds = reinterpret_cast<f32x2 *>(mat + PT_MAT_STRIDE * (size_t)n_mat);
+    const uint32_t n_slots = pt_filt_pair_slots(n_sph);
+    const f32x2 *src = reinterpret_cast<const f32x2 *>(sc.filt);
+    for (uint32_t k = threadIdx.x; k < n_slots; k += PT_BLOCK)
+      filt_lds[k] = src[k];
+  }
   if (FILT_LDS)
   {
     filt_lds = reinterpret_cast<f32x2 *>(mat + PT_MAT_STRIDE * (size_t)n_mat);
@@ -1019,7 +1034,8 @@ struct HitRec
  * hierarchy walk; the result so far goes to *rec and nothing else changes.  MODE 2: the second
  * half only, from *rec (which the caller may have completed with bvh_traverse).
  * DEFER_DIR: a diffuse hit does not sample its direction here; the caller does (HitRec). */
-template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int MODE = 0, bool DEFER_DIR = false>
+template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int MODE = 0, bool DEFER_DIR = false,
+          bool SPH_LDS = false>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
                                            unsigned long long *diag_ptr, PendingRay *stack, int &stack_n,
                                            HitRec *rec = nullptr)
@@ -1054,8 +1070,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
                                                  &H.last);
       }
       else
-        scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0, CHECKER && TRIS>(
-            S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o, d, H.min_t, H.best,
+        scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0, CHECKER && TRIS, SPH_LDS>(
+            S.geom, S.tri, (FILT_LDS || SPH_LDS) ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o, d, H.min_t, H.best,
             H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv, S.tri32);
     }
     if (MODE == 1)
@@ -2027,10 +2043,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   __shared__ double st_f[PT_BLOCK / 64][STAGE_F][PT_STAGE];
   __shared__ uint32_t st_u[PT_BLOCK / 64][STAGE_U][PT_STAGE];
 
-  const SceneCtx S = stage_scene<true, FILT_LDS>(L, lds);
-  /* the traversal stacks follow the staged scene in dynamic LDS: one entry per tree level and lane */
+  const SceneCtx S = stage_scene<true, FILT_LDS, true>(L, lds);
+  /* the traversal stacks follow the staged scene (geometry, materials, the spheres' filter pairs) in dynamic LDS:
+   * one entry per tree level and lane */
   uint32_t (*const stack)[PT_BLOCK] = reinterpret_cast<uint32_t (*)[PT_BLOCK]>(
-      lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes)));
+      lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
+             pt_filt_pair_slots(S.n_sph)));
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
   if (threadIdx.x < 3)
@@ -2228,7 +2246,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       DIAG(0, 1);
       DIAG_LANES(1);
       n_rays++;
-      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
       const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
       want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
                                             (CHECKER && S.stale_uv) ? S.t_start : hit.min_t);
@@ -2272,7 +2290,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
      * walked rays resumed at the top of this trip ---- */
     bool step_done = false;
     if (busy && (stepping || resumed))
-      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
 
     /* ---- directions of diffuse hits (see render_tiles_pooled) ---- */
     if (busy && hit.need_dir)
@@ -2829,8 +2847,9 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
     which = cast_ray ? 18 : 17;
   else if (variant == 0 && !refr && !cast_ray)
     which = 12;
-  else if ((which == 3 || which == 7) && variant != 2)
-    which = which == 3 ? 19 : 20; /* hierarchy scenes: parked walks (variant 2 keeps the lane-waiting pooled kernels) */
+  else if ((which == 3 || which == 7) && variant != 2 && !scene.wide_range)
+    which = which == 3 ? 19 : 20; /* hierarchy scenes: parked walks (variant 2, and scenes beyond fp32's comfortable range,
+                                   * whose filter needs the NaN-safe compares, keep the lane-waiting pooled kernels) */
   if (name)
     *name = names[which];
   return which;
@@ -2882,8 +2901,9 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
                                     pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk};
   const int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr);
   const Kernel kernel = family[which];
-  if (which >= 19) /* per-lane traversal stacks sized by the tree, after the staged scene */
-    lds_bytes += (size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * sizeof(uint32_t);
+  if (which >= 19) /* the spheres' filter pairs, then per-lane traversal stacks sized by the tree, after the staged scene */
+    lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
+                 (size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * sizeof(uint32_t);
   static size_t lds_allowed[21] = {0}; /* raised once per process if a scene needs > 64 KiB */
   size_t &allowed = lds_allowed[which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
