@@ -209,7 +209,11 @@ void rt_hip_set_cancel_flag(const volatile int *flag);
 
 /* Renders width x height on n_devices GPUs of this process (tiles interleaved
  * over devices, tile buffers gathered onto device 0 with RCCL when
- * n_devices > 1), then copies to the host.  Calls are serialised (one frame at a time).  h_image_rgb (w*h*3 floats) and
+ * n_devices > 1), then copies to the host.  Calls are serialised (one frame at a time).
+ * n_devices > 1 is EXPERIMENTAL: written (grouped ncclSend / ncclRecv to device 0 over cached
+ * communicators) but, as of this writing, run on one-GPU machines only; `bench.py --gpus N`
+ * exercises it in a child process whenever N > 1 GPUs are present and compares its frame with the
+ * one-device frame.  h_image_rgb (w*h*3 floats) and
  * h_image_rgb8 (w*h*3 bytes) may each be NULL.  h_stats: RT_HIP_NSTATS values,
  * overwritten.  kernel_seconds: device time of the render kernels (max over
  * devices), may be NULL.  params->tile_* are ignored. */

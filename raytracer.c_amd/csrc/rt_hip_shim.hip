@@ -365,10 +365,17 @@ int acquire_tables(const RtHipScene *scene, double near_R, hipStream_t stream, f
   TableSet &t = tables[k];
   t.near_R = near_R;
   t.stamp = ++scene->table_clock;
+  {
+    hipError_t e = pt_launch_build_tables(scene->view, near_R, t.filt, t.bvh_nodes, stream);
+    if (e == hipSuccess) e = hipEventRecord(t.built, stream);
+    if (e == hipSuccess) e = hipEventRecord(t.last_use, stream);
+    if (e != hipSuccess)
+    {
+      t.near_R = -1.0; /* never matches a launch: the set is rebuilt (or recycled) by the next one */
+      return fail(RT_HIP_ERUNTIME, "building the filter / hierarchy tables: %s", hipGetErrorString(e));
+    }
+  }
   t.users++;
-  HIP_TRY(pt_launch_build_tables(scene->view, near_R, t.filt, t.bvh_nodes, stream));
-  HIP_TRY(hipEventRecord(t.built, stream));
-  HIP_TRY(hipEventRecord(t.last_use, stream));
   *filt = t.filt;
   *bvh_nodes = t.bvh_nodes;
   *slot = k;
