@@ -195,7 +195,7 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
  * filter in small scenes; f = 1: compares from LDS; f = 2: compares by scalar loads) for ray i
  * against the 64 primitives of its block [64 (i/64), +64): bit j set = primitive 64 (i/64) + j
  * is kept.  The filter is built for ray origins within near_R (rays beyond keep everything),
- * as rt_hip_render_tiles builds it per launch.  |centre|, |radius| <= 1e17. */
+ * as rt_hip_render_tiles builds it for a camera.  |centre|, |radius| <= 1e17. */
 int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_prims, size_t n, double near_R,
                               uint8_t *h_hit, double *h_tuv, uint64_t *h_keep, int device);
 
