@@ -1100,3 +1100,25 @@ def test_small_mesh_kernel_partitions_and_chunks_are_bit_invariant(gpu, pt):
                   what="config 3 reduced")
     gs.close()
     sc.free()
+
+
+@pytest.mark.parametrize("n_tris", [6, 300])
+def test_mesh_only_scene_without_spheres(gpu, pt, n_tris):
+    """no spheres at all: the flat filter (small mesh) resp. the parked-walk kernel's sphere scan (large
+    mesh) has nothing to do, every hit comes from triangles; an emissive mesh lights a diffuse one"""
+    from rt_amd import abi, scene as S
+    rng = np.random.default_rng(77 + n_tris)
+    tris = []
+    for _ in range(n_tris):
+        c = rng.uniform(-5, 5, 3)
+        tris.append([tuple(c + rng.normal(0, 1.5, 3)) + (0.0, 0.0) for _ in range(3)])
+    floor = [[(-30, -6, -30, 0, 0), (30, -6, -30, 1, 0), (0, -6, 40, 0, 1)]]
+    meshes = [dict(flags=abi.M_DEFAULT, color=(0.7, 0.6, 0.5), triangles=tris),
+              dict(flags=abi.M_DEFAULT, color=(1, 1, 1), emission=(3, 3, 3), triangles=floor)]
+    sc = S.custom_scene([], 48, 32, 4, 4, (0, 2, 25), (0, 0, 0), meshes=meshes)
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name() == ("pt_render_tiles_tri" if n_tris < 250 else "pt_render_tiles_tri_queued")
+    gs.close()
+    st = _full(gpu, pt, sc)
+    assert st["tests"] == st["casts"] * (n_tris + 1) and st["casts"] > 48 * 32 * 4
+    _full(gpu, pt, sc, integrator="whitted")
