@@ -199,6 +199,11 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
 int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_prims, size_t n, double near_R,
                               uint8_t *h_hit, double *h_tuv, uint64_t *h_keep, int device);
 
+/* Launches n_workgroups one-wave workgroups; h_counts[x] = how many of them read HW_REG_XCC_ID == x
+ * (bits 3:0).  The parked-walk kernels partition their workspace by that id (every owner a slot ever
+ * has must sit behind the same L2): on an MI355X the counts must be spread over ids 0..7. */
+int rt_hip_selftest_xcc(uint32_t n_workgroups, uint32_t h_counts[16], int device);
+
 /* ---- convenience for C hosts: whole image, host buffers, synchronous ----------- */
 
 /* Cooperative cancellation of rt_hip_render_image(): while a flag is registered, long frames

@@ -185,6 +185,7 @@ size_t pt_render_lds_bytes(const PtSceneView &scene);
 hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant);
 hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream);
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant);
+hipError_t pt_launch_selftest_xcc(unsigned int *counts, uint32_t n_workgroups, hipStream_t stream);
 hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream);
 hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,
                                         float *filt, float *tri32, uint32_t n, double near_R, double filt_shift,

@@ -2659,6 +2659,20 @@ extern "C" __global__ __launch_bounds__(64) void pt_selftest_intersect(int kind,
   }
 }
 
+/* Self-test hook (rt_hip_selftest_xcc): which XCD each workgroup of a launch ran on, as the parked-walk kernels read it
+ * (pt_park_acquire): counts[x] = workgroups that saw HW_REG_XCC_ID == x. */
+extern "C" __global__ __launch_bounds__(64) void pt_selftest_xcc(unsigned int *counts)
+{
+  if (threadIdx.x == 0)
+    atomicAdd(&counts[(uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u], 1u);
+}
+
+hipError_t pt_launch_selftest_xcc(unsigned int *counts, uint32_t n_workgroups, hipStream_t stream)
+{
+  hipLaunchKernelGGL(pt_selftest_xcc, dim3(n_workgroups), dim3(64), 0, stream, counts);
+  return hipGetLastError();
+}
+
 hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream)
 {
   hipLaunchKernelGGL(pt_selftest_math, dim3(256), dim3(256), 0, stream, op, a, b, out, n);

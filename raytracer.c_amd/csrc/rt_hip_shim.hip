@@ -938,6 +938,25 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
   return RT_HIP_OK;
 }
 
+int rt_hip_selftest_xcc(uint32_t n_workgroups, uint32_t h_counts[16], int device)
+{
+  if (!h_counts || n_workgroups == 0 || n_workgroups > (1u << 20))
+    return fail(RT_HIP_EINVAL, "bad self-test arguments");
+  if (device < 0 || device >= usable_devices())
+    return fail(RT_HIP_ENODEV, "no HIP device %d", device);
+  DeviceScope scope(device);
+  HIP_TRY(scope.status);
+  unsigned int *d = nullptr;
+  hipError_t e = hipMalloc(&d, 16 * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemset(d, 0, 16 * sizeof(unsigned int));
+  if (e == hipSuccess) e = pt_launch_selftest_xcc(d, n_workgroups, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(h_counts, d, 16 * sizeof(unsigned int), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess)
+    return fail(RT_HIP_ERUNTIME, "xcc self-test: %s", hipGetErrorString(e));
+  return RT_HIP_OK;
+}
+
 int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_prims, size_t n, double near_R,
                               uint8_t *h_hit, double *h_tuv, uint64_t *h_keep, int device)
 {

@@ -100,6 +100,7 @@ SHIM_SYMBOLS = {
     "rt_hip_render_tiles_chunked": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RtHipParams), C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_hip_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "rt_hip_selftest_xcc": (C.c_int, [C.c_uint32, C.c_void_p, C.c_int]),
     "rt_hip_selftest_intersect": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int]),
     "rt_hip_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,

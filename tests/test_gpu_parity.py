@@ -1122,3 +1122,22 @@ def test_mesh_only_scene_without_spheres(gpu, pt, n_tris):
     st = _full(gpu, pt, sc)
     assert st["tests"] == st["casts"] * (n_tris + 1) and st["casts"] > 48 * 32 * 4
     _full(gpu, pt, sc, integrator="whitted")
+
+
+def test_xcc_id_partitions_the_workgroups(gpu):
+    """the parked-walk kernels key their workspace pools by HW_REG_XCC_ID of the running wave: on an
+    MI355X (8 XCDs) a 2,048-workgroup launch must report every id in 0..7 (and none beyond), each with a fair share"""
+    import ctypes as C
+    from rt_amd import abi
+    shim = abi.load_shim()
+    counts = (C.c_uint32 * 16)()
+    assert shim.rt_hip_selftest_xcc(2048, counts, 0) == 0, shim.rt_hip_last_error()
+    got = list(counts)
+    assert sum(got) == 2048 and sum(got[8:]) == 0, got
+    name = C.create_string_buffer(128)
+    cus = C.c_int(0)
+    shim.rt_hip_device_info(0, name, 128, C.byref(cus))
+    if cus.value == 256:  # the full chip (SPX mode): 8 XCDs
+        assert all(c >= 2048 // 16 for c in got[:8]), got
+    else:
+        assert max(got) > 0
