@@ -2026,12 +2026,14 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 {
   constexpr bool TRIS = true, FILT_LDS = false;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ float out_f[PT_TILE_PIXELS * 3];
-  __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
-  __shared__ unsigned long long wg_stats[2];
-  __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3];
-  __shared__ unsigned long long pix_nan[3];
-  __shared__ unsigned long long pix_key[PT_TILE_PIXELS];
+  /* ONE WAVE = ONE TILE here (a workgroup = four tiles, its waves independent of each other between the
+   * barrier after staging and the one before the slot goes back): a wave's pool is its tile's 64 pixels
+   * x samples, four times the 16-pixel strips of the pooled body, so the tail in which the last paths of a
+   * pool run on with most lanes idle -- each walk costs a park / walk / resume cycle, so the tail is long in
+   * these kernels -- weighs a quarter as much.  (The image is 4K-sized or the scene's cost per ray is high
+   * wherever these kernels run, so a quarter as many workgroups still fill the chip many times over.) */
+  __shared__ unsigned long long pix_sum_all[PT_BLOCK / 64][PT_TILE_PIXELS * 3];
+  __shared__ unsigned long long pix_nan_all[PT_BLOCK / 64][3];
   __shared__ double q_dir[PT_BLOCK / 64][3 * 64];
   __shared__ unsigned long long q_rng[PT_BLOCK / 64][64];
   __shared__ uint32_t q_pix[PT_BLOCK / 64][64];
@@ -2049,33 +2051,34 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   uint32_t (*const stack)[PT_BLOCK] = reinterpret_cast<uint32_t (*)[PT_BLOCK]>(
       lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
              pt_filt_pair_slots(S.n_sph)));
-  if (threadIdx.x < 2)
-    wg_stats[threadIdx.x] = 0;
-  if (threadIdx.x < 3)
-    pix_nan[threadIdx.x] = 0;
-  if (threadIdx.x < PT_TILE_PIXELS * 3)
-    pix_sum[threadIdx.x] = 0;
-  if (threadIdx.x < PT_TILE_PIXELS)
   {
-    const uint32_t t0 = L.tile_first + (blockIdx.x % L.tile_count) * L.tile_stride;
-    const uint32_t kx = (t0 % L.tiles_x) * PT_TILE + (threadIdx.x & 7u), ky = (t0 / L.tiles_x) * PT_TILE + (threadIdx.x >> 3);
-    pix_key[threadIdx.x] = rt_rng_pixel_key(L.seed, ky * (uint32_t)L.width + kx);
+    unsigned long long *z = &pix_sum_all[0][0];
+    for (uint32_t k = threadIdx.x; k < (PT_BLOCK / 64) * PT_TILE_PIXELS * 3; k += PT_BLOCK)
+      z[k] = 0;
+    if (threadIdx.x < (PT_BLOCK / 64) * 3)
+      (&pix_nan_all[0][0])[threadIdx.x] = 0;
   }
   if (threadIdx.x == 0)
     park_slot_lds = pt_park_acquire(L);
   __syncthreads();
 
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t slot = blockIdx.x % L.tile_count, chunk = blockIdx.x / L.tile_count;
+  /* work units = tile_count x sample_chunks, chunk-major (consecutive units are different tiles); wave w of
+   * workgroup b takes unit 4 b + w; the last workgroup may have waves without a unit (pool = 0) */
+  const uint32_t unit = blockIdx.x * (PT_BLOCK / 64) + wave;
+  const bool has_unit = unit < L.tile_count * L.sample_chunks;
+  const uint32_t slot = has_unit ? unit % L.tile_count : 0u, chunk = has_unit ? unit / L.tile_count : 0u;
   const uint32_t tile = L.tile_first + slot * L.tile_stride;
-  const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE + 2u * wave;
+  const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE;
   const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
-  const uint32_t vrows = ty0 >= (uint32_t)L.height ? 0u : min(2u, (uint32_t)L.height - ty0);
+  const uint32_t vrows = min((uint32_t)PT_TILE, (uint32_t)L.height - ty0);
   const uint32_t n_valid = vcols * vrows;
   const uint32_t spp = (uint32_t)L.samples;
   const uint32_t s_begin = (uint32_t)(((uint64_t)chunk * spp) / L.sample_chunks);
   const uint32_t s_end = (uint32_t)(((uint64_t)(chunk + 1u) * spp) / L.sample_chunks);
-  const uint32_t pool = n_valid * (s_end - s_begin);
+  const uint32_t pool = has_unit ? n_valid * (s_end - s_begin) : 0u;
+  unsigned long long *const pix_sum = pix_sum_all[wave];
+  unsigned long long *const pix_nan = pix_nan_all[wave];
   const CameraRegs cam = load_camera(L);
   const uint32_t park_slot = park_slot_lds;
   const bool ring_ok = park_slot != 0xFFFFFFFFu;
@@ -2187,10 +2190,10 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           DIAG(6, 1);
           DIAG_LANES(7);
           uint32_t idx, s;
-          if (n_valid == 16)
+          if (n_valid == PT_TILE_PIXELS)
           {
-            idx = job & 15u;
-            s = job >> 4;
+            idx = job & 63u;
+            s = job >> 6;
           }
           else
           {
@@ -2199,9 +2202,10 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           }
           const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
           const uint32_t col = idx - row * vcols;
-          const uint32_t slot_in_tile = (2u * wave + row) * PT_TILE + col;
+          const uint32_t slot_in_tile = row * PT_TILE + col;
           Path Q;
-          start_sample(Q, cam, pix_key[slot_in_tile], tx0 + col, ty0 + row, s_begin + s);
+          start_sample(Q, cam, rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col), tx0 + col, ty0 + row,
+                       s_begin + s);
           qd[lane] = Q.d.x;
           qd[64 + lane] = Q.d.y;
           qd[128 + lane] = Q.d.z;
@@ -2339,29 +2343,63 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     }
   }
 
-  if (n_rays)
+  /* ---- this wave's tile: counters, then the pixels (thread = pixel) ---- */
+  if (has_unit)
   {
-    atomicAdd(&wg_stats[0], (unsigned long long)n_rays);
-    atomicAdd(&wg_stats[1], (unsigned long long)n_casts);
+    uint32_t rays_w = n_rays, casts_w = n_casts;
+    for (int off = 32; off > 0; off >>= 1)
+    {
+      rays_w += (uint32_t)__shfl_xor((int)rays_w, off);
+      casts_w += (uint32_t)__shfl_xor((int)casts_w, off);
+    }
+    if (L.stats && lane == 0)
+    {
+      atomicAdd(&L.stats[0], (unsigned long long)rays_w);
+      atomicAdd(&L.stats[1], (unsigned long long)casts_w);
+      atomicAdd(&L.stats[2], (unsigned long long)casts_w * (unsigned long long)(S.n_sph + S.n_tri));
+      if (chunk == 0)
+        atomicAdd(&L.stats[3], (unsigned long long)n_valid * (unsigned long long)L.samples);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); /* the wave's own LDS atomics are done: sums are final */
+    __builtin_amdgcn_wave_barrier();
+    if (L.sample_chunks == 1)
+    {
+      const uint32_t t = lane;
+      const bool inside = (t & 7u) < vcols && (t >> 3) < vrows;
+      const double inv_s = 1.0 / (double)L.samples;
+      const double quiet_nan = __longlong_as_double(0x7FF8000000000000ll);
+      V3 mean;
+      mean.x = ((double)(long long)pix_sum[3 * t + 0] * L.acc_inv_scale) * inv_s;
+      mean.y = ((double)(long long)pix_sum[3 * t + 1] * L.acc_inv_scale) * inv_s;
+      mean.z = ((double)(long long)pix_sum[3 * t + 2] * L.acc_inv_scale) * inv_s;
+      mean.x = ((pix_nan[0] >> t) & 1ull) ? quiet_nan : mean.x; /* see finish_pixels */
+      mean.y = ((pix_nan[1] >> t) & 1ull) ? quiet_nan : mean.y;
+      mean.z = ((pix_nan[2] >> t) & 1ull) ? quiet_nan : mean.z;
+      float *of = L.tiles_rgb + (size_t)slot * (PT_TILE_PIXELS * 3) + 3 * t;
+      of[0] = inside ? (float)mean.x : 0.f;
+      of[1] = inside ? (float)mean.y : 0.f;
+      of[2] = inside ? (float)mean.z : 0.f;
+      if (L.tiles_rgb8)
+      {
+        uint8_t *ob = L.tiles_rgb8 + (size_t)slot * (PT_TILE_PIXELS * 3) + 3 * t;
+        ob[0] = inside ? tonemap(mean.x) : 0;
+        ob[1] = inside ? tonemap(mean.y) : 0;
+        ob[2] = inside ? tonemap(mean.z) : 0;
+      }
+    }
+    else
+    {
+      /* one of several sample chunks of this tile: exact integer partial sums to the tile's record */
+      for (uint32_t k = lane; k < PT_TILE_PIXELS * 3; k += 64)
+        if (pix_sum[k] != 0)
+          atomicAdd(&L.acc_ws[(size_t)slot * (PT_TILE_PIXELS * 3) + k], pix_sum[k]);
+      if (lane < 3 && pix_nan[lane] != 0)
+        atomicOr(&L.acc_ws[(size_t)L.tile_count * (PT_TILE_PIXELS * 3) + (size_t)slot * 3 + lane], pix_nan[lane]);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0 && ring_ok)
     atomicExch(&L.park_flags[park_slot], 0u); /* every wave is past its last ring access */
-
-  if (L.sample_chunks == 1)
-  {
-    finish_pixels(L, pix_sum, pix_nan, tile, out_f, out_b);
-    __syncthreads();
-    store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, true, true);
-  }
-  else
-  {
-    if (threadIdx.x < PT_TILE_PIXELS * 3 && pix_sum[threadIdx.x] != 0)
-      atomicAdd(&L.acc_ws[(size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x], pix_sum[threadIdx.x]);
-    if (threadIdx.x < 3 && pix_nan[threadIdx.x] != 0)
-      atomicOr(&L.acc_ws[(size_t)L.tile_count * (PT_TILE_PIXELS * 3) + (size_t)slot * 3 + threadIdx.x], pix_nan[threadIdx.x]);
-    store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, false, chunk == 0);
-  }
 }
 
 /* Kernel family pt_render_tiles[_tri][_big][_chk|_refr], picked by scene content
@@ -2934,7 +2972,10 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
     if (e != hipSuccess)
       return e;
   }
-  hipLaunchKernelGGL(kernel, dim3(launch.tile_count * launch.sample_chunks), dim3(PT_BLOCK), lds_bytes, stream, launch);
+  /* the parked-walk kernels render a tile per wave, four work units per workgroup */
+  const uint32_t n_units = launch.tile_count * launch.sample_chunks;
+  hipLaunchKernelGGL(kernel, dim3(which >= 19 ? (n_units + PT_BLOCK / 64 - 1) / (PT_BLOCK / 64) : n_units), dim3(PT_BLOCK), lds_bytes,
+                     stream, launch);
   if (launch.sample_chunks > 1)
     hipLaunchKernelGGL(pt_resolve_tiles, dim3(launch.tile_count), dim3(PT_BLOCK), 0, stream, launch);
   return hipGetLastError();
