@@ -1141,3 +1141,38 @@ def test_xcc_id_partitions_the_workgroups(gpu):
         assert all(c >= 2048 // 16 for c in got[:8]), got
     else:
         assert max(got) > 0
+
+
+@pytest.mark.parametrize("cfg,spp", [(4, 0), (3, 0), (5, 256)])
+def test_full_size_frames_are_partition_and_chunk_invariant(gpu, cfg, spp):
+    """BASELINE.json's full sizes through size-independent properties (the oracle cannot render these
+    frames): config 4 (1920x1080 x 1024 spp) and config 3 (x 256 spp) as they are, config 5 at its full
+    3840x2160 with 256 of its 4096 spp.  One launch == the 8-rank interleaved partition with each rank's
+    suggested sample chunks, bit for bit (float image, bytes, every counter); counters are self-consistent."""
+    import torch
+    from rt_amd import scene as S
+    sc = S.build_scene(cfg, samples=spp or None)
+    gs = gpu.GpuScene(sc)
+    total = gpu.n_tiles(sc.width, sc.height)
+    t, t8, st = gs.render_tiles(SEED, 0, 1, total)
+    full, full8 = gs.untile(t, t8, 0, 1, total)
+    torch.cuda.synchronize()
+    s = st.cpu().tolist()
+    n_prims = sc.n_objects + sc.n_triangles
+    assert s[3] == sc.width * sc.height * sc.samples and s[2] == s[1] * n_prims
+    assert s[3] <= s[1] <= s[0] <= s[3] * (sc.max_depth + 2)
+    image, image8 = torch.zeros_like(full), torch.zeros_like(full8)
+    tot = torch.zeros(4, dtype=torch.int64, device=full.device)
+    world = 8
+    for r in range(world):
+        first, stride, count = gpu.rank_tiles(sc.width, sc.height, r, world)
+        chunks = gs.suggest_chunks(count)
+        tr, tr8, sr = gs.render_tiles(SEED, first, stride, count, chunks=chunks)
+        gs.untile(tr, tr8, first, stride, count, image, image8)
+        tot += sr
+    torch.cuda.synchronize()
+    assert torch.equal(image, full) and torch.equal(image8, full8)
+    assert torch.equal(tot, st)
+    assert torch.isfinite(full).all() and float(full.max()) > 0.5
+    gs.close()
+    sc.free()
