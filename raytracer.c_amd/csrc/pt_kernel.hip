@@ -627,12 +627,18 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
  * V < -KV, or U + V > |a| + Ea + KU + KV, or T < -KT -- each a certain violation of one of the
  * exact test's conditions.  NaNs compare false: kept.  Triangles whose products could overflow
  * fp32 get Ea = +inf in the table: always kept. */
+__device__ __forceinline__ bool tri_may_hit32(const float4 &r0, const float4 &r1, const float4 &r2, float r3x, float ox,
+                                              float oy, float oz, float dx, float dy, float dz);
 __device__ __forceinline__ bool tri_may_hit32(const float4 *__restrict__ rec, float ox, float oy, float oz, float dx,
                                               float dy, float dz)
 {
-  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+  return tri_may_hit32(rec[0], rec[1], rec[2], rec[3].x, ox, oy, oz, dx, dy, dz);
+}
+__device__ __forceinline__ bool tri_may_hit32(const float4 &r0, const float4 &r1, const float4 &r2, float r3x, float ox,
+                                              float oy, float oz, float dx, float dy, float dz)
+{
   const float v0x = r0.x, v0y = r0.y, v0z = r0.z, e1x = r0.w, e1y = r1.x, e1z = r1.y, e2x = r1.z, e2y = r1.w, e2z = r2.x;
-  const float Ea = r2.y, KU = r2.z, KV = r2.w, KT = r3.x;
+  const float Ea = r2.y, KU = r2.z, KV = r2.w, KT = r3x;
   const float hx = __builtin_fmaf(dy, e2z, -(dz * e2y)), hy = __builtin_fmaf(dz, e2x, -(dx * e2z)),
               hz = __builtin_fmaf(dx, e2y, -(dy * e2x));
   const float a = __builtin_fmaf(e1z, hz, __builtin_fmaf(e1y, hy, e1x * hx));
@@ -887,7 +893,11 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.tri_object = sc.tri_object;
   ctx.filt = reinterpret_cast<const f32x2 *>(sc.filt);
   ctx.filt_lds = filt_lds;
-  ctx.tri32 = FILT_LDS ? reinterpret_cast<const float4 *>(filt_lds + pt_filt_pair_slots(n_entries)) : nullptr;
+  /* hierarchy scenes: the same table in LEAF order, in HBM behind the pair table (walk_parked) */
+  ctx.tri32 = FILT_LDS ? reinterpret_cast<const float4 *>(filt_lds + pt_filt_pair_slots(n_entries))
+                       : (sc.n_bvh_nodes != 0u ? reinterpret_cast<const float4 *>(reinterpret_cast<const f32x2 *>(sc.filt) +
+                                                                                 pt_filt_pair_slots(n_entries))
+                                               : nullptr);
   ctx.bvh_nodes = sc.bvh_nodes;
   ctx.bvh_tri = sc.bvh_tri;
   ctx.tri_leaf = sc.tri_geom_leaf;
@@ -1980,9 +1990,54 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
     else if (at_leaf)
     {
       const uint32_t first_tri = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
-      for (uint32_t k = 0; k < count; k++)
+      /* the fp32 pre-test (tri_may_hit32, table in leaf order) first: a leaf's box is entered for ~5 triangles of
+       * which the ray passes one or none, and the exact test costs the wave its full length while any lane's
+       * triangle needs it */
+      uint32_t keep = (1u << count) - 1u;
+      if (!far_origin)
+      {
+        const float fdx = (float)wd.x, fdy = (float)wd.y, fdz = (float)wd.z;
+        /* the walk is bound by memory round trips, not by instructions: triangle k + 1's record is on its way
+         * while k is tested (a leaf's records are consecutive) */
+        const float4 *rec = S.tri32 + (PT_TRI32_STRIDE / 4) * (size_t)first_tri;
+        float4 c0 = rec[0], c1 = rec[1], c2 = rec[2];
+        float c3 = rec[3].x;
+        for (uint32_t k = 0; k < count; k++)
+        {
+          DIAG(16, 1);
+          float4 n0 = c0, n1 = c1, n2 = c2;
+          float n3 = c3;
+          if (k + 1u < count)
+          {
+            rec += PT_TRI32_STRIDE / 4;
+            n0 = rec[0];
+            n1 = rec[1];
+            n2 = rec[2];
+            n3 = rec[3].x;
+          }
+          if (!tri_may_hit32(c0, c1, c2, c3, R.ox.x, R.oy.x, R.oz.x, fdx, fdy, fdz))
+            keep &= ~(1u << k);
+          c0 = n0;
+          c1 = n1;
+          c2 = n2;
+          c3 = n3;
+        }
+      }
+#ifdef PT_DIAG
+      for (uint32_t k = 0; k < count; k++) /* re-check: a dropped triangle must fail the exact test */
+      {
+        double t_probe = 1.7976931348623157e308, pu = 0, pv = 0;
+        int b_probe = -1;
+        exact_triangle(S.tri_leaf + 9 * (size_t)(first_tri + k), 0u, wo, wd, t_probe, b_probe, pu, pv);
+        if (!((keep >> k) & 1u) && b_probe >= 0)
+          atomicAdd(&diag_ptr[4 + 12], 1ull);
+      }
+#endif
+      while (keep != 0u)
       {
         DIAG(14, 1);
+        const uint32_t k = (uint32_t)__builtin_ctz(keep);
+        keep &= keep - 1u;
         const uint32_t t = S.bvh_tri[first_tri + k];
         exact_triangle<true, CHECKER>(S.tri_leaf + 9 * (size_t)(first_tri + k), S.n_sph + t, wo, wd, wmin_t, wbest, bu, bv, &last);
       }
@@ -2929,9 +2984,12 @@ hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float
   if (n_nodes)
     hipLaunchKernelGGL(pt_build_bvh, dim3(min(1024u, (n_nodes + 255u) / 256u)), dim3(256), 0, stream, scene.bvh_src,
                        n_nodes, near_R, bvh_nodes);
-  if (scene.n_triangles != 0 && pt_filter_in_lds(scene)) /* small scenes: the pre-test table behind the pair table */
-    hipLaunchKernelGGL(pt_build_tri32, dim3((scene.n_triangles + 255u) / 256u), dim3(256), 0, stream, scene.tri_geom,
-                       scene.n_triangles, near_R, filt + 2 * (size_t)pt_filt_pair_slots(n_entries));
+  /* the pre-test table behind the pair table: in scan order for small scenes (staged in LDS with the pairs), in the
+   * hierarchy's leaf order for large meshes (read from HBM at the leaves) */
+  if (scene.n_triangles != 0 && (pt_filter_in_lds(scene) || n_nodes != 0))
+    hipLaunchKernelGGL(pt_build_tri32, dim3(min(1024u, (scene.n_triangles + 255u) / 256u)), dim3(256), 0, stream,
+                       pt_filter_in_lds(scene) ? scene.tri_geom : scene.tri_geom_leaf, scene.n_triangles, near_R,
+                       filt + 2 * (size_t)pt_filt_pair_slots(n_entries));
   return hipGetLastError();
 }
 
