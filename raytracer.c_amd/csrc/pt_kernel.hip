@@ -370,6 +370,50 @@ __device__ __forceinline__ uint32_t (*bvh_stack_lds())[PT_BLOCK]
   return stack;
 }
 
+__device__ __forceinline__ bool tri_may_hit32(const float4 &r0, const float4 &r1, const float4 &r2, float r3x, float ox,
+                                              float oy, float oz, float dx, float dy, float dz);
+
+/* A leaf's triangles through the per-lane fp32 pre-test (tri_may_hit32: conservative; the table tri32 is in LEAF
+ * order here, in HBM behind the pair table) -> bit k set: triangle first + k needs the exact test.  A leaf holds
+ * ~5 triangles of which the ray passes one or none, and the exact fp64 test costs the wave its full length while
+ * any lane's triangle needs it.  The walk is bound by memory round trips as much as by instructions: triangle
+ * k + 1's record is on its way while k is tested (a leaf's records are consecutive).  Rays that start beyond
+ * near_R are outside the table's error bounds: every triangle is kept. */
+__device__ __forceinline__ uint32_t leaf_pretest(const float4 *__restrict__ tri32, uint32_t first, uint32_t count,
+                                                 bool far_origin, const BvhRay &R, const V3 &d,
+                                                 unsigned long long *diag_ptr)
+{
+  uint32_t keep = (1u << count) - 1u;
+  if (far_origin || tri32 == nullptr)
+    return keep;
+  const float fdx = (float)d.x, fdy = (float)d.y, fdz = (float)d.z;
+  const float4 *rec = tri32 + (PT_TRI32_STRIDE / 4) * (size_t)first;
+  float4 c0 = rec[0], c1 = rec[1], c2 = rec[2];
+  float c3 = rec[3].x;
+  for (uint32_t k = 0; k < count; k++)
+  {
+    DIAG(16, 1);
+    float4 n0 = c0, n1 = c1, n2 = c2;
+    float n3 = c3;
+    if (k + 1u < count)
+    {
+      rec += PT_TRI32_STRIDE / 4;
+      n0 = rec[0];
+      n1 = rec[1];
+      n2 = rec[2];
+      n3 = rec[3].x;
+    }
+    if (!tri_may_hit32(c0, c1, c2, c3, R.ox.x, R.oy.x, R.oz.x, fdx, fdy, fdz))
+      keep &= ~(1u << k);
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+  }
+  (void)diag_ptr;
+  return keep;
+}
+
 /* LAST / no_prune: scenes with M_CHECKERED materials and triangles need every triangle the ray
  * passes, not only those closer than the closest hit so far (TriLast): no pruning by min_t then. */
 template <bool LAST = false, bool OWN_STACK = false>
@@ -378,7 +422,8 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
                                              uint32_t n_sph, bool far_origin, const V3 &o, const V3 &d,
                                              double &min_t, int &best, double &bary_u, double &bary_v,
                                              unsigned long long *diag_ptr, TriLast *last = nullptr,
-                                             bool no_prune = false, uint32_t (*stack)[PT_BLOCK] = nullptr)
+                                             bool no_prune = false, uint32_t (*stack)[PT_BLOCK] = nullptr,
+                                             const float4 *__restrict__ tri32_leaf = nullptr)
 {
   if (!OWN_STACK) /* default: the workgroup's static array (the queued kernels pass their own, sized by the tree) */
     stack = bvh_stack_lds();
@@ -422,10 +467,12 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
     if (done)
       break;
     const uint32_t first = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
-    for (uint32_t k = 0; k < count; k++)
+    uint32_t keep = leaf_pretest(tri32_leaf, first, count, far_origin, R, d, diag_ptr);
+    while (keep != 0u)
     {
       DIAG(14, 1);
-      const uint32_t t = tri_order[first + k];
+      const uint32_t t = tri_order[first + (uint32_t)__builtin_ctz(keep)];
+      keep &= keep - 1u;
       exact_triangle<true, LAST>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v, last);
     }
     if (sp == 0)
@@ -797,7 +844,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
   }
   if (BVH && WALK) /* WALK = false: the caller walks the hierarchy itself, later (render_tiles_pooled) */
     bvh_traverse<LAST>(bvh_nodes, n_bvh_nodes, bvh_tri, tri_geom, n_sph, far_origin, o, d, min_t, best, bary_u, bary_v,
-                       diag_ptr, last, no_prune);
+                       diag_ptr, last, no_prune, nullptr, tri32); /* tri32: in leaf order for hierarchy scenes */
 }
 
 /* ---- scene as staged in LDS ------------------------------------------------------------ */
@@ -893,9 +940,12 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.tri_object = sc.tri_object;
   ctx.filt = reinterpret_cast<const f32x2 *>(sc.filt);
   ctx.filt_lds = filt_lds;
-  /* hierarchy scenes: the same table in LEAF order, in HBM behind the pair table (walk_parked) */
+  /* hierarchy scenes: the same table in LEAF order, in HBM behind the pair table (leaf_pretest).  A small scene's
+   * table is in scan order, for its own kernels (pt_launch_build_tables): the general kernels, which walk the
+   * hierarchy of such a scene too, go without the pre-test there */
   ctx.tri32 = FILT_LDS ? reinterpret_cast<const float4 *>(filt_lds + pt_filt_pair_slots(n_entries))
-                       : (sc.n_bvh_nodes != 0u ? reinterpret_cast<const float4 *>(reinterpret_cast<const f32x2 *>(sc.filt) +
+                       : ((sc.n_bvh_nodes != 0u && !pt_filter_in_lds(sc))
+                              ? reinterpret_cast<const float4 *>(reinterpret_cast<const f32x2 *>(sc.filt) +
                                                                                  pt_filt_pair_slots(n_entries))
                                                : nullptr);
   ctx.bvh_nodes = sc.bvh_nodes;
@@ -1683,7 +1733,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         {
           const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
           bvh_traverse<CHECKER>(S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.tri, S.n_sph, far_origin, P.o, P.d, hit.min_t,
-                                hit.best, hit.bary_u, hit.bary_v, diag_ptr, &hit.last, S.stale_uv);
+                                hit.best, hit.bary_u, hit.bary_v, diag_ptr, &hit.last, S.stale_uv, nullptr, S.tri32);
           mesh_wait = false;
         }
         wait_since = 0xFFFFFFFFu;
@@ -1990,39 +2040,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
     else if (at_leaf)
     {
       const uint32_t first_tri = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
-      /* the fp32 pre-test (tri_may_hit32, table in leaf order) first: a leaf's box is entered for ~5 triangles of
-       * which the ray passes one or none, and the exact test costs the wave its full length while any lane's
-       * triangle needs it */
-      uint32_t keep = (1u << count) - 1u;
-      if (!far_origin)
-      {
-        const float fdx = (float)wd.x, fdy = (float)wd.y, fdz = (float)wd.z;
-        /* the walk is bound by memory round trips, not by instructions: triangle k + 1's record is on its way
-         * while k is tested (a leaf's records are consecutive) */
-        const float4 *rec = S.tri32 + (PT_TRI32_STRIDE / 4) * (size_t)first_tri;
-        float4 c0 = rec[0], c1 = rec[1], c2 = rec[2];
-        float c3 = rec[3].x;
-        for (uint32_t k = 0; k < count; k++)
-        {
-          DIAG(16, 1);
-          float4 n0 = c0, n1 = c1, n2 = c2;
-          float n3 = c3;
-          if (k + 1u < count)
-          {
-            rec += PT_TRI32_STRIDE / 4;
-            n0 = rec[0];
-            n1 = rec[1];
-            n2 = rec[2];
-            n3 = rec[3].x;
-          }
-          if (!tri_may_hit32(c0, c1, c2, c3, R.ox.x, R.oy.x, R.oz.x, fdx, fdy, fdz))
-            keep &= ~(1u << k);
-          c0 = n0;
-          c1 = n1;
-          c2 = n2;
-          c3 = n3;
-        }
-      }
+      uint32_t keep = leaf_pretest(S.tri32, first_tri, count, far_origin, R, wd, diag_ptr);
 #ifdef PT_DIAG
       for (uint32_t k = 0; k < count; k++) /* re-check: a dropped triangle must fail the exact test */
       {
