@@ -335,17 +335,41 @@ __device__ __forceinline__ void bvh_test_children(const float *__restrict__ node
   r1 = __float_as_uint(tail.y);
 }
 
-/* Could the ray reach a triangle closer than min_t at all?  (The root's two child boxes.) */
+/* The bounding sphere of all triangles as the probe sees it: the compare form of the flat filter's test for a
+ * bounding entry (scan_filtered: keep unless tca < -(R + tol) or d2 > r2_hi), thresholds widened on the host for
+ * the launch's near_R by the bounds of pt_build_filter (rt_hip_shim.hip, mesh_bound_for). */
+struct MeshBound
+{
+  float cx, cy, cz, r2_hi, neg_tol;
+};
+
+/* Could the ray reach a triangle closer than min_t at all?  The root's two child boxes -- and the triangles'
+ * bounding sphere: boxes are loose around anything round (the two half-boxes of a sphere-like mesh show a ray
+ * about twice the silhouette of the mesh itself), and every ray let through costs a park / walk / resume cycle
+ * of ~15 node visits to find nothing. */
 __device__ __forceinline__ bool bvh_probe(const float *__restrict__ nodes, uint32_t n_nodes, bool far_origin,
-                                          const V3 &o, const V3 &d, double min_t)
+                                          const V3 &o, const V3 &d, double min_t, const MeshBound &mb, bool *in_sphere = nullptr)
 {
   if (n_nodes == 0)
     return false;
   bool hit0, hit1;
   float tn0, tn1;
   uint32_t r0, r1;
-  bvh_test_children(nodes, 0u, bvh_ray(o, d), far_origin, __double2float_ru(min_t), hit0, hit1, tn0, tn1, r0, r1);
-  return hit0 || hit1;
+  const BvhRay R = bvh_ray(o, d);
+  bvh_test_children(nodes, 0u, R, far_origin, __double2float_ru(min_t), hit0, hit1, tn0, tn1, r0, r1);
+  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  const float lx = mb.cx - R.ox.x, ly = mb.cy - R.oy.x, lz = mb.cz - R.oz.x;
+  const float tca = __builtin_fmaf(lz, dz, __builtin_fmaf(ly, dy, lx * dx));
+  const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+  const float d2 = __builtin_fmaf(-tca, tca, ll);
+  /* NaNs compare false: kept */
+  const bool inside = far_origin | (!(tca < mb.neg_tol) & !(d2 > mb.r2_hi));
+  if (in_sphere)
+  { /* PT_DIAG: the caller walks the ray anyway and checks that it finds nothing */
+    *in_sphere = inside;
+    return hit0 || hit1;
+  }
+  return (hit0 || hit1) && inside;
 }
 
 /* Ordered walk of the triangle hierarchy (pt_device.h: bvh_nodes).  Per lane and per visit:
@@ -865,6 +889,7 @@ struct SceneCtx
   const uint32_t *bvh_tri;
   const double *tri_leaf; /* HBM: tri geometry in leaf order (pt_device.h) */
   uint32_t n_bvh_nodes;
+  MeshBound mesh_bound;   /* bvh_probe's bounding sphere of all triangles (launch arguments: SGPRs) */
   double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
   double filt_shift;      /* tol_max of the sign-test filter form (scan_filtered) */
   double bg, t_start;     /* BACKGROUND's component and DBL_MAX, from the launch arguments (SGPR pairs) */
@@ -952,6 +977,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.bvh_tri = sc.bvh_tri;
   ctx.tri_leaf = sc.tri_geom_leaf;
   ctx.n_bvh_nodes = sc.n_bvh_nodes;
+  ctx.mesh_bound = {L.mesh_bound[0], L.mesh_bound[1], L.mesh_bound[2], L.mesh_bound[3], L.mesh_bound[4]};
   ctx.near_R2 = L.near_R2;
   ctx.filt_shift = L.filt_shift;
   ctx.bg = L.background;
@@ -1720,7 +1746,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
         /* stale_uv: every triangle the ray passes matters, not only those closer than min_t (TriLast) */
         mesh_wait = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
-                                              (CHECKER && S.stale_uv) ? S.t_start : hit.min_t);
+                                              (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound);
       }
       const uint32_t n_wait = (uint32_t)__popcll(__ballot(busy && mesh_wait));
       const uint32_t n_go = (uint32_t)__popcll(__ballot(busy && !mesh_wait));
@@ -1977,6 +2003,11 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
   BvhRay R = bvh_ray(wo, wd);
   TriLast last = {-1, 0, 0};
   const bool no_prune = CHECKER && S.stale_uv;
+#ifdef PT_DIAG
+  uint32_t visits = 0;
+  int wbest0 = wbest;
+  bool outside_bound = false; /* the probe's bounding sphere would have kept this ray out: it must find nothing */
+#endif
   for (;;)
   {
     /* refill in batches: every refill is a memory round trip the whole wave waits for, so free lanes
@@ -1998,6 +2029,11 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         ref = 0; /* the root */
         last.idx = -1;
         have = true;
+#ifdef PT_DIAG
+        visits = 0;
+        wbest0 = wbest;
+        outside_bound = (ring_ldu(ring, 1u, e) & 0x80000000u) != 0u;
+#endif
       }
       next = min(n_new, next + (uint32_t)__popcll(need));
     }
@@ -2014,6 +2050,9 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
       {
         DIAG(13, 1);
         DIAG_LANES(15);
+#ifdef PT_DIAG
+        visits++;
+#endif
         bool hit0, hit1;
         float tn0, tn1;
         uint32_t r0, r1;
@@ -2069,6 +2108,14 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
     }
     if (finished)
     {
+#ifdef PT_DIAG
+      /* walked rays: those that come back with a triangle; walks of 1, 2-3, 4-6, more node visits */
+      if (wbest >= (int)S.n_sph)
+        atomicAdd(&diag_ptr[4 + 18], 1ull);
+      if (outside_bound && (wbest != wbest0 || last.idx >= 0))
+        atomicAdd(&diag_ptr[4 + 12], 1ull); /* a violation of the conservative probe */
+      atomicAdd(&diag_ptr[4 + (visits <= 1u ? 19 : (visits <= 3u ? 20 : (visits <= 6u ? 21 : 22)))], 1ull);
+#endif
       if (own)
       {
         own_hit.min_t = wmin_t;
@@ -2230,7 +2277,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         P.rng = (uint64_t)__double_as_longlong(st_f[wave][9][q]);
         hit.min_t = st_f[wave][10][q];
         hit.best = (int)st_u[wave][0][q];
-        const uint32_t dp = st_u[wave][1][q];
+        const uint32_t dp = st_u[wave][1][q] & 0x7FFFFFFFu; /* bit 31: PT_DIAG's flag */
         P.depth = (int)(dp >> 6);
         pix_slot = dp & 63u;
         if (CHECKER)
@@ -2318,6 +2365,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     /* ---- first half of trace_path(): depth test + flat scan over the spheres, then the probe ---- */
     const bool stepping = busy && !hit.need_dir && !resumed;
     bool want_walk = false;
+#ifdef PT_DIAG
+    bool diag_in_sphere = true;
+#endif
     if (stepping)
     {
       DIAG(0, 1);
@@ -2325,8 +2375,13 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       n_rays++;
       (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
       const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
+#ifdef PT_DIAG
       want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
-                                            (CHECKER && S.stale_uv) ? S.t_start : hit.min_t);
+                                            (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound, &diag_in_sphere);
+#else
+      want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
+                                            (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound);
+#endif
     }
     /* ---- rays that can reach the mesh are parked; their lanes are idle from here on ---- */
     const unsigned long long wants = __ballot(want_walk);
@@ -2346,9 +2401,16 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           ring_st(ring, 9u, e, __longlong_as_double((long long)P.rng));
           ring_st(ring, 10u, e, hit.min_t);
           ring_stu(ring, 0u, e, (uint32_t)hit.best);
+#ifdef PT_DIAG
+          ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot | (diag_in_sphere ? 0u : 0x80000000u));
+          if (diag_in_sphere)
+            DIAG_LANES(23);
+#else
           ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot);
+#endif
           parked = true;
           busy = false;
+          DIAG_LANES(17);
         }
         n_new += min((uint32_t)__popcll(wants), space);
       }

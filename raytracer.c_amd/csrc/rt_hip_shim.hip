@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -60,6 +61,8 @@ struct RtHipScene
   double max_emission = 0; /* max |emission component| over all materials */
   bool any_mirror_glass = false; /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children */
   double max_center = 0; /* max |centre| over the spheres (rounded up) */
+  /* bounding sphere of every triangle (bvh_probe): centre, radius, |centre| -- radius < 0: no triangles */
+  double mesh_c[3] = {0, 0, 0}, mesh_R = -1, mesh_c_norm = 0;
 };
 
 namespace
@@ -593,6 +596,45 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     }
   }
 
+  /* ---- bounding sphere of all triangles, as the kernels see them (v0, v0 + e1, v0 + e2): centre = middle of
+   * their bounds, radius = the farthest corner, with slack for the roundings of e1, e2 and of the exact test's
+   * own barycentric limits ---- */
+  double mesh_c[3] = {0, 0, 0}, mesh_R = -1;
+  if (n_tri != 0)
+  {
+    double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    auto corner = [&](size_t tri, int k, double *p) {
+      const double *g = &tgeom[9 * tri];
+      for (int a = 0; a < 3; a++)
+        p[a] = k == 0 ? g[a] : g[a] + g[3 * k + a];
+    };
+    for (size_t i = 0; i < n_tri; i++)
+      for (int k = 0; k < 3; k++)
+      {
+        double p[3];
+        corner(i, k, p);
+        for (int a = 0; a < 3; a++)
+        {
+          lo[a] = std::fmin(lo[a], p[a]);
+          hi[a] = std::fmax(hi[a], p[a]);
+        }
+      }
+    for (int a = 0; a < 3; a++)
+      mesh_c[a] = 0.5 * lo[a] + 0.5 * hi[a];
+    double r2 = 0;
+    for (size_t i = 0; i < n_tri; i++)
+      for (int k = 0; k < 3; k++)
+      {
+        double p[3];
+        corner(i, k, p);
+        const double dx = p[0] - mesh_c[0], dy = p[1] - mesh_c[1], dz = p[2] - mesh_c[2];
+        r2 = std::fmax(r2, dx * dx + dy * dy + dz * dz);
+      }
+    mesh_R = std::sqrt(r2) * (1.0 + 1e-9) + 1e-300;
+    if (!(mesh_R < HUGE_VAL)) /* non-finite input: a bound that keeps every ray */
+      mesh_R = HUGE_VAL;
+  }
+
   /* ---- hierarchy over the triangles ---- */
   BvhBuild bvh;
   /* built for every scene with triangles: the small-scene kernels scan them through the flat
@@ -681,6 +723,10 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.tri_geom_leaf = reinterpret_cast<const double *>(base + off_tgeom_leaf);
   sc->view.n_bvh_nodes = (uint32_t)n_bvh_nodes;
   sc->view.bvh_depth = (uint32_t)bvh.depth;
+  for (int a = 0; a < 3; a++)
+    sc->mesh_c[a] = mesh_c[a];
+  sc->mesh_R = mesh_R;
+  sc->mesh_c_norm = std::sqrt(mesh_c[0] * mesh_c[0] + mesh_c[1] * mesh_c[1] + mesh_c[2] * mesh_c[2]) * (1.0 + 1e-12);
   sc->filt_bytes = filt_bytes;
   sc->bvh_nodes_bytes = n_bvh_nodes * PT_BVH_NODE_WORDS * 4;
   sc->view.material = reinterpret_cast<const double *>(base + off_mat);
@@ -766,6 +812,25 @@ uint32_t rt_hip_suggest_chunks(const RtHipScene *scene, uint32_t tile_count, int
   return chunks < 1 ? 1u : (uint32_t)chunks;
 }
 
+/* bvh_probe's bounding sphere of the triangles for one near_R: the thresholds of a bounding entry of the flat
+ * filter in its compare form, widened exactly as pt_build_filter widens them (e = 2^-24, A = |c| + near_R:
+ * |tca32 - tca| <= 6.2 e A, |d2_32 - d2| <= 20.5 e A^2 for origins within near_R; the conversions to fp32 are
+ * inside the (1 + k e) factors).  Non-finite or overflowing values give thresholds that keep every ray. */
+static void mesh_bound_for(const RtHipScene *scene, double near_R, float out[5])
+{
+  const float inf = std::numeric_limits<float>::infinity();
+  out[0] = out[1] = out[2] = 0.f;
+  out[3] = inf;
+  out[4] = -inf;
+  if (!(scene->mesh_R >= 0) || !(scene->mesh_R < 1e18) || !(scene->mesh_c_norm < 1e18) || !(near_R < 1e18))
+    return;
+  const double e = 5.9604644775390625e-08, A = scene->mesh_c_norm + near_R;
+  for (int a = 0; a < 3; a++)
+    out[a] = (float)scene->mesh_c[a];
+  out[3] = (float)((scene->mesh_R * scene->mesh_R + 32.0 * e * A * A) * (1.0 + 8.0 * e));
+  out[4] = -(float)((scene->mesh_R + 10.0 * e * A) * (1.0 + 4.0 * e));
+}
+
 int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
                         float *d_tiles_rgb, uint8_t *d_tiles_rgb8, uint64_t *d_stats, void *stream)
 {
@@ -829,6 +894,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
       return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.near_R);
     L.near_R2 = L.near_R * L.near_R;
     L.filt_shift = 12.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
+    mesh_bound_for(scene, L.near_R, L.mesh_bound);
     L.background = 10 / 255.0;
     L.t_start = 1.7976931348623157e308; /* DBL_MAX */
     L.w_minus_1 = (double)params->width - 1.0;

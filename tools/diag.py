@@ -10,7 +10,7 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 sc = S.build_scene(cfg, samples=spp)
 gs = G.GpuScene(sc)
-stats = torch.zeros(24, dtype=torch.int64, device="cuda")
+stats = torch.zeros(32, dtype=torch.int64, device="cuda")
 total = G.n_tiles(sc.width, sc.height)
 gs.render_tiles(1666943821, 0, 1, total, stats=stats)
 torch.cuda.synchronize()
@@ -18,7 +18,9 @@ st = stats.cpu().tolist()
 rays, casts = st[0], st[1]
 d = st[4:]
 names = ["loop iters (wave)", "loop lanes", "phase2 iters (wave)", "phase2 cands (lane)", "sqrt blocks (wave)", "sqrt lanes",
-         "fresh blocks (wave)", "fresh lanes", "hit blocks (wave)", "hit lanes", "reject-loop iters (wave)", "reject-loop lanes", "FILTER VIOLATIONS (must be 0)", "bvh node visits (wave)", "bvh leaf triangle tests (wave)", "bvh node-visit lanes", "bvh leaf pre-tests (wave)"]
+         "fresh blocks (wave)", "fresh lanes", "hit blocks (wave)", "hit lanes", "reject-loop iters (wave)", "reject-loop lanes", "FILTER VIOLATIONS (must be 0)", "bvh node visits (wave)", "bvh leaf triangle tests (wave)", "bvh node-visit lanes", "bvh leaf pre-tests (wave)", "parked rays", "walked rays returning a triangle",
+         "walks of 1 node visit", "walks of 2-3", "walks of 4-6", "walks of 7+",
+         "parked rays inside the triangles' bounding sphere"]
 for n, v in zip(names, d):
     print(f"{n:28s} {v:15d}")
 assert d[12] == 0, 'the conservative filter dropped a sphere the exact test accepts'
@@ -32,4 +34,9 @@ print(f"hit per iter {d[8] / it:.3f} lanes/64 {d[9] / (64.0 * max(d[8], 1)):.3f}
 print(f"bvh node-visit wave iterations per loop iter {d[13] / it:.1f} (lanes/64 {d[15] / (64.0 * max(d[13], 1)):.3f}, "
       f"node visits per cast {d[15] / max(casts, 1):.1f}); leaf triangle-test wave iterations per loop iter {d[14] / it:.1f}, "
       f"fp32 pre-tests before them {d[16] / it:.1f}")
+if d[17]:
+    print(f"(PT_DIAG parks every ray that passes the boxes; the shipped build only those also inside the bounding sphere: "
+          f"{d[23] / d[17]:.3f} of them)")
+    print(f"parked rays per cast {d[17] / casts:.3f}; of the walked rays {d[18] / d[17]:.3f} return with a triangle; walks by node "
+          f"visits 1: {d[19] / d[17]:.3f}  2-3: {d[20] / d[17]:.3f}  4-6: {d[21] / d[17]:.3f}  7+: {d[22] / d[17]:.3f}")
 print(f"reject iters per loop iter {d[10] / it:.2f} lanes/64 {d[11] / (64.0 * max(d[10], 1)):.3f}")
