@@ -4,7 +4,5 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "mesh or config5 or hierarchy or soup or golden or tri or fuzz" > gpurun_out/pytest_leaf.log 2>&1
 rc=$?; echo "pytest exit $rc"; tail -2 gpurun_out/pytest_leaf.log
 [ $rc -eq 0 ] || exit $rc
-RT_HIP_SHIM_PATH=raytracer.c_amd/csrc/librt_hip_diag.so timeout -k 10 300 python tools/diag.py 5 64 2>&1 | tail -8
-RT_HIP_SHIM_PATH=raytracer.c_amd/csrc/librt_hip_diag.so timeout -k 10 500 python tools/diag_fuzz.py > gpurun_out/diag_fuzz.log 2>&1; echo "diag_fuzz exit $?"; tail -1 gpurun_out/diag_fuzz.log
 timeout -k 10 600 python tools/gpu_ab.py --config 5 --spp 64 --reps 2 head base
 timeout -k 10 600 python tools/gpu_ab.py --config 5 --spp 256 --reps 1 head base
