@@ -158,6 +158,7 @@ struct PtLaunch
    * reference forms them, (double)options->width - 1.0 (raytracer.c:203-204) */
   double near_R2, w_minus_1, h_minus_1;
   double filt_shift; /* 12 e (max |c| + near_R): how far behind the origin the sign-test filter starts its ray */
+  uint32_t diag_flags; /* PT_DIAG builds only: bit 0 = walk the rays the probe's bounding sphere rejects, to check them */
   float mesh_bound[5]; /* bvh_probe: the triangles' bounding sphere for this near_R: cx cy cz r2_hi neg_tol (pt_kernel.hip, MeshBound) */
   /* two constants passed in so that they live in SGPRs (as literals the compiler parks each in a
    * VGPR pair for the whole loop, and spilled them): BACKGROUND's component 10/255

@@ -2377,8 +2377,11 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
       const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
 #ifdef PT_DIAG
+      /* RT_HIP_DIAG_WALK_REJECTED=1: rays the bounding sphere rejects are parked and walked all the same, and any
+       * that comes back with a triangle counts as a violation; otherwise the build parks what the shipped one parks */
       want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
-                                            (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound, &diag_in_sphere);
+                                            (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound,
+                                            (L.diag_flags & 1u) ? &diag_in_sphere : nullptr);
 #else
       want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
                                             (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound);

@@ -895,6 +895,10 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     L.near_R2 = L.near_R * L.near_R;
     L.filt_shift = 12.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
     mesh_bound_for(scene, L.near_R, L.mesh_bound);
+    {
+      const char *flag = getenv("RT_HIP_DIAG_WALK_REJECTED");
+      L.diag_flags = (flag && flag[0] == '1') ? 1u : 0u;
+    }
     L.background = 10 / 255.0;
     L.t_start = 1.7976931348623157e308; /* DBL_MAX */
     L.w_minus_1 = (double)params->width - 1.0;

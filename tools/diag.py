@@ -35,8 +35,9 @@ print(f"bvh node-visit wave iterations per loop iter {d[13] / it:.1f} (lanes/64 
       f"node visits per cast {d[15] / max(casts, 1):.1f}); leaf triangle-test wave iterations per loop iter {d[14] / it:.1f}, "
       f"fp32 pre-tests before them {d[16] / it:.1f}")
 if d[17]:
-    print(f"(PT_DIAG parks every ray that passes the boxes; the shipped build only those also inside the bounding sphere: "
-          f"{d[23] / d[17]:.3f} of them)")
+    if os.environ.get("RT_HIP_DIAG_WALK_REJECTED") == "1":
+        print(f"(RT_HIP_DIAG_WALK_REJECTED=1: every ray that passes the boxes is parked; the shipped build parks only those also "
+              f"inside the bounding sphere: {d[23] / d[17]:.3f} of them)")
     print(f"parked rays per cast {d[17] / casts:.3f}; of the walked rays {d[18] / d[17]:.3f} return with a triangle; walks by node "
           f"visits 1: {d[19] / d[17]:.3f}  2-3: {d[20] / d[17]:.3f}  4-6: {d[21] / d[17]:.3f}  7+: {d[22] / d[17]:.3f}")
 print(f"reject iters per loop iter {d[10] / it:.2f} lanes/64 {d[11] / (64.0 * max(d[10], 1)):.3f}")

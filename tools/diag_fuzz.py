@@ -12,6 +12,7 @@ from test_gpu_parity import _random_scene
 from util import whitted_scene
 
 assert "diag" in os.environ.get("RT_HIP_SHIM_PATH", ""), "run with the PT_DIAG build"
+os.environ["RT_HIP_DIAG_WALK_REJECTED"] = "1"  # also walk what bvh_probe's bounding sphere rejects, and count any triangle found
 scenes = [("config %d" % c, S.build_scene(c, w, h, spp)) for c, w, h, spp in
           [(1, 256, 256, 4), (2, 400, 300, 8), (3, 240, 136, 4), (4, 480, 270, 16), (5, 96, 54, 2)]]
 scenes += [("fuzz %d" % k, _random_scene(k, False, 0)) for k in range(40)]
