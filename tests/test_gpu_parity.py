@@ -1176,3 +1176,49 @@ def test_full_size_frames_are_partition_and_chunk_invariant(gpu, cfg, spp):
     assert torch.isfinite(full).all() and float(full.max()) > 0.5
     gs.close()
     sc.free()
+
+
+def _icosphere(radius, center, levels):
+    """triangles (each 3 x (x, y, z)) of a subdivided icosahedron: 20 * 4**levels faces, vertices on the sphere"""
+    import math
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+         (9, 8, 1)]
+
+    def unit(p):
+        n = math.sqrt(sum(x * x for x in p))
+        return tuple(x / n for x in p)
+    tris = [tuple(unit(v[i]) for i in face) for face in f]
+    for _ in range(levels):
+        nxt = []
+        for a, b, c in tris:
+            ab, bc, ca = (unit(tuple((x + y) / 2 for x, y in zip(p, q))) for p, q in ((a, b), (b, c), (c, a)))
+            nxt += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        tris = nxt
+    return [[tuple(center[k] + radius * p[k] for k in range(3)) for p in tri] for tri in tris]
+
+
+@pytest.mark.parametrize("cam", [(0, 4, 30), (0, 0.5, 4.2), (0.3, 0.2, 0.1), (0, 0, 3.9999), (0, 9, 0.5), (55, 30, 40)])
+def test_round_mesh_probe_from_outside_near_and_inside(gpu, pt, cam):
+    """the probe that decides which rays are parked for a hierarchy walk tests the triangles' bounding sphere
+    (bvh_probe, conservative fp32): a round mesh (320-face icosphere of radius 4, where that sphere is tight) seen
+    from far away, from just outside its surface, from its centre region, from a point on the bounding sphere
+    itself to rounding, from above, and from beyond the scene -- frames and counters equal the oracle's, which
+    scans every triangle"""
+    from rt_amd import abi, scene as S
+    meshes = [dict(flags=abi.M_DEFAULT, color=(0.8, 0.5, 0.3), triangles=_icosphere(4.0, (0, 0, 0), 2))]
+    objs = [dict(flags=abi.M_DEFAULT, radius=1e4, center=(0, -10006.0, 0), color=(0.7, 0.7, 0.7)),
+            dict(flags=abi.M_REFLECTION, radius=3.0, center=(8, -1, 2), color=(1, 1, 1)),
+            dict(flags=abi.M_DEFAULT, radius=2.0, center=(-7, 1, 5), color=(0.3, 0.4, 0.9)),
+            dict(flags=abi.M_DEFAULT, radius=6.0, center=(0, 22, 0), color=(1, 1, 1), emission=(4, 4, 4))]
+    sc = S.custom_scene(objs, 64, 40, 4, 6, cam, (0, 0, 0) if cam != (0.3, 0.2, 0.1) else (5, 1, 5), meshes=meshes)
+    assert sc.n_triangles == 320
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name() == "pt_render_tiles_tri_queued"
+    gs.close()
+    st = _full(gpu, pt, sc)
+    assert st["tests"] == st["casts"] * (4 + 320)
+    _full(gpu, pt, sc, integrator="whitted")
