@@ -144,6 +144,11 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
 void rt_hip_scene_destroy(RtHipScene *scene);
 int rt_hip_scene_device(const RtHipScene *scene);
 size_t rt_hip_scene_primitives(const RtHipScene *scene); /* spheres + triangles */
+/* diagnostic: how many triangles the scene marked as HULL FACETS -- every triangle of the scene lies on the inner
+ * side of their plane, the stored normal (calculate_surface_normal, raytracer.c:42-45) pointing outward (*n_plus)
+ * or inward (*n_minus).  A bounce that leaves such a facet on its outer side cannot meet a triangle, so the
+ * hierarchy kernels do not walk it (pt_device.h).  0 / 0 for more than 65,536 triangles (the marking is quadratic). */
+int rt_hip_scene_hull_facets(const RtHipScene *scene, uint32_t *n_plus, uint32_t *n_minus);
 /* name of the render kernel a launch of this scene takes (the family is picked by scene content:
  * triangles, table size, M_CHECKERED / M_REFRACTION materials) -- for profiles and bench lines */
 const char *rt_hip_kernel_name(const RtHipScene *scene, uint32_t integrator);

@@ -27,7 +27,10 @@
  *       (raytracer.c:42-45), read only for the winning triangle.
  *   tri_tex    [n_triangles] x 6 f64 : st0, st1, st2 (read only for a winning triangle of an
  *       M_CHECKERED mesh).
- *   tri_object [n_triangles] u32     : material slot of the owning mesh.
+ *   tri_object [n_triangles] u32     : material slot of the owning mesh; bits 31 / 30 (PT_HULL_PLUS / PT_HULL_MINUS,
+ *       set on the device by pt_build_hull_flags): every triangle of the scene lies on the inner side of this
+ *       triangle's plane, the stored normal pointing out / in -- a ray that leaves such a HULL FACET on its outer
+ *       side cannot meet a triangle again.
  *   bvh_src    [n_bvh_nodes] x 16 f64 : a binary bounding-volume hierarchy over the triangles
  *       (built for every scene that has any; the small-scene kernels scan triangles through
  *       the flat filter and ignore it).  A node holds the boxes of its TWO children
@@ -71,6 +74,9 @@
 #define PT_PARK_SLOTS_PER_XCD 192u
 #define PT_PARK_XCDS 8u
 
+#define PT_HULL_PLUS 0x80000000u
+#define PT_HULL_MINUS 0x40000000u
+#define PT_HULL_MAX_TRIS 65536u /* pt_build_hull_flags is quadratic: larger triangle sets go without the flags */
 #define PT_ACC_WS_WORDS (PT_TILE_PIXELS * 3 + 3) /* chunked renders: u64 per tile in the workspace: 192 sums + 3 NaN masks */
 
 #define PT_REFRACT_MAX_DEPTH 32 /* the pending-ray stack of the two-child kernels holds max_depth + 2 */
@@ -158,6 +164,7 @@ struct PtLaunch
    * reference forms them, (double)options->width - 1.0 (raytracer.c:203-204) */
   double near_R2, w_minus_1, h_minus_1;
   double filt_shift; /* 12 e (max |c| + near_R): how far behind the origin the sign-test filter starts its ray */
+  double hull_margin; /* a ray leaves a hull facet for good if (outward normal) . d exceeds this (rt_hip_shim.hip) */
   uint32_t diag_flags; /* PT_DIAG builds only: bit 0 = walk the rays the probe's bounding sphere rejects, to check them */
   float mesh_bound[5]; /* bvh_probe: the triangles' bounding sphere for this near_R: cx cy cz r2_hi neg_tol (pt_kernel.hip, MeshBound) */
   /* two constants passed in so that they live in SGPRs (as literals the compiler parks each in a
@@ -185,6 +192,8 @@ struct PtLaunch
 /* host-side launchers, defined next to the kernels in pt_kernel.hip */
 size_t pt_render_lds_bytes(const PtSceneView &scene);
 hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant);
+hipError_t pt_launch_build_hull_flags(const double *tri_geom, const double *tri_normal, uint32_t n_tri, double tau,
+                                      uint32_t *tri_object, hipStream_t stream);
 hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream);
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant);
 hipError_t pt_launch_selftest_xcc(unsigned int *counts, uint32_t n_workgroups, hipStream_t stream);

@@ -891,6 +891,7 @@ struct SceneCtx
   const double *tri_leaf; /* HBM: tri geometry in leaf order (pt_device.h) */
   uint32_t n_bvh_nodes;
   MeshBound mesh_bound;   /* bvh_probe's bounding sphere of all triangles (launch arguments: SGPRs) */
+  double hull_margin;     /* a ray leaves a hull facet for good if outward . d exceeds this (launch argument) */
   double near_R2;         /* the filter is valid for ray origins with |o|^2 <= near_R2 */
   double filt_shift;      /* tol_max of the sign-test filter form (scan_filtered) */
   double bg, t_start;     /* BACKGROUND's component and DBL_MAX, from the launch arguments (SGPR pairs) */
@@ -979,6 +980,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.tri_leaf = sc.tri_geom_leaf;
   ctx.n_bvh_nodes = sc.n_bvh_nodes;
   ctx.mesh_bound = {L.mesh_bound[0], L.mesh_bound[1], L.mesh_bound[2], L.mesh_bound[3], L.mesh_bound[4]};
+  ctx.hull_margin = L.hull_margin;
   ctx.near_R2 = L.near_R2;
   ctx.filt_shift = L.filt_shift;
   ctx.bg = L.background;
@@ -1112,8 +1114,11 @@ struct HitRec
    * NORMAL meanwhile, P.T lacks the factor albedo * cos; dir_slot / dir_scale say which
    * albedo (material slot, checker factor). */
   bool need_dir;
-  uint32_t dir_slot;
+  uint32_t dir_slot; /* bit 31: the hit is on a hull facet whose stored normal points outward (PT_HULL_PLUS) */
   double dir_scale;
+  /* the ray this call sends on starts on a hull facet and leaves on its outer side by more than the launch's
+   * margin: it cannot meet a triangle (pt_build_hull_flags); kernels with parked walks skip the probe for it */
+  bool leaving;
   TriLast last; /* kernels with M_CHECKERED code and triangles only */
 };
 
@@ -1166,6 +1171,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
   }
   const double min_t = H.min_t;
   const int best = H.best;
+  if (TRIS && (MODE != 0 || DEFER_DIR))
+    H.leaving = false;
 
   if (H.depth_ok)
   {
@@ -1176,7 +1183,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       /* ---- the winner's hit record (:406-411 / :428-431) ---- */
       V3 p = v_add(o, v_scale(d, min_t)); /* point_at :257 */
       V3 n;
-      uint32_t slot;
+      uint32_t slot, hull = 0u;
       double tex_u = 0, tex_v = 0;
       const bool is_tri = TRIS && (uint32_t)best >= S.n_sph;
       if (!is_tri)
@@ -1194,6 +1201,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         const uint32_t ti = (uint32_t)best - S.n_sph;
         n = ld3(S.tri_normal + 3 * (size_t)ti);
         slot = S.tri_object[ti];
+        hull = slot & (PT_HULL_PLUS | PT_HULL_MINUS);
+        slot &= ~(PT_HULL_PLUS | PT_HULL_MINUS);
       }
       const double *m = S.mat + PT_MAT_STRIDE * slot;
       const double prob = m[0];
@@ -1269,7 +1278,11 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         else if (flags & PT_FLAG_MIRROR)
         {
           /* reflect :349-352; direction left un-normalised (:542) */
-          nd = v_sub(d, v_scale(n, 2 * v_dot(d, n)));
+          const double dn = v_dot(d, n);
+          nd = v_sub(d, v_scale(n, 2 * dn));
+          /* nd . n = -(d . n) up to rounding far below the margin */
+          if (TRIS && (MODE != 0 || DEFER_DIR))
+            H.leaving = (hull & PT_HULL_PLUS) ? (-dn > S.hull_margin) : ((hull & PT_HULL_MINUS) ? (dn > S.hull_margin) : false);
         }
         else
         {
@@ -1277,7 +1290,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           if (DEFER_DIR)
           {
             H.need_dir = true;
-            H.dir_slot = slot;
+            H.dir_slot = slot | (hull & PT_HULL_PLUS); /* the bounce goes into the stored normal's hemisphere */
             H.dir_scale = checker_scale;
             dir_deferred = true;
             nd = n; /* P.d carries the normal until the caller has the sample */
@@ -1372,7 +1385,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
       {
         const uint32_t ti = (uint32_t)best - S.n_sph;
         n = ld3(S.tri_normal + 3 * (size_t)ti);
-        slot = S.tri_object[ti];
+        slot = S.tri_object[ti] & ~(PT_HULL_PLUS | PT_HULL_MINUS);
       }
       const uint32_t flags = (uint32_t)__double_as_longlong(S.mat[PT_MAT_STRIDE * slot + 7]);
       V3 color = ld3(S.color_raw + 3 * (size_t)slot);
@@ -1818,7 +1831,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       }
       if (!again)
       {
-        const double *m = S.mat + PT_MAT_STRIDE * hit.dir_slot;
+        const double *m = S.mat + PT_MAT_STRIDE * (hit.dir_slot & ~PT_HULL_PLUS);
         V3 albedo = ld3(m + 1);
         if (CHECKER)
           albedo = v_scale(albedo, hit.dir_scale);
@@ -2008,6 +2021,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
   uint32_t visits = 0;
   int wbest0 = wbest;
   bool outside_bound = false; /* the probe's bounding sphere would have kept this ray out: it must find nothing */
+  bool origin_inside = false;
 #endif
   for (;;)
   {
@@ -2034,6 +2048,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         visits = 0;
         wbest0 = wbest;
         outside_bound = (ring_ldu(ring, 1u, e) & 0x80000000u) != 0u;
+        origin_inside = (ring_ldu(ring, 1u, e) & 0x40000000u) != 0u;
 #endif
       }
       next = min(n_new, next + (uint32_t)__popcll(need));
@@ -2113,6 +2128,8 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
       /* walked rays: those that come back with a triangle; walks of 1, 2-3, 4-6, more node visits */
       if (wbest >= (int)S.n_sph)
         atomicAdd(&diag_ptr[4 + 18], 1ull);
+      /* parked rays by where they start (inside the bounding ball or not) and whether the walk found a closer triangle */
+      atomicAdd(&diag_ptr[4 + 24 + (origin_inside ? 0 : 2) + (wbest != wbest0 ? 0 : 1)], 1ull);
       if (outside_bound && (wbest != wbest0 || last.idx >= 0))
         atomicAdd(&diag_ptr[4 + 12], 1ull); /* a violation of the conservative probe */
       atomicAdd(&diag_ptr[4 + (visits <= 1u ? 19 : (visits <= 3u ? 20 : (visits <= 6u ? 21 : 22)))], 1ull);
@@ -2227,6 +2244,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   hit.need_dir = false;
   hit.dir_slot = 0;
   hit.dir_scale = 1.0;
+  hit.leaving = false;
   hit.last.idx = -1;
   hit.last.u = 0;
   hit.last.v = 0;
@@ -2278,7 +2296,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         P.rng = (uint64_t)__double_as_longlong(st_f[wave][9][q]);
         hit.min_t = st_f[wave][10][q];
         hit.best = (int)st_u[wave][0][q];
-        const uint32_t dp = st_u[wave][1][q] & 0x7FFFFFFFu; /* bit 31: PT_DIAG's flag */
+        const uint32_t dp = st_u[wave][1][q] & 0x3FFFFFFFu; /* bits 31, 30: PT_DIAG's flags */
         P.depth = (int)(dp >> 6);
         pix_slot = dp & 63u;
         if (CHECKER)
@@ -2350,6 +2368,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         P.Ls = {0, 0, 0};
         P.depth = 0;
         hit.need_dir = false;
+        hit.leaving = false;
         busy = true;
       }
       next_job = min(next_job + (uint32_t)__popcll(idle), made_jobs);
@@ -2374,6 +2393,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       DIAG(0, 1);
       DIAG_LANES(1);
       n_rays++;
+      /* a ray that left a hull facet on its outer side cannot meet a triangle: no probe, no walk (set by the
+       * second half of the previous step; the first half does not touch it) */
+      const bool no_mesh = hit.leaving && !(CHECKER && S.stale_uv);
       (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
       const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
 #ifdef PT_DIAG
@@ -2382,9 +2404,16 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
                                             (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound,
                                             (L.diag_flags & 1u) ? &diag_in_sphere : nullptr);
+      if (no_mesh)
+      { /* walked all the same under RT_HIP_DIAG_WALK_REJECTED=1, and counted as a violation if it finds a triangle */
+        diag_in_sphere = false;
+        want_walk = want_walk && (L.diag_flags & 1u) != 0u;
+        DIAG_LANES(28);
+      }
 #else
-      want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
-                                            (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound);
+      want_walk = hit.depth_ok && !no_mesh &&
+                  bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d, (CHECKER && S.stale_uv) ? S.t_start : hit.min_t,
+                            S.mesh_bound);
 #endif
     }
     /* ---- rays that can reach the mesh are parked; their lanes are idle from here on ---- */
@@ -2406,7 +2435,11 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           ring_st(ring, 10u, e, hit.min_t);
           ring_stu(ring, 0u, e, (uint32_t)hit.best);
 #ifdef PT_DIAG
-          ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot | (diag_in_sphere ? 0u : 0x80000000u));
+          const double diag_lx = (double)S.mesh_bound.cx - P.o.x, diag_ly = (double)S.mesh_bound.cy - P.o.y,
+                       diag_lz = (double)S.mesh_bound.cz - P.o.z; /* bit 30: the ray starts inside the bounding ball */
+          const bool diag_origin_inside = diag_lx * diag_lx + diag_ly * diag_ly + diag_lz * diag_lz <= (double)S.mesh_bound.r2_hi;
+          ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot | (diag_in_sphere ? 0u : 0x80000000u) |
+                                    (diag_origin_inside ? 0x40000000u : 0u));
           if (diag_in_sphere)
             DIAG_LANES(23);
 #else
@@ -2449,7 +2482,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       }
       if (!again)
       {
-        const double *m = S.mat + PT_MAT_STRIDE * hit.dir_slot;
+        const double *m = S.mat + PT_MAT_STRIDE * (hit.dir_slot & ~PT_HULL_PLUS);
         V3 albedo = ld3(m + 1);
         if (CHECKER)
           albedo = v_scale(albedo, hit.dir_scale);
@@ -2458,6 +2491,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         P.d = hemisphere_from_sample(q, len2, n, weight);
         P.T = v_mul(P.T, v_scale(albedo, weight));
         hit.need_dir = false;
+        hit.leaving = (hit.dir_slot & PT_HULL_PLUS) != 0u && weight > S.hull_margin; /* weight = the new direction . n */
       }
     }
     if (busy)
@@ -2895,6 +2929,66 @@ extern "C" __global__ __launch_bounds__(256) void pt_build_bvh(const double *bvh
   }
 }
 
+/* HULL FACETS (scene creation, once): triangle F is one if every corner p of every triangle of the scene has
+ * m . (p - v0_F) <= tau for m = +n_F (PT_HULL_PLUS: the stored normal points outward) or m = -n_F (PT_HULL_MINUS).
+ * What it buys (render_tiles_queued): a ray that starts at a hit point on F -- within delta of F's plane -- with
+ * m . d > mu has m . (o + t d - v0) >= t mu - delta, so it can meet a triangle point only at t <= (tau + delta) / mu;
+ * the launch picks mu so that this is below EPSILON / 4 (rt_hip_shim.hip, hull_margin_for), where intersect_triangle
+ * rejects the hit (t > EPSILON, raytracer.c:150): the ray cannot hit any triangle, whatever the mesh looks like
+ * elsewhere.  Every facet of a convex mesh is one; of config 5's bounces off the mesh 42 % of all hierarchy walks
+ * were such rays, each ~15 node visits to find nothing (PT_DIAG counters, profiles/).  One thread per triangle over
+ * all 3 n corners: quadratic, so only up to PT_HULL_MAX_TRIS triangles (3 x 10^8 plane tests for config 5: ~1 ms). */
+extern "C" __global__ __launch_bounds__(256) void pt_build_hull_flags(const double *__restrict__ tri_geom,
+                                                                      const double *__restrict__ tri_normal, uint32_t n_tri,
+                                                                      double tau, uint32_t *tri_object)
+{
+  __shared__ double corner[3 * 256][3];
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = f < n_tri;
+  const double *g = tri_geom + 9 * (size_t)(live ? f : 0u);
+  const double *nn = tri_normal + 3 * (size_t)(live ? f : 0u);
+  const double nx = nn[0], ny = nn[1], nz = nn[2], vx = g[0], vy = g[1], vz = g[2];
+  double smax = -1.7976931348623157e308, smin = 1.7976931348623157e308;
+  bool bad = !(nx == nx) || !(ny == ny) || !(nz == nz); /* a degenerate triangle has no plane */
+  {
+    /* shape: the bound on how far a computed hit point lies from F's plane grows with |e1||e2| / |e1 x e2| (the
+     * rounding of intersect_triangle's t; derivation at hull_margin_for): facets sharper than 1/16 go without a flag */
+    const double cx = g[4] * g[8] - g[5] * g[7], cy = g[5] * g[6] - g[3] * g[8], cz = g[3] * g[7] - g[4] * g[6];
+    const double e1 = g[3] * g[3] + g[4] * g[4] + g[5] * g[5], e2 = g[6] * g[6] + g[7] * g[7] + g[8] * g[8];
+    bad |= !((cx * cx + cy * cy + cz * cz) * 256.0 >= e1 * e2) || !(e1 * e2 > 0.0);
+  }
+  for (uint32_t base = 0; base < n_tri; base += 256)
+  {
+    __syncthreads();
+    const uint32_t t = base + threadIdx.x;
+    if (t < n_tri)
+    {
+      const double *q = tri_geom + 9 * (size_t)t;
+      for (int k = 0; k < 3; k++)
+        for (int a = 0; a < 3; a++)
+          corner[3 * threadIdx.x + k][a] = k == 0 ? q[a] : q[a] + q[3 * k + a]; /* v0, v0 + e1, v0 + e2: as the kernels see it */
+    }
+    __syncthreads();
+    const uint32_t n = 3u * min(256u, n_tri - base);
+    for (uint32_t c = 0; c < n; c++)
+    {
+      const double s = (nx * (corner[c][0] - vx) + ny * (corner[c][1] - vy)) + nz * (corner[c][2] - vz);
+      smax = fmax(smax, s);
+      smin = fmin(smin, s);
+      bad |= !(s == s);
+    }
+  }
+  if (live)
+  {
+    uint32_t bits = 0u;
+    if (!bad && smax <= tau)
+      bits = PT_HULL_PLUS;
+    else if (!bad && smin >= -tau)
+      bits = PT_HULL_MINUS;
+    tri_object[f] = (tri_object[f] & ~(PT_HULL_PLUS | PT_HULL_MINUS)) | bits;
+  }
+}
+
 /* The fp32 triangle table of tri_may_hit32 for one near_R: v0, e1, e2 rounded to nearest, the four
  * thresholds formed in fp64 and rounded up. */
 extern "C" __global__ __launch_bounds__(256) void pt_build_tri32(const double *tri_geom, uint32_t n_tri, double near_R,
@@ -3056,6 +3150,16 @@ const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int va
 /* The camera-dependent tables of a scene for one near_R (two ~2 us kernels): the packed-fp32
  * filter table and the fp32 hierarchy nodes.  The shim keeps them per (scene, near_R) and builds
  * them once (rt_hip_shim.hip, TableSet), never while a render that reads them can be in flight. */
+hipError_t pt_launch_build_hull_flags(const double *tri_geom, const double *tri_normal, uint32_t n_tri, double tau,
+                                      uint32_t *tri_object, hipStream_t stream)
+{
+  if (n_tri == 0 || n_tri > PT_HULL_MAX_TRIS)
+    return hipSuccess;
+  hipLaunchKernelGGL(pt_build_hull_flags, dim3((n_tri + 255u) / 256u), dim3(256), 0, stream, tri_geom, tri_normal, n_tri, tau,
+                     tri_object);
+  return hipGetLastError();
+}
+
 hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream)
 {
   const uint32_t n_nodes = scene.n_bvh_nodes;

@@ -63,6 +63,7 @@ struct RtHipScene
   double max_center = 0; /* max |centre| over the spheres (rounded up) */
   /* bounding sphere of every triangle (bvh_probe): centre, radius, |centre| -- radius < 0: no triangles */
   double mesh_c[3] = {0, 0, 0}, mesh_R = -1, mesh_c_norm = 0;
+  bool hull_flags = false; /* tri_object carries PT_HULL_PLUS / PT_HULL_MINUS (pt_build_hull_flags ran) */
 };
 
 namespace
@@ -736,6 +737,24 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.tri_normal = reinterpret_cast<const double *>(base + off_tnorm);
   sc->view.tri_tex = reinterpret_cast<const double *>(base + off_ttex);
   sc->view.tri_object = reinterpret_cast<const uint32_t *>(base + off_tobj);
+  if (n_tri != 0 && n_tri <= PT_HULL_MAX_TRIS && mesh_R >= 0 && mesh_R < 1e150)
+  {
+    /* hull facets (pt_build_hull_flags): tau = 2^-43 x the triangles' extent -- 64 u sigma_max extent with u = 2^-53
+     * and the shape limit sigma_max = 16, well above the residual of a facet's own corners and of coplanar
+     * neighbours (~u sigma extent) */
+    const double extent = sc->mesh_c_norm + mesh_R;
+    hipError_t he = pt_launch_build_hull_flags(sc->view.tri_geom, sc->view.tri_normal, (uint32_t)n_tri,
+                                               1.1368683772161603e-13 * extent, reinterpret_cast<uint32_t *>(base + off_tobj), nullptr);
+    if (he == hipSuccess)
+      he = hipDeviceSynchronize();
+    if (he != hipSuccess)
+    {
+      (void)hipFree(sc->blob);
+      delete sc;
+      return fail(RT_HIP_ERUNTIME, "hull flags: %s", hipGetErrorString(he));
+    }
+    sc->hull_flags = true;
+  }
   sc->view.n_spheres = (uint32_t)n_spheres;
   sc->view.n_meshes = (uint32_t)n_meshes;
   sc->view.n_triangles = (uint32_t)n_tri;
@@ -785,6 +804,25 @@ size_t rt_hip_scene_primitives(const RtHipScene *scene)
   return scene ? (size_t)scene->view.n_spheres + scene->view.n_triangles : 0;
 }
 
+int rt_hip_scene_hull_facets(const RtHipScene *scene, uint32_t *n_plus, uint32_t *n_minus)
+{
+  if (!scene || !n_plus || !n_minus)
+    return fail(RT_HIP_EINVAL, "rt_hip_scene_hull_facets: null argument");
+  *n_plus = *n_minus = 0;
+  const size_t n = scene->view.n_triangles;
+  if (n == 0 || !scene->hull_flags)
+    return 0;
+  std::vector<uint32_t> obj(n);
+  HIP_TRY(hipSetDevice(scene->device));
+  HIP_TRY(hipMemcpy(obj.data(), scene->view.tri_object, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; i++)
+  {
+    *n_plus += (obj[i] & PT_HULL_PLUS) ? 1u : 0u;
+    *n_minus += (obj[i] & PT_HULL_MINUS) ? 1u : 0u;
+  }
+  return 0;
+}
+
 const char *rt_hip_kernel_name(const RtHipScene *scene, uint32_t integrator)
 {
   return scene ? pt_kernel_name(scene->view, integrator, kernel_variant()) : "";
@@ -829,6 +867,26 @@ static void mesh_bound_for(const RtHipScene *scene, double near_R, float out[5])
     out[a] = (float)scene->mesh_c[a];
   out[3] = (float)((scene->mesh_R * scene->mesh_R + 32.0 * e * A * A) * (1.0 + 8.0 * e));
   out[4] = -(float)((scene->mesh_R + 10.0 * e * A) * (1.0 + 4.0 * e));
+}
+
+/* How far on the outer side of a hull facet F (pt_build_hull_flags) a ray must point, mu < m . d, to be certain
+ * not to meet a triangle.  With u = 2^-53, sigma = |e1||e2| / |e1 x e2| <= 16 (the flag's shape limit), D >= |o - v0|
+ * and the hit distance (3 (near_R + extent) covers both):
+ *   - the computed hit point on F lies within delta of F's plane: N . (o + t d - v0) = e2 . q - t a exactly (N = e1 x e2,
+ *     q = s x e1, a = e1 . (d x e2): intersect_triangle's own quantities), which vanishes for the exact t; the computed
+ *     t carries 6 u (|s| + t) |e1||e2| / |N| + 3 u |s| of plane distance, the point's own three roundings 6 u D more:
+ *     delta <= 26 u sigma D <= 1.4e-13 (near_R + extent);
+ *   - every triangle point p has m . (p - v0) <= tau = 2^-43 extent;
+ *   - so a hit needs t <= (tau + delta) / mu, and mu = 4 (tau + delta) / EPSILON puts that at EPSILON / 4, where the
+ *     exact test (t > EPSILON, raytracer.c:150) rejects it, its own rounding of t (relative ~1e-12) included.
+ * Never below 1e-3; scenes so large that mu reaches 1 simply never skip a walk. */
+static double hull_margin_for(const RtHipScene *scene, double near_R)
+{
+  if (!scene->hull_flags || !(near_R < 1e150))
+    return 2.0; /* no ray has m . d > 2 */
+  const double extent = scene->mesh_c_norm + scene->mesh_R;
+  const double tau = 1.1368683772161603e-13 * extent, delta = 1.4e-13 * (near_R + extent);
+  return std::fmax(1e-3, 4.0 * (tau + delta) / 1e-8);
 }
 
 int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
@@ -895,6 +953,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     L.near_R2 = L.near_R * L.near_R;
     L.filt_shift = 12.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
     mesh_bound_for(scene, L.near_R, L.mesh_bound);
+    L.hull_margin = hull_margin_for(scene, L.near_R);
     {
       const char *flag = getenv("RT_HIP_DIAG_WALK_REJECTED");
       L.diag_flags = (flag && flag[0] == '1') ? 1u : 0u;

@@ -92,6 +92,7 @@ SHIM_SYMBOLS = {
     "rt_hip_scene_destroy": (None, [C.c_void_p]),
     "rt_hip_scene_device": (C.c_int, [C.c_void_p]),
     "rt_hip_scene_primitives": (C.c_size_t, [C.c_void_p]),
+    "rt_hip_scene_hull_facets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_hip_kernel_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "rt_hip_render_tiles": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RtHipParams), C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

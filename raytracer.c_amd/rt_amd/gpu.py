@@ -60,6 +60,12 @@ class GpuScene:
     def kernel_name(self, integrator="path"):
         return self.shim.rt_hip_kernel_name(self.handle, abi.INTEGRATORS[integrator]).decode()
 
+    def hull_facets(self):
+        """(triangles marked as hull facets with the stored normal pointing outward, ... inward)"""
+        plus, minus = C.c_uint32(0), C.c_uint32(0)
+        _check(self.shim.rt_hip_scene_hull_facets(self.handle, C.byref(plus), C.byref(minus)), "rt_hip_scene_hull_facets")
+        return plus.value, minus.value
+
     def suggest_chunks(self, count, samples=None):
         return int(self.shim.rt_hip_suggest_chunks(self.handle, count, samples or self.scene.samples))
 

@@ -1222,3 +1222,63 @@ def test_round_mesh_probe_from_outside_near_and_inside(gpu, pt, cam):
     st = _full(gpu, pt, sc)
     assert st["tests"] == st["casts"] * (4 + 320)
     _full(gpu, pt, sc, integrator="whitted")
+
+
+def _hull_scene(tris, cam=(0, 5, 30), flags=None, extra=(), samples=4, size=(64, 40)):
+    from rt_amd import abi, scene as S
+    meshes = [dict(flags=abi.M_DEFAULT if flags is None else flags, color=(0.8, 0.6, 0.4), triangles=tris)] + list(extra)
+    objs = [dict(flags=abi.M_DEFAULT, radius=1e4, center=(0, -10006.0, 0), color=(0.7, 0.7, 0.7)),
+            dict(flags=abi.M_REFLECTION, radius=3.0, center=(9, -1, 2), color=(1, 1, 1)),
+            dict(flags=abi.M_DEFAULT, radius=6.0, center=(0, 22, 0), color=(1, 1, 1), emission=(4, 4, 4))]
+    return S.custom_scene(objs, size[0], size[1], samples, 8, cam, (0, 0, 0), meshes=meshes)
+
+
+def test_hull_facets_are_marked_and_bounces_off_them_skip_the_walk(gpu, pt):
+    """HULL FACETS (pt_build_hull_flags): every triangle of the scene on the inner side of the facet's plane.  A
+    bounce that leaves one on its outer side is not walked through the hierarchy; images and counters must still
+    equal the oracle's, which tests every triangle for every ray.  Cases: a convex mesh with outward normals (all
+    facets marked '+'), the same wound the other way ('-': diffuse bounces go inward and must be walked), a mirror
+    convex mesh, two convex meshes side by side (only the facets whose plane clears the other mesh stay marked), a
+    convex mesh with needle-shaped facets (not marked: the error bound behind the margin needs a decent shape)."""
+    from rt_amd import abi
+    ico = _icosphere(4.0, (0, 0, 0), 2)
+    flipped = [[a, c, b] for a, b, c in ico]
+    cases = []
+    sc = _hull_scene(ico)
+    cases.append((sc, "convex", lambda p, m: p + m == 320 and (p == 320 or m == 320)))
+    sc2 = _hull_scene(flipped)
+    cases.append((sc2, "convex, wound the other way", lambda p, m: p + m == 320 and (p == 320 or m == 320)))
+    cases.append((_hull_scene(ico, flags=abi.M_REFLECTION), "mirror", lambda p, m: p + m == 320))
+    other = dict(flags=abi.M_DEFAULT, color=(0.3, 0.5, 0.9), triangles=_icosphere(3.0, (8.5, 0, 1), 2))
+    cases.append((_hull_scene(ico, extra=[other]), "two meshes", lambda p, m: 0 < p + m < 640))
+    # a long thin pyramid: four needle facets (apex angle ~0.3 degrees) and a square base
+    apex, h = (0.0, 2.0, 0.0), 0.02
+    base = [(-h, -2.0, -h), (h, -2.0, -h), (h, -2.0, h), (-h, -2.0, h)]
+    needle = [[apex, base[(k + 1) % 4], base[k]] for k in range(4)] + [[base[0], base[1], base[2]], [base[0], base[2], base[3]]]
+    big = dict(flags=abi.M_DEFAULT, color=(0.3, 0.5, 0.9), triangles=ico)  # enough triangles for the hierarchy kernels
+    cases.append((_hull_scene([[tuple(8 + x if i == 0 else x for i, x in enumerate(v)) for v in t] for t in needle], extra=[big]),
+                  "needles", None))
+    signs = []
+    for sc, what, check in cases:
+        gs = gpu.GpuScene(sc)
+        assert gs.kernel_name() == "pt_render_tiles_tri_queued", what
+        p, m = gs.hull_facets()
+        if check is not None:
+            assert check(p, m), (what, p, m)
+        signs.append((p, m))
+        gs.close()
+        _full(gpu, pt, sc)
+        _full(gpu, pt, sc, integrator="whitted")
+    assert signs[0] == signs[1][::-1], "flipping the winding flips the side the stored normal is on"
+    assert signs[0][0] + signs[0][1] == 320
+
+
+def test_hull_facets_config5_and_walk_counts(gpu):
+    """BASELINE configs[4]'s mesh is convex: all of its facets but the needles at the poles are hull facets"""
+    from rt_amd import scene as S
+    sc = S.build_scene(5, 64, 36, 2)
+    gs = gpu.GpuScene(sc)
+    p, m = gs.hull_facets()
+    assert (p == 0 or m == 0) and 9000 <= p + m <= 10240, (p, m)
+    gs.close()
+    sc.free()

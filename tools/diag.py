@@ -10,7 +10,7 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 sc = S.build_scene(cfg, samples=spp)
 gs = G.GpuScene(sc)
-stats = torch.zeros(32, dtype=torch.int64, device="cuda")
+stats = torch.zeros(40, dtype=torch.int64, device="cuda")
 total = G.n_tiles(sc.width, sc.height)
 gs.render_tiles(1666943821, 0, 1, total, stats=stats)
 torch.cuda.synchronize()
@@ -20,7 +20,10 @@ d = st[4:]
 names = ["loop iters (wave)", "loop lanes", "phase2 iters (wave)", "phase2 cands (lane)", "sqrt blocks (wave)", "sqrt lanes",
          "fresh blocks (wave)", "fresh lanes", "hit blocks (wave)", "hit lanes", "reject-loop iters (wave)", "reject-loop lanes", "FILTER VIOLATIONS (must be 0)", "bvh node visits (wave)", "bvh leaf triangle tests (wave)", "bvh node-visit lanes", "bvh leaf pre-tests (wave)", "parked rays", "walked rays returning a triangle",
          "walks of 1 node visit", "walks of 2-3", "walks of 4-6", "walks of 7+",
-         "parked rays inside the triangles' bounding sphere"]
+         "parked rays inside the triangles' bounding sphere",
+         "parked from inside the ball, found a triangle", "parked from inside the ball, found none",
+         "parked from outside the ball, found a triangle", "parked from outside the ball, found none",
+         "rays leaving a hull facet (no probe)"]
 for n, v in zip(names, d):
     print(f"{n:28s} {v:15d}")
 assert d[12] == 0, 'the conservative filter dropped a sphere the exact test accepts'
