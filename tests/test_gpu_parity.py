@@ -1282,3 +1282,22 @@ def test_hull_facets_config5_and_walk_counts(gpu):
     assert (p == 0 or m == 0) and 9000 <= p + m <= 10240, (p, m)
     gs.close()
     sc.free()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_hull_fuzz_random_convex_meshes(gpu, pt, seed):
+    """random convex polyhedra (scipy's hull of random points on an ellipsoid: ~400 facets of every shape), each
+    facet wound at random (stored normals point in or out per facet), placed near or hundreds of units from the
+    origin (the margin grows with the extent), diffuse or mirror, a second body inside or beside the first on odd
+    seeds (its facets and the outer ones that do not clear it lose their marks): frames and counters equal the oracle's"""
+    from util import convex_body_scene
+    sc, n_outer = convex_body_scene(seed)
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name() == "pt_render_tiles_tri_queued"
+    p, m = gs.hull_facets()
+    if seed % 2 == 0:
+        assert p + m >= 0.8 * n_outer and p > 0 and m > 0, (p, m, n_outer)  # needles aside, every facet; both windings
+    else:
+        assert p + m < sc.n_triangles
+    gs.close()
+    _full(gpu, pt, sc)

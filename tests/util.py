@@ -169,3 +169,36 @@ def decode_png_rgb8(path):
         out[y] = cur
         prev = cur
     return out.reshape(h, w, 3)
+
+
+def convex_body_scene(seed, width=56, height=36, samples=4):
+    """-> (scene, facets of the outer body): a random convex polyhedron (scipy's hull of 210 random points on an
+    ellipsoid: ~400 facets of every shape), each facet wound at random, near or far from the origin, diffuse or mirror;
+    on odd seeds a second body inside or beside it"""
+    from scipy.spatial import ConvexHull
+    from rt_amd import abi, scene as S
+    rng = np.random.default_rng(1000 + seed)
+
+    def body(n, radii, centre):
+        p = rng.normal(size=(n, 3))
+        p /= np.linalg.norm(p, axis=1)[:, None]
+        p = p * np.asarray(radii) + np.asarray(centre)
+        tris = []
+        for a, b, c in ConvexHull(p).simplices:
+            t = [tuple(p[a]), tuple(p[b]), tuple(p[c])]
+            if rng.random() < 0.5:
+                t = [t[0], t[2], t[1]]
+            tris.append(t)
+        return tris
+    centres = [(0, 0, 0), (300, 100, -200), (0, 0, 0), (-40, 5, 10), (0, 0, 0), (2000, 0, 0), (0, 0, 0), (7, 1, 3)]
+    centre = np.array(centres[seed % len(centres)], float)
+    tris = body(210, rng.uniform(2, 5, 3), centre)
+    meshes = [dict(flags=abi.M_REFLECTION if seed % 3 == 2 else abi.M_DEFAULT, color=(0.8, 0.6, 0.4), triangles=tris)]
+    if seed % 2:
+        off = np.array([0.5, 0.2, 0.1]) if seed % 4 == 1 else np.array([7.0, 0.5, 1.0])
+        meshes.append(dict(flags=abi.M_DEFAULT, color=(0.3, 0.5, 0.9), triangles=body(40, rng.uniform(0.5, 1.5, 3), centre + off)))
+    objs = [dict(flags=abi.M_DEFAULT, radius=1e4, center=tuple(centre + (0, -10008.0, 0)), color=(0.7, 0.7, 0.7)),
+            dict(flags=abi.M_REFLECTION, radius=3.0, center=tuple(centre + (9, -1, 2)), color=(1, 1, 1)),
+            dict(flags=abi.M_DEFAULT, radius=6.0, center=tuple(centre + (0, 24, 0)), color=(1, 1, 1), emission=(4, 4, 4))]
+    cam = tuple(centre + rng.uniform(-1, 1, 3) * (6, 3, 6) + (0, 4, 22))
+    return S.custom_scene(objs, width, height, samples, 8, cam, tuple(centre), meshes=meshes), len(tris)

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from rt_amd import gpu as G, scene as S
 from test_gpu_parity import _random_scene
-from util import whitted_scene
+from util import whitted_scene, convex_body_scene
 
 assert "diag" in os.environ.get("RT_HIP_SHIM_PATH", ""), "run with the PT_DIAG build"
 os.environ["RT_HIP_DIAG_WALK_REJECTED"] = "1"  # also walk what bvh_probe's bounding sphere rejects, and count any triangle found
@@ -18,6 +18,8 @@ scenes = [("config %d" % c, S.build_scene(c, w, h, spp)) for c, w, h, spp in
 scenes += [("fuzz %d" % k, _random_scene(k, False, 0)) for k in range(40)]
 scenes += [("fuzz mesh %d" % k, _random_scene(k, True, n)) for k, n in zip(range(100, 112), [3, 10, 40, 120, 250, 300, 400, 700, 1000, 60, 500, 2000])]
 scenes += [("whitted scene", whitted_scene())]
+# convex bodies at many samples per pixel: ~1e6 bounces off hull facets each, all walked (RT_HIP_DIAG_WALK_REJECTED)
+scenes += [("convex body %d" % k, convex_body_scene(k, 160, 100, 64)[0]) for k in range(8)]
 worst = 0
 for name, sc in scenes:
     for integrator in ("path", "whitted"):
