@@ -105,6 +105,9 @@ struct PtSceneView
   const double *tri_geom_leaf; /* n_triangles x 9: tri_geom in LEAF order (entry k belongs to triangle bvh_tri[k]), so a leaf's
                                 * triangles are contiguous and their loads do not wait for the index load */
   uint32_t n_spheres, n_meshes, n_triangles, any_checker;
+  /* the triangles' bounding sphere shows a ray no more than their bounding box does on average (pi R^2 against
+   * (ab + bc + ca) / 2): the parked-walk kernel's probe then tests the sphere alone (pt_render_tiles_tri_queued_sph) */
+  uint32_t mesh_round;
   uint32_t any_refract, n_bvh_nodes; /* n_bvh_nodes == 0: the scene has no triangles */
   uint32_t wide_range;               /* a centre or radius beyond 1e17: fp32 sums could overflow */
   uint32_t any_mirror_glass;         /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children per hit */

@@ -348,18 +348,23 @@ struct MeshBound
  * bounding sphere: boxes are loose around anything round (the two half-boxes of a sphere-like mesh show a ray
  * about twice the silhouette of the mesh itself), and every ray let through costs a park / walk / resume cycle
  * of ~15 node visits to find nothing. */
+/* SPHERE_ONLY (pt_render_tiles_tri_queued_sph, scenes whose bounding sphere is at least as tight as the root's
+ * boxes, PtSceneView.mesh_round): the boxes are left to the walk's first visit, which tests them anyway. */
+template <bool SPHERE_ONLY = false>
 __device__ __forceinline__ bool bvh_probe(const float *__restrict__ nodes, uint32_t n_nodes, bool far_origin,
                                           const V3 &o, const V3 &d, double min_t, const MeshBound &mb, bool *in_sphere = nullptr)
 {
   if (n_nodes == 0)
     return false;
-  bool hit0, hit1;
-  float tn0, tn1;
-  uint32_t r0, r1;
-  const BvhRay R = bvh_ray(o, d);
-  bvh_test_children(nodes, 0u, R, far_origin, __double2float_ru(min_t), hit0, hit1, tn0, tn1, r0, r1);
+  bool hit0 = true, hit1 = true;
+  if (!SPHERE_ONLY)
+  {
+    float tn0, tn1;
+    uint32_t r0, r1;
+    bvh_test_children(nodes, 0u, bvh_ray(o, d), far_origin, __double2float_ru(min_t), hit0, hit1, tn0, tn1, r0, r1);
+  }
   const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
-  const float lx = mb.cx - R.ox.x, ly = mb.cy - R.oy.x, lz = mb.cz - R.oz.x;
+  const float lx = mb.cx - (float)o.x, ly = mb.cy - (float)o.y, lz = mb.cz - (float)o.z;
   const float tca = __builtin_fmaf(lz, dz, __builtin_fmaf(ly, dy, lx * dx));
   const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
   const float d2 = __builtin_fmaf(-tca, tca, ll);
@@ -2159,7 +2164,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* results in L2 before anyone resumes them */
 }
 
-template <bool CHECKER>
+template <bool CHECKER, bool SPHERE_PROBE = false>
 __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 {
   constexpr bool TRIS = true, FILT_LDS = false;
@@ -2401,9 +2406,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 #ifdef PT_DIAG
       /* RT_HIP_DIAG_WALK_REJECTED=1: rays the bounding sphere rejects are parked and walked all the same, and any
        * that comes back with a triangle counts as a violation; otherwise the build parks what the shipped one parks */
-      want_walk = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
-                                            (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound,
-                                            (L.diag_flags & 1u) ? &diag_in_sphere : nullptr);
+      want_walk = hit.depth_ok && bvh_probe<SPHERE_PROBE>(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
+                                                          (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound,
+                                                          (L.diag_flags & 1u) ? &diag_in_sphere : nullptr);
       if (no_mesh)
       { /* walked all the same under RT_HIP_DIAG_WALK_REJECTED=1, and counted as a violation if it finds a triangle */
         diag_in_sphere = false;
@@ -2412,8 +2417,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       }
 #else
       want_walk = hit.depth_ok && !no_mesh &&
-                  bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d, (CHECKER && S.stale_uv) ? S.t_start : hit.min_t,
-                            S.mesh_bound);
+                  bvh_probe<SPHERE_PROBE>(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
+                                          (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound);
 #endif
     }
     /* ---- rays that can reach the mesh are parked; their lanes are idle from here on ---- */
@@ -2603,6 +2608,11 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED) void pt_r
 extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_tri_queued_chk(const PtLaunch L)
 {
   render_tiles_queued<true>(L);
+}
+/* round meshes: the probe is the triangles' bounding sphere alone (bvh_probe) */
+extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED) void pt_render_tiles_tri_queued_sph(const PtLaunch L)
+{
+  render_tiles_queued<false, true>(L);
 }
 PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK), true, false, true)
 PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK), true, false, false)
@@ -3114,13 +3124,13 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
  * pt_launch_render, also reported by rt_hip_kernel_name for profiles and bench lines) */
 static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name)
 {
-  static const char *const names[21] = {
+  static const char *const names[22] = {
       "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
       "pt_render_tiles_chk",  "pt_render_tiles_big_chk",  "pt_render_tiles_tri_chk",  "pt_render_tiles_tri_big_chk",
       "pt_render_tiles_refr", "pt_render_tiles_big_refr", "pt_render_tiles_tri_refr", "pt_render_tiles_tri_big_refr",
       "pt_render_tiles_v0",   "pt_whitted_tiles",         "pt_whitted_tiles_big",     "pt_whitted_tiles_tri",
       "pt_whitted_tiles_tri_big", "pt_render_tiles_mem",  "pt_whitted_tiles_mem",
-      "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk"};
+      "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk", "pt_render_tiles_tri_queued_sph"};
   const bool tris = scene.n_triangles != 0;
   const bool big = !pt_filter_in_lds(scene);
   const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
@@ -3133,7 +3143,7 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
   else if (variant == 0 && !refr && !cast_ray)
     which = 12;
   else if ((which == 3 || which == 7) && variant != 2 && !scene.wide_range)
-    which = which == 3 ? 19 : 20; /* hierarchy scenes: parked walks (variant 2, and scenes beyond fp32's comfortable range,
+    which = which == 3 ? (scene.mesh_round ? 21 : 19) : 20; /* hierarchy scenes: parked walks (variant 2, and scenes beyond fp32's comfortable range,
                                    * whose filter needs the NaN-safe compares, keep the lane-waiting pooled kernels) */
   if (name)
     *name = names[which];
@@ -3191,18 +3201,18 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }();
   size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[21] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
+  static const Kernel family[22] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
                                     pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr,
                                     pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
                                     pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem,
-                                    pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk};
+                                    pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph};
   const int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr);
   const Kernel kernel = family[which];
   if (which >= 19) /* the spheres' filter pairs, then per-lane traversal stacks sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
                  (size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * sizeof(uint32_t);
-  static size_t lds_allowed[21] = {0}; /* raised once per process if a scene needs > 64 KiB */
+  static size_t lds_allowed[22] = {0}; /* raised once per process if a scene needs > 64 KiB */
   size_t &allowed = lds_allowed[which];
   if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
   {

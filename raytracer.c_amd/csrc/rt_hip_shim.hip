@@ -601,6 +601,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
    * their bounds, radius = the farthest corner, with slack for the roundings of e1, e2 and of the exact test's
    * own barycentric limits ---- */
   double mesh_c[3] = {0, 0, 0}, mesh_R = -1;
+  bool mesh_round = false; /* the sphere's silhouette is no larger than the mean silhouette of the triangles' box */
   if (n_tri != 0)
   {
     double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
@@ -634,6 +635,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     mesh_R = std::sqrt(r2) * (1.0 + 1e-9) + 1e-300;
     if (!(mesh_R < HUGE_VAL)) /* non-finite input: a bound that keeps every ray */
       mesh_R = HUGE_VAL;
+    const double a = hi[0] - lo[0], b = hi[1] - lo[1], c = hi[2] - lo[2];
+    mesh_round = 3.14159265358979 * mesh_R * mesh_R <= 0.5 * (a * b + b * c + c * a); /* false for NaN / inf */
   }
 
   /* ---- hierarchy over the triangles ---- */
@@ -759,6 +762,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.n_meshes = (uint32_t)n_meshes;
   sc->view.n_triangles = (uint32_t)n_tri;
   sc->view.any_checker = any_checker ? 1u : 0u;
+  sc->view.mesh_round = mesh_round ? 1u : 0u;
   sc->view.any_refract = any_refract ? 1u : 0u;
   sc->view.wide_range = wide_range ? 1u : 0u;
   sc->max_center = max_center;

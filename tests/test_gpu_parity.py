@@ -726,7 +726,7 @@ def test_bench_host_path_and_config_array(gpu):
     d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
     got = {c["config"]: c for c in d["configs"]}
     assert set(got) == {2, 3, 4, 5} or set(got) == {2, 3, 5}
-    assert got[3]["kernel"] == "pt_render_tiles_tri" and got[5]["kernel"] == "pt_render_tiles_tri_queued"
+    assert got[3]["kernel"] == "pt_render_tiles_tri" and got[5]["kernel"] == "pt_render_tiles_tri_queued_sph"
     assert all("error" not in c and c["kernel_ms"] > 0 and c["ray_bounces_per_s"] > 0 for c in got.values())
 
 
@@ -1053,7 +1053,7 @@ def test_hierarchy_kernel_without_its_workspace(gpu, pt):
     os.environ["RT_HIP_NO_PARK_WS"] = "1"
     try:
         gs = gpu.GpuScene(sc)
-        assert gs.kernel_name() == "pt_render_tiles_tri_queued"
+        assert gs.kernel_name() == "pt_render_tiles_tri_queued_sph"  # config 5's mesh is round: the probe is its bounding sphere
         img, img8, st = gs.render_image(SEED)
     finally:
         del os.environ["RT_HIP_NO_PARK_WS"]
@@ -1117,7 +1117,7 @@ def test_mesh_only_scene_without_spheres(gpu, pt, n_tris):
               dict(flags=abi.M_DEFAULT, color=(1, 1, 1), emission=(3, 3, 3), triangles=floor)]
     sc = S.custom_scene([], 48, 32, 4, 4, (0, 2, 25), (0, 0, 0), meshes=meshes)
     gs = gpu.GpuScene(sc)
-    assert gs.kernel_name() == ("pt_render_tiles_tri" if n_tris < 250 else "pt_render_tiles_tri_queued")
+    assert gs.kernel_name() == ("pt_render_tiles_tri" if n_tris < 250 else "pt_render_tiles_tri_queued")  # a soup is not round
     gs.close()
     st = _full(gpu, pt, sc)
     assert st["tests"] == st["casts"] * (n_tris + 1) and st["casts"] > 48 * 32 * 4
@@ -1217,7 +1217,7 @@ def test_round_mesh_probe_from_outside_near_and_inside(gpu, pt, cam):
     sc = S.custom_scene(objs, 64, 40, 4, 6, cam, (0, 0, 0) if cam != (0.3, 0.2, 0.1) else (5, 1, 5), meshes=meshes)
     assert sc.n_triangles == 320
     gs = gpu.GpuScene(sc)
-    assert gs.kernel_name() == "pt_render_tiles_tri_queued"
+    assert gs.kernel_name() == "pt_render_tiles_tri_queued_sph"
     gs.close()
     st = _full(gpu, pt, sc)
     assert st["tests"] == st["casts"] * (4 + 320)
@@ -1261,7 +1261,7 @@ def test_hull_facets_are_marked_and_bounces_off_them_skip_the_walk(gpu, pt):
     signs = []
     for sc, what, check in cases:
         gs = gpu.GpuScene(sc)
-        assert gs.kernel_name() == "pt_render_tiles_tri_queued", what
+        assert gs.kernel_name().startswith("pt_render_tiles_tri_queued"), what
         p, m = gs.hull_facets()
         if check is not None:
             assert check(p, m), (what, p, m)
@@ -1293,7 +1293,7 @@ def test_hull_fuzz_random_convex_meshes(gpu, pt, seed):
     from util import convex_body_scene
     sc, n_outer = convex_body_scene(seed)
     gs = gpu.GpuScene(sc)
-    assert gs.kernel_name() == "pt_render_tiles_tri_queued"
+    assert gs.kernel_name().startswith("pt_render_tiles_tri_queued")
     p, m = gs.hull_facets()
     if seed % 2 == 0:
         assert p + m >= 0.8 * n_outer and p > 0 and m > 0, (p, m, n_outer)  # needles aside, every facet; both windings
