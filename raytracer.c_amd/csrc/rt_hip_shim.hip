@@ -817,7 +817,8 @@ int rt_hip_scene_hull_facets(const RtHipScene *scene, uint32_t *n_plus, uint32_t
   if (n == 0 || !scene->hull_flags)
     return 0;
   std::vector<uint32_t> obj(n);
-  HIP_TRY(hipSetDevice(scene->device));
+  DeviceScope on(scene->device);
+  HIP_TRY(on.status);
   HIP_TRY(hipMemcpy(obj.data(), scene->view.tri_object, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; i++)
   {
