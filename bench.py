@@ -307,7 +307,8 @@ def main():
     ap.add_argument("--cpu-tiles", type=int, default=2048, help="8x8 tiles of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the CPU baseline (0 = the CPUs this process may use)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration array")
-    ap.add_argument("--c5-spp", type=int, default=256, help="spp of config 5 in the per-configuration array (its own: 4096)")
+    ap.add_argument("--c5-spp", type=int, default=0,
+                    help="spp of config 5 in the per-configuration array (0 = its own 4096: ~4 s a frame on one GPU)")
     ap.add_argument("--host-path", action="store_true",
                     help="single process: time rt_hip_render_image() over --gpus devices (the C host's path) and exit")
     args = ap.parse_args()
@@ -480,7 +481,8 @@ def main():
                 if cfg == args.config:
                     continue
                 try:
-                    lines.append(config_line(cfg, cspp, 3, dev))
+                    # config 5 at its own 4096 spp is ~4 s a frame: one warm-up frame + one timed
+                    lines.append(config_line(cfg, cspp, 1 if cfg == 5 and cspp in (0, 4096) else 3, dev))
                 except Exception as exc:
                     lines.append({"config": cfg, "error": repr(exc)})
             out["configs"] = lines
