@@ -841,6 +841,33 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       for (int off = 32; off > 0; off >>= 1)
         tot += (uint32_t)__shfl_xor((int)tot, off);
       DIAG(3, tot);                /* lane-level candidates */
+      if (!TRIS)
+      { /* what pruning the wall-sized spheres (r > 1000) among themselves could reach: iterations if every lane
+         * kept one wall, the lanes' other candidates, the walls alone */
+        uint32_t walls = 0, others = 0, lo = cand_lo, hi = cand_hi;
+        while (lo | hi)
+        {
+          const bool in_lo = lo != 0;
+          const uint32_t word = in_lo ? lo : hi;
+          const uint32_t k = (uint32_t)__builtin_ctz(word) + (in_lo ? 0u : 32u);
+          lo = in_lo ? (word & (word - 1u)) : 0u;
+          hi = in_lo ? hi : (word & (word - 1u));
+          const bool wall = geom[PT_GEOM_STRIDE * (base + k) + 3] > 1e6;
+          walls += wall ? 1u : 0u;
+          others += wall ? 0u : 1u;
+        }
+        DIAG(29, wave_max_u32(min(walls, 1u) + others));
+        DIAG(30, wave_max_u32(others));
+        DIAG(31, wave_max_u32(walls));
+        uint32_t tw = walls, to = others;
+        for (int off = 32; off > 0; off >>= 1)
+        {
+          tw += (uint32_t)__shfl_xor((int)tw, off);
+          to += (uint32_t)__shfl_xor((int)to, off);
+        }
+        DIAG(32, tw);
+        DIAG(33, to);
+      }
     }
 #endif
     /* ---- phase 2: the exact test on each lane's own candidates, in index order: spheres ... ---- */
