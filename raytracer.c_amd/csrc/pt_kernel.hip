@@ -496,7 +496,7 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
     }
     if (done)
       break;
-    const uint32_t first = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
+    const uint32_t first = (ref & ~PT_BVH_LEAF_FLAG) >> PT_BVH_COUNT_BITS, count = ref & ((1u << PT_BVH_COUNT_BITS) - 1u);
     uint32_t keep = leaf_pretest(tri32_leaf, first, count, far_origin, R, d, diag_ptr);
     while (keep != 0u)
     {
@@ -2126,7 +2126,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
     }
     else if (at_leaf)
     {
-      const uint32_t first_tri = (ref & ~PT_BVH_LEAF_FLAG) >> 3, count = ref & 7u;
+      const uint32_t first_tri = (ref & ~PT_BVH_LEAF_FLAG) >> PT_BVH_COUNT_BITS, count = ref & ((1u << PT_BVH_COUNT_BITS) - 1u);
       uint32_t keep = leaf_pretest(S.tri32, first_tri, count, far_origin, R, wd, diag_ptr);
 #ifdef PT_DIAG
       for (uint32_t k = 0; k < count; k++) /* re-check: a dropped triangle must fail the exact test */

@@ -255,7 +255,7 @@ struct BvhBuild
         ch[k] = std::fmax(ch[k], cen[3 * t + k]);
       }
     if (end - begin <= PT_BVH_LEAF)
-      return PT_BVH_LEAF_FLAG | (begin << 3) | (end - begin);
+      return PT_BVH_LEAF_FLAG | (begin << PT_BVH_COUNT_BITS) | (end - begin);
     const uint32_t me = (uint32_t)(nodes.size() / PT_BVH_SRC_DOUBLES);
     nodes.resize(nodes.size() + PT_BVH_SRC_DOUBLES, 0.0);
     depth = std::max(depth, level + 1);
