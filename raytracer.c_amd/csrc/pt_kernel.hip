@@ -1235,6 +1235,12 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         slot = S.tri_object[ti];
         hull = slot & (PT_HULL_PLUS | PT_HULL_MINUS);
         slot &= ~(PT_HULL_PLUS | PT_HULL_MINUS);
+        /* the margin's error bound (hull_margin_for) assumes the ray that found this facet travelled no farther
+         * than 2 near_R (its origin is then within 1.0001 x that + the facet's size of v0): a hit from farther away
+         * -- a bounce off a far point of a wall-sized sphere -- lands less precisely on the plane.  (near_R^2 is
+         * in SGPRs already; this kernel has none to spare for a constant of its own.) */
+        if (TRIS && (MODE != 0 || DEFER_DIR) && !(min_t * min_t <= 4.0 * S.near_R2))
+          hull = 0u;
       }
       const double *m = S.mat + PT_MAT_STRIDE * slot;
       const double prob = m[0];

@@ -884,7 +884,9 @@ static void mesh_bound_for(const RtHipScene *scene, double near_R, float out[5])
  *   - every triangle point p has m . (p - v0) <= tau = 2^-43 extent;
  *   - so a hit needs t <= (tau + delta) / mu, and mu = 4 (tau + delta) / EPSILON puts that at EPSILON / 4, where the
  *     exact test (t > EPSILON, raytracer.c:150) rejects it, its own rounding of t (relative ~1e-12) included.
- * Never below 1e-3; scenes so large that mu reaches 1 simply never skip a walk. */
+ * Never below 1e-3; scenes so large that mu reaches 1 simply never skip a walk.  D holds for rays whose hit
+ * distance is at most 2 near_R: then |o - v0| <= 1.0001 x that + the facet's size as well; trace_step drops the
+ * facet's mark for any other (a bounce that came in from a far point of a wall-sized sphere, say). */
 static double hull_margin_for(const RtHipScene *scene, double near_R)
 {
   if (!scene->hull_flags || !(near_R < 1e150))
