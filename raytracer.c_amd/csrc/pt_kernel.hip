@@ -1065,6 +1065,46 @@ __device__ __forceinline__ CameraRegs load_camera(const PtLaunch &L)
   return c;
 }
 
+/* The pooled kernels keep the camera in LDS instead: as kernel arguments its 16 doubles sit in 32 of the wave's
+ * ~100 SGPRs for the whole trip loop although only the camera-sample batch (once per 64 jobs) reads them, and the
+ * kernels are at the SGPR limit -- what does not fit is spilled to VGPR lanes and read back with v_readlane, a
+ * VALU slot each, in loops that are bound by VALU issue.  camera_to_lds: once per workgroup, before a barrier. */
+#define PT_CAM_LDS_DOUBLES 16
+__device__ __forceinline__ void camera_to_lds(const PtLaunch &L, double *cam_lds)
+{
+  if (threadIdx.x < 12)
+    cam_lds[threadIdx.x] = (&L.cam.pos[0])[threadIdx.x]; /* pos, horizontal, vertical, llc: contiguous (PtCamera) */
+  else if (threadIdx.x < PT_CAM_LDS_DOUBLES)
+    cam_lds[threadIdx.x] = threadIdx.x == 12 ? L.w_minus_1 : (threadIdx.x == 13 ? L.h_minus_1 : (threadIdx.x == 14 ? L.inv_w_minus_1 : L.inv_h_minus_1));
+}
+/* an index the compiler cannot see through: loads addressed with it stay where they are written (hoisted out of
+ * the trip loop they would occupy vector registers for its whole length instead) */
+__device__ __forceinline__ uint32_t opaque_zero()
+{
+  uint32_t z = 0;
+  asm volatile("" : "+v"(z));
+  return z;
+}
+__device__ __forceinline__ CameraRegs load_camera_lds(const double *cam_lds)
+{
+  const uint32_t z = opaque_zero();
+  CameraRegs c;
+  c.pos = {cam_lds[z + 0], cam_lds[z + 1], cam_lds[z + 2]};
+  c.horizontal = {cam_lds[z + 3], cam_lds[z + 4], cam_lds[z + 5]};
+  c.vertical = {cam_lds[z + 6], cam_lds[z + 7], cam_lds[z + 8]};
+  c.llc = {cam_lds[z + 9], cam_lds[z + 10], cam_lds[z + 11]};
+  c.w_minus_1 = cam_lds[z + 12];
+  c.h_minus_1 = cam_lds[z + 13];
+  c.inv_w_minus_1 = cam_lds[z + 14];
+  c.inv_h_minus_1 = cam_lds[z + 15];
+  return c;
+}
+__device__ __forceinline__ V3 load_camera_pos_lds(const double *cam_lds)
+{
+  const uint32_t z = opaque_zero();
+  return {cam_lds[z + 0], cam_lds[z + 1], cam_lds[z + 2]};
+}
+
 /* a / b, correctly rounded, for a >= 0 and an INTEGER 1 <= b < 2^20, given y = RN(1/b)
  * (formed on the host): q0 = RN(a y); r = a - b q0 (exact: a multiple of ulp(q0) below
  * 2.01 b ulp(q0), so it fits 53 bits); q = RN(q0 + r y).
@@ -1630,6 +1670,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __shared__ float out_f[PT_TILE_PIXELS * 3];
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
+  __shared__ double cam_lds[PT_CAM_LDS_DOUBLES];             /* the camera (camera_to_lds) */
   __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3]; /* fixed-point radiance sums */
   __shared__ unsigned long long pix_nan[3];                  /* per channel: pixels that received a NaN sample */
   __shared__ unsigned long long pix_key[PT_TILE_PIXELS];     /* per-pixel half of the RNG key */
@@ -1651,6 +1692,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     const uint32_t kx = (t0 % L.tiles_x) * PT_TILE + (threadIdx.x & 7u), ky = (t0 / L.tiles_x) * PT_TILE + (threadIdx.x >> 3);
     pix_key[threadIdx.x] = rt_rng_pixel_key(L.seed, ky * (uint32_t)L.width + kx);
   }
+  camera_to_lds(L, cam_lds);
   __syncthreads();
 
   /* ---- this wave's pixels and job pool ---- */
@@ -1669,7 +1711,6 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   const uint32_t s_begin = (uint32_t)(((uint64_t)chunk * spp) / L.sample_chunks);
   const uint32_t s_end = (uint32_t)(((uint64_t)(chunk + 1u) * spp) / L.sample_chunks);
   const uint32_t pool = n_valid * (s_end - s_begin); /* jobs: j -> pixel j % n_valid, sample s_begin + j / n_valid */
-  const CameraRegs cam = load_camera(L);
 
   Path P;
   P.o = {0, 0, 0};
@@ -1743,7 +1784,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
           const uint32_t col = idx - row * vcols;
           const uint32_t slot_in_tile = (2u * wave + row) * PT_TILE + col;
           Path Q;
-          start_sample(Q, cam, pix_key[slot_in_tile], tx0 + col, ty0 + row, s_begin + s);
+          start_sample(Q, load_camera_lds(cam_lds), pix_key[slot_in_tile], tx0 + col, ty0 + row, s_begin + s);
           qd[lane] = Q.d.x;
           qd[64 + lane] = Q.d.y;
           qd[128 + lane] = Q.d.z;
@@ -1759,7 +1800,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       if (!busy && job < made_jobs)
       {
         const uint32_t q = job & 63u; /* batches start at multiples of 64 */
-        P.o = cam.pos;
+        P.o = load_camera_pos_lds(cam_lds);
         P.d = {qd[q], qd[64 + q], qd[128 + q]};
         P.rng = qr[q];
         pix_slot = qp[q];
@@ -2214,6 +2255,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   __shared__ unsigned long long q_rng[PT_BLOCK / 64][64];
   __shared__ uint32_t q_pix[PT_BLOCK / 64][64];
   __shared__ uint32_t park_slot_lds;
+  __shared__ double cam_lds[PT_CAM_LDS_DOUBLES]; /* the camera (camera_to_lds) */
   /* walked rays on their way back into lanes: PT_STAGE at a time are copied from the ring into LDS
    * (one memory round trip for the batch) and handed out from there -- a few idle lanes taking them
    * straight from the ring would put that round trip at the head of every trip */
@@ -2236,6 +2278,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   }
   if (threadIdx.x == 0)
     park_slot_lds = pt_park_acquire(L);
+  camera_to_lds(L, cam_lds);
   __syncthreads();
 
   const uint32_t wave = threadIdx.x >> 6;
@@ -2255,7 +2298,6 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   const uint32_t pool = has_unit ? n_valid * (s_end - s_begin) : 0u;
   unsigned long long *const pix_sum = pix_sum_all[wave];
   unsigned long long *const pix_nan = pix_nan_all[wave];
-  const CameraRegs cam = load_camera(L);
   const uint32_t park_slot = park_slot_lds;
   const bool ring_ok = park_slot != 0xFFFFFFFFu;
   ParkRing ring;
@@ -2381,8 +2423,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           const uint32_t col = idx - row * vcols;
           const uint32_t slot_in_tile = row * PT_TILE + col;
           Path Q;
-          start_sample(Q, cam, rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col), tx0 + col, ty0 + row,
-                       s_begin + s);
+          start_sample(Q, load_camera_lds(cam_lds), rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col),
+                       tx0 + col, ty0 + row, s_begin + s);
           qd[lane] = Q.d.x;
           qd[64 + lane] = Q.d.y;
           qd[128 + lane] = Q.d.z;
@@ -2398,7 +2440,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       if (!busy && job < made_jobs)
       {
         const uint32_t q = job & 63u;
-        P.o = cam.pos;
+        P.o = load_camera_pos_lds(cam_lds);
         P.d = {qd[q], qd[64 + q], qd[128 + q]};
         P.rng = qr[q];
         pix_slot = qp[q];
