@@ -15,11 +15,12 @@ for m in re.finditer(r"\.amdhsa_kernel (\w+)(.*?)\.end_amdhsa_kernel", txt, re.S
     def g(key):
         r = re.search(r"\.amdhsa_%s (\d+)" % key, blk)
         return int(r.group(1)) if r else -1
-    body = re.search(r"^%s:[^\n]*\n(.*?)^\s*s_endpgm" % re.escape(name), txt, re.S | re.M)
+    body = re.search(r"^%s:[^\n]*\n(.*?)^\.Lfunc_end\d+:" % re.escape(name), txt, re.S | re.M)  # the whole function (a kernel may hold several s_endpgm)
     b = body.group(1) if body else ""
     cnt = lambda pat: len(re.findall(pat, b, re.M))
     n_all, n_f64 = cnt(r"^\s+[vsd][_a-z]"), cnt(r"^\s+v_\w+_f64")
     n_pk, n_scr = cnt(r"^\s+v_pk_\w+_f32"), cnt(r"^\s+scratch_")
+    n_lane = cnt(r"^\s+v_(read|write)lane_b32")  # mostly SGPRs spilled to VGPR lanes: a VALU slot each
     print(f"{name:34s} vgpr {g('next_free_vgpr'):4d} sgpr {g('next_free_sgpr'):4d} scratch {g('private_segment_fixed_size'):5d} "
-          f"lds {g('group_segment_fixed_size'):6d} | insts {n_all:6d} f64 {n_f64:5d} pk_f32 {n_pk:4d} scratch_ops {n_scr:4d}")
+          f"lds {g('group_segment_fixed_size'):6d} | insts {n_all:6d} f64 {n_f64:5d} pk_f32 {n_pk:4d} scratch_ops {n_scr:4d} lane_ops {n_lane:4d}")
 PY
