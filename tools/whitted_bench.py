@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo/raytracer.c_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer.c_amd"))
 import torch
 from rt_amd import gpu as G, scene as S
 for cfg, spp in [(4, 64), (3, 64), (5, 8)]:
