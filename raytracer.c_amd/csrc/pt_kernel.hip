@@ -798,6 +798,15 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       if (FILT_LDS && !far_origin)
       {
         /* ---- phase 1b: per-lane fp32 pre-test of the lane's own triangle candidates (tri_may_hit32) ---- */
+#ifdef PT_DIAG
+        DIAG(34, wave_max_u32((uint32_t)(__popc(tri_lo) + __popc(tri_hi)))); /* wave-level pre-test iterations */
+        {
+          uint32_t tot = (uint32_t)(__popc(tri_lo) + __popc(tri_hi));
+          for (int off = 32; off > 0; off >>= 1)
+            tot += (uint32_t)__shfl_xor((int)tot, off);
+          DIAG(35, tot); /* lane-level pre-tests */
+        }
+#endif
         uint32_t keep_lo = 0, keep_hi = 0, w_lo = tri_lo, w_hi = tri_hi;
         while (w_lo | w_hi)
         {
@@ -837,6 +846,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       DIAG(12, violations);
       const uint32_t mine = (uint32_t)(__popc(cand_lo) + __popc(cand_hi) + __popc(tri_lo) + __popc(tri_hi));
       DIAG(2, wave_max_u32((uint32_t)(__popc(cand_lo) + __popc(cand_hi))) + wave_max_u32((uint32_t)(__popc(tri_lo) + __popc(tri_hi)))); /* wave-level phase-2 iterations */
+      DIAG(36, wave_max_u32((uint32_t)(__popc(tri_lo) + __popc(tri_hi)))); /* of them: exact triangle tests */
       uint32_t tot = mine;
       for (int off = 32; off > 0; off >>= 1)
         tot += (uint32_t)__shfl_xor((int)tot, off);

@@ -10,7 +10,7 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 sc = S.build_scene(cfg, samples=spp)
 gs = G.GpuScene(sc)
-stats = torch.zeros(40, dtype=torch.int64, device="cuda")
+stats = torch.zeros(48, dtype=torch.int64, device="cuda")
 total = G.n_tiles(sc.width, sc.height)
 gs.render_tiles(1666943821, 0, 1, total, stats=stats)
 torch.cuda.synchronize()
@@ -24,7 +24,8 @@ names = ["loop iters (wave)", "loop lanes", "phase2 iters (wave)", "phase2 cands
          "parked from inside the ball, found a triangle", "parked from inside the ball, found none",
          "parked from outside the ball, found a triangle", "parked from outside the ball, found none",
          "rays leaving a hull facet (no probe)", "phase-2 iters if each lane kept one wall (wave)", "phase-2 iters of non-wall candidates alone (wave)",
-         "phase-2 iters of wall candidates alone (wave)", "wall candidates (lane)", "non-wall candidates (lane)"]
+         "phase-2 iters of wall candidates alone (wave)", "wall candidates (lane)", "non-wall candidates (lane)", "small-mesh fp32 pre-test iters (wave)",
+         "small-mesh fp32 pre-tests (lane)", "small-mesh exact triangle iters (wave)"]
 for n, v in zip(names, d):
     print(f"{n:28s} {v:15d}")
 assert d[12] == 0, 'the conservative filter dropped a sphere the exact test accepts'
@@ -47,4 +48,7 @@ if d[17]:
 if d[29]:
     print(f"sphere candidates per ray: walls (r > 1000) {d[32] / casts:.2f}, others {d[33] / casts:.2f}; phase-2 iterations per trip: "
           f"now {d[2] / it:.2f}, walls alone {d[31] / it:.2f}, others alone {d[30] / it:.2f}, with one wall per lane {d[29] / it:.2f}")
+if d[34]:
+    print(f"small mesh: fp32 pre-test wave iterations per trip {d[34] / it:.2f} for {d[35] / casts:.2f} bounding-sphere candidates per ray; "
+          f"exact triangle wave iterations per trip {d[36] / it:.2f}, exact sphere {(d[2] - d[36]) / it:.2f}")
 print(f"reject iters per loop iter {d[10] / it:.2f} lanes/64 {d[11] / (64.0 * max(d[10], 1)):.3f}")

@@ -26,7 +26,7 @@ for name, sc in scenes:
         if integrator == "whitted" and sc.max_depth > 32:
             continue
         gs = G.GpuScene(sc)
-        stats = torch.zeros(40, dtype=torch.int64, device="cuda")
+        stats = torch.zeros(48, dtype=torch.int64, device="cuda")
         try:
             gs.render_tiles(1666943821, 0, 1, G.n_tiles(sc.width, sc.height), stats=stats, integrator=integrator)
         except G.ShimError as e:

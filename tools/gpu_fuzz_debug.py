@@ -24,7 +24,7 @@ for k in [int(a) for a in sys.argv[1:]]:
           f"flags {flags} max emission {emax:.3g} radii {rmin:.3g}..{rmax:.3g}")
     gs = G.GpuScene(sc)
     seed = 1666943821 + k
-    stats = torch.zeros(40, dtype=torch.int64, device="cuda")
+    stats = torch.zeros(48, dtype=torch.int64, device="cuda")
     total = G.n_tiles(sc.width, sc.height)
     t, t8, _ = gs.render_tiles(seed, 0, 1, total, stats=stats)
     img, img8 = gs.untile(t, t8, 0, 1, total)
