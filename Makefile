@@ -1,7 +1,7 @@
 # Top-level build.  Everything is built IN-TREE so the binaries travel to the GPU box
 # with the source snapshot (they are git-ignored, not gpurun-ignored).
 #
-#   make            shim + host library + CLI + oracle checkers
+#   make            shim + its PT_DIAG twin + host library + CLI + oracle checkers
 #   make shim       raytracer.c_amd/csrc/librt_hip.so        (hipcc, gfx950 only)
 #   make host       raytracer.c_amd/host/libraytracer_amd.so + raytracer (gcc, C99)
 #   make oracle     oracle/libpt_oracle.so (+ oracle/_ref/*.so when /root/reference exists)
@@ -27,7 +27,7 @@ CLI     := $(HOST)/raytracer
 HOST_SRC := $(HOST)/raytracer_amd.c $(HOST)/scenes.c $(HOST)/obj_load.c $(HOST)/png_out.c
 HOST_HDR := $(INC)/raytracer.h $(INC)/vector.h $(INC)/rt_hip.h $(INC)/rt_rng.h $(HOST)/scenes.h
 
-all: shim host oracle
+all: shim shim-diag host oracle
 
 # oracle/_ref/ref_main_dropin links against the host library: build that first
 oracle: host
@@ -36,7 +36,10 @@ shim: $(SHIM)
 $(SHIM): $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC)/rt_hip.h $(INC)/rt_rng.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl
 
-# diagnostic build: wave-level event counters in stats[4..15] (tools/diag.py); never shipped
+# diagnostic build: wave-level event counters in stats[4..] and the exhaustive re-checks of every conservative rule
+# (filter, fp32 pre-tests, bounding-sphere probe, hull facets).  Not the product: only tests/test_gpu_diag.py
+# (child processes with RT_HIP_SHIM_PATH) and tools/diag*.py load it.  Built by `make all` so that it travels to
+# the GPU box with the snapshot like the other binaries (git-ignored, not gpurun-ignored).
 shim-diag: $(CSRC)/librt_hip_diag.so
 $(CSRC)/librt_hip_diag.so: $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC)/rt_hip.h $(INC)/rt_rng.h
 	$(HIPCC) $(HIPFLAGS) -DPT_DIAG -shared -o $@ $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl

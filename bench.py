@@ -4,7 +4,9 @@ hot path on BASELINE.json configs[3]: 1920x1080, 1024 spp, the reference's 38-sp
 Cornell-box-style room, depth 16.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nproc-per-node N ...
+     bench.py --gpus N ... -- or plain `python bench.py --gpus N`, which starts its own ranks
+     in a child torch.distributed.run, see launch_ranks)
 
 One "step" = one full frame.  With N ranks the frame's 8x8 tiles are interleaved over the
 ranks (rank r renders tiles r, r+N, ...: no data-path collective), then the compact tile
@@ -50,21 +52,37 @@ FLOPS_NOTE = ("algorithmic model flops (SURVEY 8d: 17 per sphere test + 40 per t
               "lane_utilisation for the hardware-true picture")
 
 
-def committed_pmc(config, width, height, spp, world):
-    """The committed PMC summary of this exact configuration (profiles/pmc_c<N>.json, written by
-    tools/summarize_pmc*.py from separate rocprofv3 --pmc passes), or None: PMC counters cannot be
-    collected from inside the benchmark process."""
-    for name in (f"pmc_c{config}.json", "traffic_c4.json" if config == 4 else None):
-        if not name:
-            continue
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if (rec["config"], rec["width"], rec["height"], rec["spp"], rec["n_gpus"]) == (config, width, height, spp, world):
-                rec["file"] = "profiles/" + name
-                return rec
-        except Exception:
-            pass
+def committed_pmc(config, width, height, spp, world, any_spp=False):
+    """The committed PMC summary of this configuration (profiles/pmc_c<N>.json, written by
+    tools/summarize_pmc_cfg.py from separate rocprofv3 --pmc passes), or None: PMC counters cannot be
+    collected from inside the benchmark process.  The record must match the image size and GPU count;
+    spp too unless any_spp (the per-configuration array: config 5's committed pass is at 256 spp while the
+    array runs its own 4096 -- per-ray figures carry over, per-launch bytes are scaled and say so)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", f"pmc_c{config}.json")))
+        if (rec["config"], rec["width"], rec["height"], rec["n_gpus"]) == (config, width, height, world) and \
+                (any_spp or rec["spp"] == spp):
+            rec["file"] = f"profiles/pmc_c{config}.json"
+            return rec
+    except Exception:
+        pass
     return None
+
+
+def pmc_keys(pmc, spp):
+    """hardware-true figures of a configuration's dominant kernel from its committed PMC pass"""
+    if not pmc:
+        return {"valu_busy": None, "lane_utilisation": None, "valu_instr_per_64_bounces": None, "traffic": None,
+                "pmc_source": None}
+    same = pmc["spp"] == spp
+    src = pmc.get("source", pmc["file"])
+    return {"valu_busy": pmc.get("valu_busy"), "lane_utilisation": pmc.get("lane_utilisation"),
+            "valu_instr_per_64_bounces": pmc.get("valu_instr_per_64_bounces"),
+            # HBM bytes per launch; a pass at another spp is scaled by the sample count (ring / table traffic is per ray)
+            "traffic": pmc["traffic_bytes_per_launch"] * (1.0 if same else spp / pmc["spp"]),
+            "pmc_source": f"committed PMC pass {src} (rocprofv3 --pmc, separate passes; FETCH_SIZE doubled per the gfx950 "
+                          "correction)" + ("" if same else f"; from the {pmc['spp']}-spp pass: per-ray figures as measured, "
+                                           f"traffic scaled x{spp / pmc['spp']:g} to this launch's {spp} spp")}
 
 
 def flops_per_ray(n_spheres, n_triangles):
@@ -225,12 +243,17 @@ def config_line(cfg, spp, steps, dev):
             "kernel": gs.kernel_name(), "kernel_ms": ms, "ray_bounces_per_s": casts / (ms * 1e-3),
             "mpixel_samples_per_s": samples / (ms * 1e-3) * 1e-6, "rays_per_sample": rays / max(samples, 1),
             "flops_per_ray_bounce": fr, "frac": casts * fr / (ms * 1e-3) * 1e-12 / PEAK_FP64_TFLOPS}
+    line.update(pmc_keys(committed_pmc(cfg, sc.width, sc.height, sc.samples, 1, any_spp=True), sc.samples))
     nominal = S.scene_info(cfg).samples
     if sc.samples != nominal:
         line["note"] = f"reduced spp: the configuration's own is {nominal}"
     if sc.n_triangles > 256:
+        # the hierarchy skips nearly all of the model's O(N) triangle tests: a model-flops fraction means nothing here
+        line["frac"] = None
         line["note"] = (line.get("note", "") + "; " if "note" in line else "") + \
-            "frac > 1 is expected: the hierarchy legitimately skips most of the model's O(N) triangle tests"
+            ("frac is null: the model counts 40 flops for each of the scene's triangles per ray-bounce and the hierarchy "
+             "legitimately skips almost all of them; judge this kernel by valu_busy / lane_utilisation / "
+             "valu_instr_per_64_bounces / traffic")
     if ms < 0.3:
         line["note"] = (line.get("note", "") + "; " if "note" in line else "") + "launch-bound at this size"
     gs.close()
@@ -291,6 +314,45 @@ def run_host_path_child(args, n, timeout_s=240):
         return {"error": repr(exc)}
 
 
+# ---- `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves ---------
+
+def launch_ranks(n):
+    """Called as plain `python bench.py --gpus N` (N > 1, no RANK in the environment): run the same
+    command line under torch.distributed.run as a CHILD process -- one rank per GPU, rendezvous on
+    127.0.0.1 -- relay rank 0's JSON line and return the child's exit code.  This parent never
+    touches the GPU (replacing a process that has initialised HIP takes the machine down on this
+    pool, so nothing here execs; torch.cuda.device_count() does not initialise it)."""
+    import socket
+    with socket.socket() as s:               # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    try:
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:
+        have = 0
+    if have < n and not rehearse:
+        print(json.dumps({"metric": "ray-bounces/sec", "value": None, "unit": "ray-bounces/s", "n_gpus": n,
+                          "error": f"--gpus {n} but {have} GPU(s) visible on this node (RT_BENCH_REHEARSE=1 runs the "
+                                   f"{n}-rank control flow on one GPU over gloo; its number is not a measurement)"}), flush=True)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)     # stderr passes through
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)      # anything else the ranks printed is not the result line
+    if lines:
+        print(lines[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks printed no JSON line", file=sys.stderr)
+        return 4
+    return proc.returncode
+
+
 # ---- main ------------------------------------------------------------------------------
 
 def main():
@@ -314,6 +376,8 @@ def main():
     args = ap.parse_args()
     if args.host_path:
         return host_path_main(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args.gpus)   # plain `python bench.py --gpus N`: start the ranks ourselves
 
     import torch
     import torch.distributed as dist
@@ -451,7 +515,10 @@ def main():
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_TFLOPS,
                          "flops": FLOPS_NOTE, "flops_per_ray_bounce": fr, "kernel_ms": kern_s * 1e3,
                          "traffic": pmc["traffic_bytes_per_launch"] if pmc else None, "traffic_source": pmc_source,
-                         "valu_busy": pmc.get("valu_busy") if pmc else None,
+                         "valu_busy": min(pmc["valu_busy"], 1.0) if pmc and pmc.get("valu_busy") is not None else None,
+                         "valu_busy_raw": pmc.get("valu_busy_raw", pmc.get("valu_busy")) if pmc else None,
+                         "valu_busy_note": "per-wave quad-cycles over the cycles of the same PMC pass; overlapping waves on a SIMD "
+                                           "can push the raw ratio past 1, so valu_busy is capped at 1 (= VALU issue saturated)",
                          "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
                          "valu_instr_per_64_bounces": pmc.get("valu_instr_per_64_bounces") if pmc else None,
                          "source": pmc_source,

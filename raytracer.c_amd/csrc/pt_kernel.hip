@@ -3297,15 +3297,13 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   if (which >= 19) /* the spheres' filter pairs, then per-lane traversal stacks sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
                  (size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * sizeof(uint32_t);
-  static size_t lds_allowed[22] = {0}; /* raised once per process if a scene needs > 64 KiB */
-  size_t &allowed = lds_allowed[which];
-  if (lds_bytes > 64 * 1024 && lds_bytes > allowed)
-  {
+  if (lds_bytes > 64 * 1024)
+  { /* the attribute belongs to the (kernel, current device) pair: set whenever it is needed -- a process-wide
+     * "already raised" note would skip devices 1..N-1 of the multi-device path (round-2 advisor finding) */
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;
-    allowed = lds_bytes;
   }
   if (launch.sample_chunks > 1)
   {

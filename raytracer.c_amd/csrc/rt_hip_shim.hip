@@ -32,12 +32,16 @@ static_assert(RT_HIP_TILE == PT_TILE && RT_HIP_TILE_PIXELS == PT_TILE_PIXELS, "t
  * the first launch that needs them and immutable afterwards, so launches of one scene with
  * different cameras on different streams or threads never write a table another launch reads;
  * later launches on other streams wait on `built`.  A scene keeps up to RT_TABLE_SETS of them;
- * beyond that the least recently used one is recycled after its last reader (`last_use`) is done. */
+ * beyond that the least recently used one is recycled after every stream that read it (`readers`) is done. */
 struct TableSet
 {
   double near_R = 0;
   float *filt = nullptr, *bvh_nodes = nullptr;
-  hipEvent_t built = nullptr, last_use = nullptr;
+  hipEvent_t built = nullptr;
+  /* one "last read" event PER READER STREAM: a single event re-recorded by whichever launch releases last would
+   * forget the readers on other streams (an event holds only its latest record), and the set could be recycled
+   * under a kernel that still reads it (round-2 advisor finding) */
+  std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
   uint64_t stamp = 0;
   int users = 0;      /* launches between acquire_tables() and release_tables(): not recyclable */
   bool owned = false; /* allocated apart from the scene blob */
@@ -341,10 +345,8 @@ int acquire_tables(const RtHipScene *scene, double near_R, hipStream_t stream, f
       }
     }
     hipError_t e = hipEventCreateWithFlags(&t.built, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&t.last_use, hipEventDisableTiming);
     if (e != hipSuccess)
     {
-      if (t.built) (void)hipEventDestroy(t.built);
       if (t.owned)
       {
         (void)hipFree(t.filt);
@@ -364,7 +366,9 @@ int acquire_tables(const RtHipScene *scene, double near_R, hipStream_t stream, f
     if (k == tables.size())
       return fail(RT_HIP_ELIMIT, "more than %d launches of one scene with different camera distances are being submitted at once",
                   RT_TABLE_SETS);
-    HIP_TRY(hipEventSynchronize(tables[k].last_use));
+    HIP_TRY(hipEventSynchronize(tables[k].built));
+    for (auto &r : tables[k].readers) /* every stream that ever read this set, not only the last one to release it */
+      HIP_TRY(hipEventSynchronize(r.second));
   }
   TableSet &t = tables[k];
   t.near_R = near_R;
@@ -372,7 +376,6 @@ int acquire_tables(const RtHipScene *scene, double near_R, hipStream_t stream, f
   {
     hipError_t e = pt_launch_build_tables(scene->view, near_R, t.filt, t.bvh_nodes, stream);
     if (e == hipSuccess) e = hipEventRecord(t.built, stream);
-    if (e == hipSuccess) e = hipEventRecord(t.last_use, stream);
     if (e != hipSuccess)
     {
       t.near_R = -1.0; /* never matches a launch: the set is rebuilt (or recycled) by the next one */
@@ -392,8 +395,32 @@ void release_tables(const RtHipScene *scene, size_t slot, hipStream_t stream)
   std::lock_guard<std::mutex> lock(scene->table_mutex);
   if (slot < scene->tables.size())
   {
-    (void)hipEventRecord(scene->tables[slot].last_use, stream);
-    scene->tables[slot].users--;
+    TableSet &t = scene->tables[slot];
+    hipEvent_t ev = nullptr;
+    for (auto &r : t.readers)
+      if (r.first == stream)
+        ev = r.second;
+    if (!ev && t.readers.size() >= 32)
+    { /* a caller cycling through many streams: wait out the oldest reader and hand its event to this stream */
+      (void)hipEventSynchronize(t.readers.front().second);
+      ev = t.readers.front().second;
+      t.readers.erase(t.readers.begin());
+      t.readers.emplace_back(stream, ev);
+    }
+    else if (!ev)
+    {
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess)
+        t.readers.emplace_back(stream, ev);
+      else
+      { /* no event to remember this reader by: let it finish before the set can be recycled */
+        ev = nullptr;
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream);
+      }
+    }
+    if (ev)
+      (void)hipEventRecord(ev, stream);
+    t.users--;
   }
 }
 
@@ -786,9 +813,13 @@ void rt_hip_scene_destroy(RtHipScene *scene)
     DeviceScope scope(scene->device);
     for (TableSet &t : scene->tables)
     {
-      if (t.last_use) (void)hipEventSynchronize(t.last_use);
+      if (t.built) (void)hipEventSynchronize(t.built);
+      for (auto &r : t.readers)
+      {
+        (void)hipEventSynchronize(r.second);
+        (void)hipEventDestroy(r.second);
+      }
       if (t.built) (void)hipEventDestroy(t.built);
-      if (t.last_use) (void)hipEventDestroy(t.last_use);
       if (t.owned)
       {
         (void)hipFree(t.filt);
@@ -1216,7 +1247,9 @@ struct ImageCtx
     uint32_t count = 0;
   };
   int G = 0, W = 0, H = 0;
+  bool force_comm = false; /* RT_HIP_FORCE_COMM=1: communicators and the gather's send/recv block even with one device */
   uint64_t scene_hash = 0;
+  std::vector<unsigned char> scene_bytes; /* what the hash was taken over: compared on a hash match */
   std::vector<Dev> dev;
   std::vector<ncclComm_t> comms;
   float *all_tiles = nullptr, *image = nullptr;
@@ -1259,14 +1292,18 @@ void ctx_release(ImageCtx &c)
   c.builds = builds;
 }
 
-/* FNV-1a over everything that defines the scene */
-uint64_t scene_fingerprint(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes)
+/* Everything that defines the scene, serialised (`bytes`), and FNV-1a over it.  The cached context is reused only
+ * when the hash AND the bytes match: a collision must not render another scene. */
+uint64_t scene_fingerprint(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes,
+                           std::vector<unsigned char> &bytes)
 {
   uint64_t h = 1469598103934665603ull;
+  bytes.clear();
   auto mix = [&](const void *p, size_t n) {
     const unsigned char *b = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < n; i++)
       h = (h ^ b[i]) * 1099511628211ull;
+    bytes.insert(bytes.end(), b, b + n);
   };
   mix(&n_spheres, sizeof n_spheres);
   mix(&n_meshes, sizeof n_meshes);
@@ -1304,9 +1341,16 @@ uint64_t scene_fingerprint(const RtHipSphere *spheres, size_t n_spheres, const R
 int ctx_prepare(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes, int G, int W, int H,
                 int prev)
 {
-  const uint64_t fp = scene_fingerprint(spheres, n_spheres, meshes, n_meshes);
+  std::vector<unsigned char> bytes;
+  const uint64_t fp = scene_fingerprint(spheres, n_spheres, meshes, n_meshes, bytes);
+  /* RT_HIP_FORCE_COMM=1: build the RCCL communicator(s) and run the gather's grouped send / recv block even with ONE
+   * device (the device sends its tile buffers to itself): how a one-GPU box exercises library load, bootstrap,
+   * communicator creation / destruction and the send / recv kernels of the N > 1 path */
+  const char *fc = getenv("RT_HIP_FORCE_COMM");
+  const bool force_comm = fc && fc[0] == '1';
   ImageCtx &c = g_ctx;
-  if (c.G == G && c.W == W && c.H == H && c.scene_hash == fp && (int)c.dev.size() == G)
+  if (c.G == G && c.W == W && c.H == H && c.force_comm == force_comm && c.scene_hash == fp && (int)c.dev.size() == G &&
+      c.scene_bytes == bytes)
     return RT_HIP_OK;
   ctx_release(c);
   c.builds++;
@@ -1337,7 +1381,7 @@ int ctx_prepare(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *m
   CTX_TRY(hipSetDevice(0));
   CTX_TRY(hipMalloc(&c.image, n_px * 3 * sizeof(float)));
   CTX_TRY(hipMalloc(&c.image8, n_px * 3));
-  if (G > 1)
+  if (G > 1 || force_comm)
   {
     CTX_TRY(hipMalloc(&c.all_tiles, (size_t)n_tiles * 192 * sizeof(float)));
     CTX_TRY(hipMalloc(&c.all_tiles8, (size_t)n_tiles * 192));
@@ -1356,7 +1400,9 @@ int ctx_prepare(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *m
   c.G = G;
   c.W = W;
   c.H = H;
+  c.force_comm = force_comm;
   c.scene_hash = fp;
+  c.scene_bytes.swap(bytes);
   return RT_HIP_OK;
 }
 
@@ -1466,10 +1512,12 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   std::vector<size_t> first_slot(G, 0);
   for (int g = 1; g < G; g++)
     first_slot[g] = first_slot[g - 1] + dev[g - 1].count;
-  if (G > 1)
+  /* force_comm with one device: g = 0 sends to itself (send and recv of one group on one communicator) */
+  const int g_first = (G == 1 && c.force_comm) ? 0 : 1;
+  if (G > 1 || c.force_comm)
   {
     ncclResult_t nr = ncclGroupStart();
-    for (int g = 1; g < G && nr == ncclSuccess; g++)
+    for (int g = g_first; g < G && nr == ncclSuccess; g++)
     {
       if (!dev[g].count)
         continue;
@@ -1495,8 +1543,9 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   {
     if (!dev[g].count)
       continue;
-    const float *src = (g == 0) ? dev[0].tiles : c.all_tiles + first_slot[g] * 192;
-    const uint8_t *src8 = (g == 0) ? dev[0].tiles8 : c.all_tiles8 + first_slot[g] * 192;
+    const bool local = g == 0 && g_first != 0; /* device 0's own tiles never travel -- unless force_comm sent them through RCCL */
+    const float *src = local ? dev[0].tiles : c.all_tiles + first_slot[g] * 192;
+    const uint8_t *src8 = local ? dev[0].tiles8 : c.all_tiles8 + first_slot[g] * 192;
     rc = rt_hip_untile(src, src8, W, H, (uint32_t)g, (uint32_t)G, dev[g].count, c.image, c.image8, dev[0].stream);
     if (rc)
     {

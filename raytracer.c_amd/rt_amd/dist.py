@@ -39,14 +39,17 @@ def alloc_tile_buffers(width, height, world, device):
             torch.zeros((n, abi.TILE_PIXELS, 3), dtype=torch.uint8, device=device))
 
 
-def gather_tiles(tiles, tiles8, rank, world, gathered=None, gathered8=None, dst=0, via_cpu=False):
+def gather_tiles(tiles, tiles8, rank, world, gathered=None, gathered8=None, dst=0, via_cpu=False, force_collective=False):
     """Gather every rank's padded tile buffers on `dst`.  Returns (list, list) on dst,
-    (None, None) elsewhere.  world == 1: no collective, the inputs are returned.
+    (None, None) elsewhere.  world == 1: no collective, the inputs are returned -- unless
+    force_collective, which sends a one-rank group through the backend's gather all the same (how the
+    tests run RCCL on a one-GPU box).
     via_cpu: stage through host memory (gloo rehearsals with device buffers; RCCL never needs it)."""
-    if world == 1:
+    if world == 1 and not force_collective:
         return [tiles], [tiles8]
     if via_cpu:
-        host, host8 = gather_tiles(tiles.cpu(), tiles8.cpu() if tiles8 is not None else None, rank, world, dst=dst)
+        host, host8 = gather_tiles(tiles.cpu(), tiles8.cpu() if tiles8 is not None else None, rank, world, dst=dst,
+                                   force_collective=force_collective)
         if rank != dst:
             return None, None
         return ([t.to(tiles.device) for t in host],

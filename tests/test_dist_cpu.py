@@ -85,3 +85,37 @@ def test_world_one_needs_no_collective():
     a, b = D.alloc_tile_buffers(16, 16, 1, torch.device("cpu"))
     parts, parts8 = D.gather_tiles(a, b, 0, 1)
     assert parts[0] is a and parts8[0] is b
+
+
+def test_force_collective_with_one_rank(tmp_path):
+    """world 1 normally short-circuits; force_collective sends the one-rank group through the backend's gather
+    (what tests/rccl_child.py does over RCCL on the GPU box)"""
+    import torch
+    import torch.distributed as dist
+    from rt_amd import dist as D
+    dist.init_process_group("gloo", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{_free_port()}")
+    try:
+        tiles = torch.arange(3 * 64 * 3, dtype=torch.float32).reshape(3, 64, 3)
+        tiles8 = (torch.arange(3 * 64 * 3) % 251).to(torch.uint8).reshape(3, 64, 3)
+        same, same8 = D.gather_tiles(tiles, tiles8, 0, 1)
+        assert same[0] is tiles and same8[0] is tiles8
+        parts, parts8 = D.gather_tiles(tiles, tiles8, 0, 1, force_collective=True)
+        assert parts[0] is not tiles and torch.equal(parts[0], tiles) and torch.equal(parts8[0], tiles8)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_started_without_a_launcher_and_without_gpus():
+    """`python bench.py --gpus 8` as the driver calls it, on a box without GPUs: no traceback, one JSON line that
+    says why, exit code 2 (with GPUs it starts its own ranks: tests/test_gpu_multi.py)"""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RT_BENCH_REHEARSE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 2, p.stderr[-1000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 8 and "error" in json.loads(lines[0])

@@ -1,0 +1,78 @@
+"""The exhaustive checks of the kernels' CONSERVATIVE rules, in the driver's suite.
+
+The render kernels may skip exact fp64 tests only through rules that can never change an outcome: the packed-fp32
+phase-1 filter (three forms), the per-lane fp32 Moeller-Trumbore pre-test (small meshes and hierarchy leaves), the
+bounding-sphere probe in front of a hierarchy walk, and the hull-facet rule (a bounce that leaves a convex facet
+on its outer side is not walked).  Each rests on a hand-derived error bound (pt_kernel.hip: pt_build_filter,
+tri_may_hit32; rt_hip_shim.hip: mesh_bound_for, hull_margin_for).  The PT_DIAG build of the same kernels
+(`make shim-diag`, part of `make all`: raytracer.c_amd/csrc/librt_hip_diag.so) re-checks every application of every
+rule at run time: each primitive the filter or a pre-test drops is put through the exact test, and with
+RT_HIP_DIAG_WALK_REJECTED=1 every ray the probe or the hull rule would not walk is walked all the same; anything
+found counts into stats[4 + 12].  That count must be ZERO.
+
+The diag library is loaded in child processes (RT_HIP_SHIM_PATH), never into the test process, whose shim is the
+shipped one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG_LIB = os.path.join(ROOT, "raytracer.c_amd", "csrc", "librt_hip_diag.so")
+
+
+def _run(which, timeout=600):
+    assert os.path.exists(DIAG_LIB), "make all builds librt_hip_diag.so"
+    env = dict(os.environ, RT_HIP_SHIM_PATH=DIAG_LIB, RT_HIP_DIAG_WALK_REJECTED="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag_child.py"), which], env=env, capture_output=True,
+                       text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    recs = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert recs, p.stdout[-2000:]
+    return recs
+
+
+def _no_violations(recs):
+    bad = [r for r in recs if r.get("violations", 0) != 0]
+    assert not bad, f"a conservative rule dropped something the exact test accepts: {bad}"
+
+
+def test_diag_configs_1_to_5_zero_violations():
+    recs = _run("configs")
+    _no_violations(recs)
+    path = {r["scene"]: r for r in recs if r["integrator"] == "path" and "skipped" not in r}
+    assert set(path) == {"config %d" % c for c in range(1, 6)}
+    for r in path.values():   # the filter really dropped primitives (else the re-check had nothing to check)
+        assert 0 < r["candidates"] < r["casts"] * r["n_primitives"], r
+    c3, c5 = path["config 3"], path["config 5"]
+    assert c3["kernel"] == "pt_render_tiles_tri" and c3["small_mesh_pretests"] > 0
+    assert c5["kernel"] == "pt_render_tiles_tri_queued_sph"
+    # rays the probe's bounding sphere rejects were walked too (parked > what the shipped build parks), bounces off hull
+    # facets were seen, leaves were pre-tested, and walks did find triangles
+    assert c5["parked"] > c5["parked_probe_would_park"] > 0 and c5["left_hull_facet"] > 0
+    assert c5["leaf_pretests"] > 0 and c5["walked_found_triangle"] > 0
+
+
+def test_diag_fuzz_scenes_zero_violations():
+    recs = _run("fuzz")
+    _no_violations(recs)
+    done = [r for r in recs if "skipped" not in r]
+    assert len({r["scene"] for r in done}) == 13 and {r["integrator"] for r in done} == {"path", "whitted"}
+    kernels = {r["kernel"] for r in done}
+    # flat-filter kernels, small-mesh kernels and both hierarchy families were all exercised
+    assert any(k.startswith("pt_render_tiles_tri_queued") for k in kernels), kernels
+    assert any(k.startswith("pt_whitted_tiles") for k in kernels), kernels
+    assert any("_tri" in k and "queued" not in k and "big" not in k for k in kernels), kernels
+
+
+def test_diag_convex_bodies_zero_violations():
+    recs = _run("convex")
+    _no_violations(recs)
+    path = [r for r in recs if r["integrator"] == "path" and "skipped" not in r]
+    assert len(path) == 4
+    for r in path:   # thousands of bounces off hull facets each -- all walked under RT_HIP_DIAG_WALK_REJECTED, none found a triangle
+        assert r["left_hull_facet"] > 1000 and r["parked"] > 0, r

@@ -979,6 +979,21 @@ def test_two_cameras_of_one_scene_on_two_streams(gpu):
         for (t, t8, st), (a, a8, ast) in zip(out, seq):
             assert torch.equal(t, a) and torch.equal(t8, a8) and torch.equal(st, ast)
         gs.close()
+        # every camera on TWO streams at once (one table set read from two streams: it keeps a last-read event per
+        # reader stream, and may only be recycled when both readers are done), again more cameras than table sets
+        gs = gpu.GpuScene(sc)
+        out = []
+        for k, cam in enumerate(cams):
+            pair = []
+            for j in (0, 1):
+                with torch.cuda.stream(streams[(k + j) % 3]):
+                    pair.append(gs.render_tiles(SEED, 0, 1, total, camera=cam))
+            out.append(pair)
+        torch.cuda.synchronize()
+        for pair, (a, a8, ast) in zip(out, seq):
+            for t, t8, st in pair:
+                assert torch.equal(t, a) and torch.equal(t8, a8) and torch.equal(st, ast)
+        gs.close()
         sc.free()
 
 

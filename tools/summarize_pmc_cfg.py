@@ -19,7 +19,13 @@ casts = bench["ray_bounces_per_step"]
 v = vals
 ms = v["SQ_INSTS_VALU"][-1][1]
 clk = v["GRBM_GUI_ACTIVE"][-1][0] / 8 / (v["GRBM_GUI_ACTIVE"][-1][1] * 1e-3)
-busy = v["SQ_ACTIVE_INST_VALU"][-1][0] * 4 / 1024 / (v["GRBM_GUI_ACTIVE"][-1][0] / 8)
+# VALU busy: SQ_ACTIVE_INST_VALU counts quad-cycles summed over WAVES (a SIMD that overlaps two waves' VALU instructions --
+# packed-fp32 / 32-bit ops issue in 2 of the 4 cycles -- counts both), normalised by the cycles of the SAME pass
+# (GRBM_GUI_ACTIVE is collected with the SQ counters).  So the raw ratio can exceed 1: it is reported as measured, and
+# `valu_busy` is that ratio capped at 1 ("the VALU issue port is saturated"), not a 3-digit measurement above 100 %.
+busy_raw = v["SQ_ACTIVE_INST_VALU"][-1][0] * 4 / 1024 / (v["GRBM_GUI_ACTIVE"][-1][0] / 8)
+busy = min(busy_raw, 1.0)
+sq_busy = v["SQ_BUSY_CYCLES"][-1][0] / v["GRBM_GUI_ACTIVE"][-1][0] if "SQ_BUSY_CYCLES" in v else None
 util = v["SQ_THREAD_CYCLES_VALU"][-1][0] / (v["SQ_ACTIVE_INST_VALU"][-1][0] * 64)
 fetch_kb, write_kb = v["FETCH_SIZE"][-1][0], v["WRITE_SIZE"][-1][0]
 traffic = (2 * fetch_kb + write_kb) * 1024
@@ -28,7 +34,8 @@ lines = [
     f"kernel {kernel}, {cfg['workload']}, per launch",
     f"kernel time              {ms:.2f} ms",
     f"effective clock          {clk / 1e9:.3f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)",
-    f"VALU busy                {busy * 100:.1f} % (SQ_ACTIVE_INST_VALU [quad-cycles] * 4 / 1024 SIMDs / cycles; >= 100 % = saturated)",
+    f"VALU busy                {busy * 100:.1f} % (raw ratio {busy_raw * 100:.1f} %: SQ_ACTIVE_INST_VALU [quad-cycles, summed over waves] * 4 / 1024 SIMDs / "
+    f"GRBM_GUI_ACTIVE per XCD of the same pass; a raw value above 100 % = overlapping waves counted twice, i.e. saturated)",
     f"VALU lane utilisation    {util * 100:.1f} % (SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64))",
     f"VALU wave-instructions   {v['SQ_INSTS_VALU'][-1][0]:.4g} = {v['SQ_INSTS_VALU'][-1][0] / casts * 64:.0f} per 64 ray-bounces",
     f"LDS wave-instructions    {v['SQ_INSTS_LDS'][-1][0]:.4g} = {v['SQ_INSTS_LDS'][-1][0] / casts * 64:.0f} per 64 ray-bounces",
@@ -42,7 +49,10 @@ pre = f"{P}/{tag}_c{cfg_n}"
 open(f"{pre}_pmc.txt", "w").write("\n".join(lines) + "\n")
 json.dump({"kernel": kernel, "config": cfg_n, "width": cfg["width"], "height": cfg["height"], "spp": cfg["spp"],
            "n_gpus": 1, "traffic_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-           "valu_busy": busy, "lane_utilisation": util, "valu_instr_per_64_bounces": v["SQ_INSTS_VALU"][-1][0] / casts * 64,
+           "valu_busy": busy, "valu_busy_raw": busy_raw,
+           "valu_busy_note": "SQ_ACTIVE_INST_VALU*4/1024/(GRBM_GUI_ACTIVE/8), both from ONE pass; per-wave quad-cycles, so overlapping "
+                             "waves on a SIMD can push the raw ratio past 1: valu_busy is capped at 1 = saturated",
+           "lane_utilisation": util, "valu_instr_per_64_bounces": v["SQ_INSTS_VALU"][-1][0] / casts * 64,
            "effective_clock_ghz": clk / 1e9,
            "method": "rocprofv3 --pmc, one counter group per pass with --kernel-trace only (tools/gpu_pmc_cfg.sh); traffic = "
                      "(2*FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md",
