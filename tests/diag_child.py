@@ -27,15 +27,19 @@ def scene_sets(which):
     if which == "configs":   # BASELINE configurations 1-5, reduced
         return [("config %d" % c, S.build_scene(c, w, h, spp)) for c, w, h, spp in
                 [(1, 256, 256, 4), (2, 400, 300, 8), (3, 240, 136, 8), (4, 480, 270, 16), (5, 192, 108, 8)]]
-    if which == "fuzz":      # 6 random sphere scenes, 6 random mesh scenes (flat filter and hierarchy), the every-branch scene
-        sets = [("fuzz %d" % k, _random_scene(k, False, 0)) for k in range(6)]
-        sets += [("fuzz mesh %d" % k, _random_scene(k, True, n)) for k, n in zip(range(100, 106), [3, 40, 250, 300, 700, 2000])]
+    if which == "fuzz":      # 6 random sphere scenes, 6 random mesh scenes (flat filter and hierarchy), the every-branch scene;
+        # materials rotate so that the static (_refr), the pooled _chk and the plain kernel families all come up
+        kinds = ["all", "no_glass", "plain"]
+        sets = [("fuzz %d" % k, _random_scene(k, False, 0, materials=kinds[k % 3])) for k in range(6)]
+        sets += [("fuzz mesh %d" % k, _random_scene(k, True, n, materials=kinds[k % 3]))
+                 for k, n in zip(range(100, 106), [3, 40, 250, 300, 700, 2000])]
         return sets + [("whitted scene", whitted_scene())]
     if which == "convex":    # convex bodies at 64 spp: ~1e6 bounces off hull facets each, all walked
         return [("convex body %d" % k, convex_body_scene(k, 160, 100, 64)[0]) for k in range(4)]
     if which == "wide":      # the wider sweep of tools/diag_fuzz.py
-        sets = [("fuzz %d" % k, _random_scene(k, False, 0)) for k in range(40)]
-        sets += [("fuzz mesh %d" % k, _random_scene(k, True, n)) for k, n in
+        kinds = ["all", "no_glass", "plain"]
+        sets = [("fuzz %d" % k, _random_scene(k, False, 0, materials=kinds[k % 3])) for k in range(40)]
+        sets += [("fuzz mesh %d" % k, _random_scene(k, True, n, materials=kinds[k % 3])) for k, n in
                  zip(range(100, 112), [3, 10, 40, 120, 250, 300, 400, 700, 1000, 60, 500, 2000])]
         return sets + [("convex body %d" % k, convex_body_scene(k, 160, 100, 64)[0]) for k in range(8)]
     raise SystemExit(f"unknown scene set {which!r}")

@@ -63,10 +63,11 @@ def test_diag_fuzz_scenes_zero_violations():
     done = [r for r in recs if "skipped" not in r]
     assert len({r["scene"] for r in done}) == 13 and {r["integrator"] for r in done} == {"path", "whitted"}
     kernels = {r["kernel"] for r in done}
-    # flat-filter kernels, small-mesh kernels and both hierarchy families were all exercised
+    # the static (_refr), pooled (plain / _chk), small-mesh, parked-walk and cast_ray families were all exercised
     assert any(k.startswith("pt_render_tiles_tri_queued") for k in kernels), kernels
     assert any(k.startswith("pt_whitted_tiles") for k in kernels), kernels
-    assert any("_tri" in k and "queued" not in k and "big" not in k for k in kernels), kernels
+    assert any(k.endswith("_refr") for k in kernels) and any(k in ("pt_render_tiles", "pt_render_tiles_chk") for k in kernels), kernels
+    assert any(k in ("pt_render_tiles_tri", "pt_render_tiles_tri_chk") for k in kernels), kernels
 
 
 def test_diag_convex_bodies_zero_violations():

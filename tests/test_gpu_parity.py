@@ -415,14 +415,20 @@ def test_device_math_shortcuts_are_bit_exact(gpu):
     assert np.array_equal(run(5, y, y), 1.0 / y), "unscaled reciprocal differs from IEEE division"
 
 
-def _random_scene(seed, with_mesh, n_tris, extra_flags=()):
+def _random_scene(seed, with_mesh, n_tris, extra_flags=(), materials="all"):
     """a deliberately nasty random scene: overlapping / nested / touching spheres, radii from
     1e-3 to 1e4, every material flag, HDR emission, camera possibly inside a sphere, optional
-    triangle soup with degenerate and duplicated triangles"""
+    triangle soup with degenerate and duplicated triangles.
+    materials: "all" (M_REFRACTION included: the static `_refr` kernels render such scenes), "no_glass" (the pooled
+    `_chk` / parked-walk `_chk` kernels), "plain" (diffuse / mirror only: the headline kernel family)"""
     from rt_amd import abi, scene as S
     rng = np.random.default_rng(1000 + seed)
     flags = [abi.M_DEFAULT, abi.M_REFLECTION, abi.M_REFRACTION, abi.M_DEFAULT | abi.M_CHECKERED,
              abi.M_REFLECTION | abi.M_CHECKERED] + list(extra_flags)
+    if materials == "no_glass":
+        flags = [f for f in flags if not f & abi.M_REFRACTION]
+    elif materials == "plain":
+        flags = [abi.M_DEFAULT, abi.M_REFLECTION]
     objs = []
     for k in range(int(rng.integers(1, 70))):
         r = float(10.0 ** rng.uniform(-3, 1.3)) if rng.uniform() < 0.9 else float(10.0 ** rng.uniform(2, 4))
