@@ -686,6 +686,118 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
   cand_hi = far_origin ? valid_hi : (cand_hi & valid_hi);
 }
 
+/* Phase 1 for a PRIMARY trip of the pooled kernels (render_tiles_pooled: all 64 lanes hold fresh camera rays of one
+ * 8x8 tile): only the pairs of `pair_mask` (wave-uniform; bit p = pair p of this chunk holds a primitive that some
+ * camera ray of the tile can reach at all, tile_cull below) go through the packed-fp32 test; every other primitive
+ * of the chunk is dropped for all lanes.  Same arithmetic and thresholds as filter_chunk, so a listed primitive gets
+ * the keep bit it would get there; keep bits are placed by position instead of shifted in, because pairs are skipped. */
+template <bool SHIFT>
+__device__ __forceinline__ void filter_chunk_listed(const f32x2 *__restrict__ filt, uint32_t base, uint32_t chunk, uint32_t pair_mask,
+                                                    const FiltRay &fr, uint32_t &cand_lo, uint32_t &cand_hi)
+{
+  const f32x2 dx = fr.dx, dy = fr.dy, dz = fr.dz;
+  const f32x2 neg_od = {-fr.od, -fr.od}, oo = {fr.oo, fr.oo};
+  const f32x2 m2ox = {fr.m2ox, fr.m2ox}, m2oy = {fr.m2oy, fr.m2oy}, m2oz = {fr.m2oz, fr.m2oz};
+  unsigned long long keep = 0;
+  uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_mask);
+  while (pm != 0u)
+  {
+    const uint32_t p = (uint32_t)__builtin_ctz(pm);
+    pm &= pm - 1u;
+    const f32x2 *g = filt + PT_FILT_STRIDE * (size_t)((base >> 1) + p);
+    uint32_t two;
+    if (SHIFT)
+    {
+      const f32x2 cx = g[0], cy = g[1], cz = g[2], kq = g[5];
+      const f32x2 tca = __builtin_elementwise_fma(cz, dz, __builtin_elementwise_fma(cy, dy, __builtin_elementwise_fma(cx, dx, neg_od)));
+      const f32x2 ll = __builtin_elementwise_fma(cz, m2oz, __builtin_elementwise_fma(cy, m2oy, __builtin_elementwise_fma(cx, m2ox, kq + oo)));
+      const f32x2 q = __builtin_elementwise_fma(tca, tca, -ll);
+      /* a set sign bit of tca or q means DROP (filter_chunk) */
+      const uint32_t d0 = (__float_as_uint(tca.x) | __float_as_uint(q.x)) >> 31, d1 = (__float_as_uint(tca.y) | __float_as_uint(q.y)) >> 31;
+      two = (d0 | (d1 << 1)) ^ 3u;
+    }
+    else
+    {
+      const f32x2 cx = g[0], cy = g[1], cz = g[2], r2_hi = g[3], neg_tol = g[4];
+      const f32x2 lx = cx - fr.ox, ly = cy - fr.oy, lz = cz - fr.oz;
+      const f32x2 tca = __builtin_elementwise_fma(lz, dz, __builtin_elementwise_fma(ly, dy, lx * dx));
+      const f32x2 ll = __builtin_elementwise_fma(lz, lz, __builtin_elementwise_fma(ly, ly, lx * lx));
+      const f32x2 d2 = __builtin_elementwise_fma(-tca, tca, ll);
+      /* NaNs compare false and stay candidates */
+      const bool drop0 = (bool)((int)(tca.x < neg_tol.x) | (int)(d2.x > r2_hi.x));
+      const bool drop1 = (bool)((int)(tca.y < neg_tol.y) | (int)(d2.y > r2_hi.y));
+      two = (drop0 ? 0u : 1u) | (drop1 ? 0u : 2u);
+    }
+    keep |= (unsigned long long)two << (2u * p);
+  }
+  const uint32_t valid_lo = chunk >= 32u ? 0xFFFFFFFFu : ((1u << chunk) - 1u);
+  const uint32_t valid_hi = chunk >= 64u ? 0xFFFFFFFFu : (chunk > 32u ? ((1u << (chunk - 32u)) - 1u) : 0u);
+  cand_lo = fr.far_origin ? valid_lo : ((uint32_t)keep & valid_lo);
+  cand_hi = fr.far_origin ? valid_hi : ((uint32_t)(keep >> 32) & valid_hi);
+}
+
+/* Which primitives can a camera ray of tile (tx0, ty0) reach at all?  -> pairs[c]: bit p set = pair p of chunk c (entries
+ * 64 c + 2 p, + 1) holds such a primitive.  Once per workgroup, thread = entry, before a barrier.
+ *   The camera rays of the tile are d = normalize(w), w(u, v) = pos - (llc + H u + V v) (get_camera_ray :377-383) with
+ *   u in [tx0, tx0 + 8] / (W - 1), v in [ty0, ty0 + 8] / (H - 1) (pixel + jitter in [0, 1), raytracer.c:203-204): w is
+ *   affine in (u, v), so every direction lies in the convex cone of the four corner vectors, i.e. within the angle
+ *   theta of the centre direction a that the farthest corner makes.  A ray from pos with direction within theta of a
+ *   can touch the ball (c, R) only if the angle between a and c - pos is at most theta + asin(R / |c - pos|) (or pos is
+ *   inside the ball).  R is the sphere's radius, or the radius of a triangle's bounding sphere (entry_src).  Everything
+ *   in fp64 (errors ~1e-15 relative) with margins of 1e-5 in the radius, in cos(theta) and in the final comparison:
+ *   conservative by ten orders of magnitude over the fp64 rounding of the exact tests that decide, which can accept
+ *   nothing farther than ~1e-12 |c| outside a primitive.  Non-finite anything: keep.  (The PT_DIAG build re-checks
+ *   every primitive dropped this way with the exact test, like every other dropped primitive.) */
+__device__ __forceinline__ void tile_cull(const double *cam_lds, const double *entry_src, uint32_t n_sph, uint32_t n_entries,
+                                          uint32_t tx0, uint32_t ty0, uint32_t *pairs)
+{
+  const uint32_t i = threadIdx.x;
+  bool keep = false;
+  if (i < n_entries)
+  {
+    const V3 pos = {cam_lds[0], cam_lds[1], cam_lds[2]}, Hh = {cam_lds[3], cam_lds[4], cam_lds[5]},
+             Vv = {cam_lds[6], cam_lds[7], cam_lds[8]}, llc = {cam_lds[9], cam_lds[10], cam_lds[11]};
+    const double u0 = (double)tx0 / cam_lds[12], u1 = (double)(tx0 + PT_TILE) / cam_lds[12];
+    const double v0 = (double)ty0 / cam_lds[13], v1 = (double)(ty0 + PT_TILE) / cam_lds[13];
+    V3 w[4];
+    for (int k = 0; k < 4; k++)
+    {
+      const double u = (k & 1) ? u1 : u0, v = (k & 2) ? v1 : v0;
+      w[k] = v_sub(pos, v_add(llc, v_add(v_scale(Hh, u), v_scale(Vv, v))));
+    }
+    V3 a = v_add(v_add(w[0], w[1]), v_add(w[2], w[3]));
+    a = v_scale(a, 1.0 / sqrt(v_dot(a, a)));
+    double cos_t = 1.0;
+    for (int k = 0; k < 4; k++)
+      cos_t = fmin(cos_t, v_dot(a, w[k]) / sqrt(v_dot(w[k], w[k])));
+    cos_t -= 1e-5;
+    const double sin_t = sqrt(fmax(0.0, 1.0 - cos_t * cos_t));
+    const double *e = entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz R2 |c| Rb */
+    const double R = (i < n_sph ? sqrt(e[3]) : e[5]) * (1.0 + 1e-5) + 1e-300;
+    const V3 L = v_sub(ld3(e), pos);
+    const double len = sqrt(v_dot(L, L));
+    const double sin_p = R / len; /* NaN / inf: the comparisons below keep the primitive */
+    if (!(sin_p < 1.0) || !(cos_t > 0.0))
+      keep = true; /* the camera inside (or on) the ball; a degenerate cone */
+    else
+    {
+      const double cos_p = sqrt(1.0 - sin_p * sin_p);
+      const double cos_a = v_dot(a, L) / len;
+      keep = !(cos_a < cos_t * cos_p - sin_t * sin_p - 1e-5);
+    }
+  }
+  unsigned long long m = __ballot(keep);
+  /* entry mask -> pair mask: OR neighbouring bits, then gather the even positions */
+  m = (m | (m >> 1)) & 0x5555555555555555ull;
+  m = (m | (m >> 1)) & 0x3333333333333333ull;
+  m = (m | (m >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  m = (m | (m >> 4)) & 0x00FF00FF00FF00FFull;
+  m = (m | (m >> 8)) & 0x0000FFFF0000FFFFull;
+  m = (m | (m >> 16)) & 0x00000000FFFFFFFFull;
+  if ((threadIdx.x & 63u) == 0u)
+    pairs[threadIdx.x >> 6] = (uint32_t)m;
+}
+
 /* Per-lane fp32 pre-test of one triangle candidate (small scenes: the flat filter passes a
  * triangle through its bounding sphere, which is loose -- a ray near a cube passes the spheres of
  * most of its 12 triangles; measured on config 3: 6.9 exact tests per wave trip for 1.7 candidates
@@ -747,8 +859,10 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
                                               unsigned long long *diag_ptr, const float *bvh_nodes = nullptr,
                                               uint32_t n_bvh_nodes = 0, const uint32_t *bvh_tri = nullptr,
                                               double filt_shift = 0.0, TriLast *last = nullptr, bool no_prune = false,
-                                              const float4 *tri32 = nullptr)
+                                              const float4 *tri32 = nullptr, const uint32_t *prim_pairs = nullptr)
 {
+  /* prim_pairs (wave-uniform; pooled kernels' primary trips, FILT_LDS only): per chunk the pairs that a camera ray of
+   * this tile can reach (tile_cull); nullptr: every pair */
   /* with a hierarchy the flat filter covers the spheres only */
   if (BVH)
     n_entries = n_sph;
@@ -782,6 +896,8 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     uint32_t cand_lo, cand_hi;
     if (SPH_LDS)
       filter_chunk<false, true>(filt, base, chunk, fr, cand_lo, cand_hi);
+    else if (FILT_LDS && prim_pairs != nullptr)
+      filter_chunk_listed<SHIFT>(filt, base, chunk, prim_pairs[base >> 6], fr, cand_lo, cand_hi);
     else
       filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, fr, cand_lo, cand_hi);
     /* triangle candidates of this chunk: bits from entry n_sph on */
@@ -1212,7 +1328,7 @@ template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int
           bool SPH_LDS = false>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
                                            unsigned long long *diag_ptr, PendingRay *stack, int &stack_n,
-                                           HitRec *rec = nullptr)
+                                           HitRec *rec = nullptr, const uint32_t *prim_pairs = nullptr)
 {
   V3 add = {S.bg, S.bg, S.bg}; /* what this call contributes if the path ends here */
   bool path_ends = true;
@@ -1246,7 +1362,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       else
         scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0, CHECKER && TRIS, SPH_LDS>(
             S.geom, S.tri, (FILT_LDS || SPH_LDS) ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o, d, H.min_t, H.best,
-            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv, S.tri32);
+            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv, S.tri32, prim_pairs);
     }
     if (MODE == 1)
       return false;
@@ -1684,14 +1800,27 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3]; /* fixed-point radiance sums */
   __shared__ unsigned long long pix_nan[3];                  /* per channel: pixels that received a NaN sample */
   __shared__ unsigned long long pix_key[PT_TILE_PIXELS];     /* per-pixel half of the RNG key */
-  /* per-wave queue of prepared camera samples: direction, RNG state, pixel slot (64 entries) */
-  __shared__ double q_dir[PT_BLOCK / 64][3 * 64];
-  __shared__ unsigned long long q_rng[PT_BLOCK / 64][64];
-  __shared__ uint32_t q_pix[PT_BLOCK / 64][64];
+  /* kernels with a triangle hierarchy postpone its walks in the lanes (see the loop): they keep round 2's job
+   * hand-out, a queue of prepared camera samples; all others swap whole paths in and out (SWAP, see the loop) */
+  constexpr bool DEFER_MESH = TRIS && !FILT_LDS;
+  constexpr bool SWAP = !DEFER_MESH;
+  /* !SWAP: per-wave queue of prepared camera samples: direction, RNG state, pixel slot (64 entries) */
+  __shared__ double q_dir[SWAP ? 1 : PT_BLOCK / 64][SWAP ? 1 : 3 * 64];
+  __shared__ unsigned long long q_rng[SWAP ? 1 : PT_BLOCK / 64][SWAP ? 1 : 64];
+  __shared__ uint32_t q_pix[SWAP ? 1 : PT_BLOCK / 64][SWAP ? 1 : 64];
+  /* SWAP: per-wave list of WAITING paths (up to 64): origin, direction (the normal while a direction is still to be
+   * sampled), throughput, RNG state, [checker factor]; depth / pixel slot / need_dir; material slot of a pending direction */
+  constexpr uint32_t WAIT_F = CHECKER ? 11u : 10u;
+  __shared__ double w_f[SWAP ? PT_BLOCK / 64 : 1][SWAP ? WAIT_F : 1][SWAP ? 64 : 1];
+  __shared__ uint32_t w_u[SWAP ? PT_BLOCK / 64 : 1][SWAP ? 2 : 1][SWAP ? 64 : 1];
+  __shared__ uint32_t tile_pairs[PT_FILT_LDS_MAX / 64]; /* tile_cull: pairs a camera ray of this tile can reach, per chunk of 64 entries */
+  __shared__ uint32_t wg_next_job;                      /* SWAP: jobs of the tile's pool handed out so far */
 
   const SceneCtx S = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
+  if (threadIdx.x == 2)
+    wg_next_job = 0;
   if (threadIdx.x < 3)
     pix_nan[threadIdx.x] = 0;
   if (threadIdx.x < PT_TILE_PIXELS * 3)
@@ -1711,10 +1840,19 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
    * tiles, so the chunks of an expensive tile are spread over the launch */
   const uint32_t slot = blockIdx.x % L.tile_count, chunk = blockIdx.x / L.tile_count;
   const uint32_t tile = L.tile_first + slot * L.tile_stride;
-  const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE + 2u * wave;
-  /* valid sub-rectangle of the wave's 8x2 strip (edge tiles of ragged images) */
+  if (SWAP && FILT_LDS)
+  { /* the primitives a camera ray of this tile can reach at all: what the filter of a PRIMARY trip looks at */
+    tile_cull(cam_lds, L.scene.entry_src, S.n_sph, S.n_sph + S.n_tri, (tile % L.tiles_x) * PT_TILE, (tile / L.tiles_x) * PT_TILE, tile_pairs);
+    __syncthreads();
+  }
+  /* SWAP kernels: the four waves draw their 64-job batches from ONE pool, the tile's 64 pixels x samples (an LDS
+   * counter): whichever wave is free takes the next batch, so the waves finish together whatever the rows of the
+   * tile cost (a batch = one sample index of every pixel of the tile: its rays span exactly the tile's cone).  The
+   * others keep round 2's split: wave w owns tile rows 2w, 2w + 1 and their samples. */
+  const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE + (SWAP ? 0u : 2u * wave);
+  /* valid sub-rectangle of the tile / of the wave's 8x2 strip (edge tiles of ragged images) */
   const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
-  const uint32_t vrows = ty0 >= (uint32_t)L.height ? 0u : min(2u, (uint32_t)L.height - ty0);
+  const uint32_t vrows = ty0 >= (uint32_t)L.height ? 0u : min(SWAP ? (uint32_t)PT_TILE : 2u, (uint32_t)L.height - ty0);
   const uint32_t n_valid = vcols * vrows;
   const uint32_t spp = (uint32_t)L.samples;
   /* this workgroup's share of the samples: [s_begin, s_end) of every pixel */
@@ -1730,8 +1868,6 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   P.rng = 1;
   P.depth = 0;
   uint32_t n_rays = 0, n_casts = 0;
-  /* kernels with a triangle hierarchy postpone its walks (see the loop) */
-  constexpr bool DEFER_MESH = TRIS && !FILT_LDS;
   /* small-mesh kernels keep throughput and radiance in LDS across the scan (see the loop) */
   constexpr bool PARK_T = TRIS && FILT_LDS && !CHECKER;
   __shared__ double t_park[PARK_T ? 3 : 1][PARK_T ? PT_BLOCK : 1];
@@ -1761,29 +1897,89 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   unsigned long long *const qr = q_rng[wave];
   uint32_t *const qp = q_pix[wave];
 
+  uint32_t n_wait = 0; /* SWAP: paths in this wave's waiting list (wave-uniform) */
+  double *const wf = &w_f[SWAP ? wave : 0][0][0];
+  uint32_t *const wu = &w_u[SWAP ? wave : 0][0][0];
   for (;;)
   {
-    /* ---- hand out jobs to idle lanes: wave-synchronous, deterministic ----
-     * Idle lanes take jobs next_job, next_job + 1, ... in lane order.  The camera rays are
-     * not generated by the few lanes that happen to be idle (about a fifth of the wave per
-     * trip: start_sample would run on every trip at 20 % lane occupancy) but 64 at a time by
-     * the whole wave into a queue in LDS, from which idle lanes only copy. */
-    unsigned long long idle = __ballot(!busy);
-    while (idle != 0 && next_job < pool)
+    /* wave-uniform: this trip every busy lane holds a fresh camera ray of this tile (SWAP kernels) */
+    bool primary_trip = false;
+    if (SWAP)
     {
-      if (next_job == made_jobs)
+      /* ---- idle lanes take work: wave-synchronous, deterministic ----
+       * Round 2 handed idle lanes camera rays that the whole wave had prepared 64 at a time; the FIRST BOUNCE of those
+       * rays then ran in ordinary trips, a fifth of the lanes at a time, mixed with incoherent rays.  But camera rays
+       * are the one coherent population there is: one origin, 64 directions inside one tile's narrow cone.  So the
+       * wave now SWAPS: when lanes are idle, nobody waits in the list and jobs remain, every busy lane puts its path
+       * on the wave's waiting list in LDS (o, d, T, RNG state, depth: 84 bytes) and ALL 64 lanes start fresh camera
+       * samples -- a PRIMARY TRIP: full occupancy, a filter that only looks at the primitives the tile's cone can
+       * reach (tile_cull: typically 3-5 pairs of the headline scene's 19), exact tests on coherent rays.  The fresh
+       * paths that survive their first bounce stay in their lanes; lanes that fall idle in later trips pick up the
+       * waiting paths (last in, first out), and when the list is dry the wave swaps again.  A sample's value depends
+       * on its (seed, pixel, sample) stream alone and pixel sums are integers, so none of this can change a value. */
+      unsigned long long idle = __ballot(!busy);
+      if (idle != 0 && n_wait != 0u)
       {
-        /* queue empty: every lane, busy or not, prepares job made_jobs + lane */
-        const uint32_t job = made_jobs + lane;
-        if (job < pool)
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        if (!busy && rank < n_wait)
+        {
+          const uint32_t e = n_wait - 1u - rank;
+          P.o = {wf[0 * 64 + e], wf[1 * 64 + e], wf[2 * 64 + e]};
+          P.d = {wf[3 * 64 + e], wf[4 * 64 + e], wf[5 * 64 + e]};
+          P.T = {wf[6 * 64 + e], wf[7 * 64 + e], wf[8 * 64 + e]};
+          P.rng = (uint64_t)__double_as_longlong(wf[9 * 64 + e]);
+          if (CHECKER)
+            hit.dir_scale = wf[(CHECKER ? 10 : 0) * 64 + e];
+          const uint32_t meta = wu[e];
+          hit.dir_slot = wu[64 + e];
+          pix_slot = meta & 63u;
+          hit.need_dir = (meta & 64u) != 0u;
+          P.depth = (int)(meta >> 7);
+          busy = true;
+        }
+        n_wait -= min((uint32_t)__popcll(idle), n_wait);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        idle = __ballot(!busy);
+      }
+      uint32_t batch = 0;
+      if (idle != 0 && next_job < pool)
+      { /* (idle lanes are left only when the list is dry: n_wait == 0 here) take the tile's next batch of 64 jobs */
+        if (lane == 0)
+          batch = atomicAdd(&wg_next_job, 64u);
+        batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch);
+        next_job = batch < pool ? 0u : pool; /* the pool is dry: never ask again */
+      }
+      if (idle != 0 && next_job < pool)
+      {
+        /* the swap */
+        const unsigned long long bm = __ballot(busy);
+        if (busy)
+        {
+          const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+          wf[0 * 64 + e] = P.o.x; wf[1 * 64 + e] = P.o.y; wf[2 * 64 + e] = P.o.z;
+          wf[3 * 64 + e] = P.d.x; wf[4 * 64 + e] = P.d.y; wf[5 * 64 + e] = P.d.z;
+          wf[6 * 64 + e] = P.T.x; wf[7 * 64 + e] = P.T.y; wf[8 * 64 + e] = P.T.z;
+          wf[9 * 64 + e] = __longlong_as_double((long long)P.rng);
+          if (CHECKER)
+            wf[(CHECKER ? 10 : 0) * 64 + e] = hit.dir_scale;
+          wu[e] = ((uint32_t)P.depth << 7) | (hit.need_dir ? 64u : 0u) | pix_slot;
+          wu[64 + e] = hit.dir_slot;
+        }
+        n_wait = (uint32_t)__popcll(bm);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t job = batch + lane;
+        busy = job < pool;
+        if (busy)
         {
           DIAG(6, 1);
           DIAG_LANES(7);
           uint32_t idx, s;
-          if (n_valid == 16)
+          if (n_valid == PT_TILE_PIXELS)
           {
-            idx = job & 15u;
-            s = job >> 4;
+            idx = job & 63u;
+            s = job >> 6;
           }
           else
           {
@@ -1792,40 +1988,80 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
           }
           const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
           const uint32_t col = idx - row * vcols;
-          const uint32_t slot_in_tile = (2u * wave + row) * PT_TILE + col;
-          Path Q;
-          start_sample(Q, load_camera_lds(cam_lds), pix_key[slot_in_tile], tx0 + col, ty0 + row, s_begin + s);
-          qd[lane] = Q.d.x;
-          qd[64 + lane] = Q.d.y;
-          qd[128 + lane] = Q.d.z;
-          qr[lane] = Q.rng;
-          qp[lane] = slot_in_tile;
+          pix_slot = row * PT_TILE + col;
+          start_sample(P, load_camera_lds(cam_lds), pix_key[pix_slot], tx0 + col, ty0 + row, s_begin + s);
+          hit.need_dir = false;
         }
-        made_jobs = min(made_jobs + 64u, pool);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        primary_trip = FILT_LDS;
       }
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-      const uint32_t job = next_job + rank;
-      if (!busy && job < made_jobs)
+    }
+    else
+    {
+      /* ---- hand out jobs to idle lanes: wave-synchronous, deterministic ----
+       * Idle lanes take jobs next_job, next_job + 1, ... in lane order.  The camera rays are
+       * not generated by the few lanes that happen to be idle (about a fifth of the wave per
+       * trip: start_sample would run on every trip at 20 % lane occupancy) but 64 at a time by
+       * the whole wave into a queue in LDS, from which idle lanes only copy. */
+      unsigned long long idle = __ballot(!busy);
+      while (idle != 0 && next_job < pool)
       {
-        const uint32_t q = job & 63u; /* batches start at multiples of 64 */
-        P.o = load_camera_pos_lds(cam_lds);
-        P.d = {qd[q], qd[64 + q], qd[128 + q]};
-        P.rng = qr[q];
-        pix_slot = qp[q];
-        P.T = {1, 1, 1};
-        P.Ls = {0, 0, 0};
-        P.depth = 0;
-        busy = true;
+        if (next_job == made_jobs)
+        {
+          /* queue empty: every lane, busy or not, prepares job made_jobs + lane */
+          const uint32_t job = made_jobs + lane;
+          if (job < pool)
+          {
+            DIAG(6, 1);
+            DIAG_LANES(7);
+            uint32_t idx, s;
+            if (n_valid == 16)
+            {
+              idx = job & 15u;
+              s = job >> 4;
+            }
+            else
+            {
+              s = job / n_valid;
+              idx = job - s * n_valid;
+            }
+            const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
+            const uint32_t col = idx - row * vcols;
+            const uint32_t slot_in_tile = (2u * wave + row) * PT_TILE + col;
+            Path Q;
+            start_sample(Q, load_camera_lds(cam_lds), pix_key[slot_in_tile], tx0 + col, ty0 + row, s_begin + s);
+            qd[lane] = Q.d.x;
+            qd[64 + lane] = Q.d.y;
+            qd[128 + lane] = Q.d.z;
+            qr[lane] = Q.rng;
+            qp[lane] = slot_in_tile;
+          }
+          made_jobs = min(made_jobs + 64u, pool);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        const uint32_t job = next_job + rank;
+        if (!busy && job < made_jobs)
+        {
+          const uint32_t q = job & 63u; /* batches start at multiples of 64 */
+          P.o = load_camera_pos_lds(cam_lds);
+          P.d = {qd[q], qd[64 + q], qd[128 + q]};
+          P.rng = qr[q];
+          pix_slot = qp[q];
+          P.T = {1, 1, 1};
+          P.Ls = {0, 0, 0};
+          P.depth = 0;
+          busy = true;
+        }
+        next_job = min(next_job + (uint32_t)__popcll(idle), made_jobs);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        idle = __ballot(!busy);
       }
-      next_job = min(next_job + (uint32_t)__popcll(idle), made_jobs);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      idle = __ballot(!busy);
     }
     if (__ballot(busy) == 0)
-      break; /* pool dry and every lane drained: the one exit, reached by all lanes together */
+      break; /* pool dry and every lane drained (an idle lane would have taken a waiting path): the one exit, reached by all lanes together */
+    const uint32_t *const prim_pairs = (SWAP && FILT_LDS && primary_trip) ? tile_pairs : nullptr;
 
     bool step_done = false;
     /* lanes still sampling a direction from an earlier trip sit this trip's step out */
@@ -1886,7 +2122,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         t_park[1][threadIdx.x] = P.T.y;
         t_park[2][threadIdx.x] = P.T.z;
         asm volatile("" ::: "memory"); /* no store-to-load forwarding: the values must leave the registers */
-        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit, prim_pairs);
         asm volatile("" ::: "memory");
         P.T = {t_park[0][threadIdx.x], t_park[1][threadIdx.x], t_park[2][threadIdx.x]};
         step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
@@ -1897,7 +2133,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 0, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 0, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit, prim_pairs);
     }
     /* ---- directions of diffuse hits: PT_DIR_ROUNDS rejection rounds per trip ----
      * A lane needs 1.91 rounds on average, but a loop that runs until the wave's last lane has
@@ -2025,16 +2261,33 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * 128u && PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u <= 128u, "ring bytes per wave");
 static_assert((PT_PARK_Q & (PT_PARK_Q - 1u)) == 0u && PT_PARK_WALK + 64u <= PT_PARK_Q, "ring size");
 
-/* entry-major: an entry is 128 contiguous bytes (13 doubles, then 4 words), so a lane's park or
- * resume touches one or two cache lines and the L2 merges its stores into whole-line write-backs */
-#define PT_PARK_ENTRY_F64 16u
+/* Entry-major, in three regions per wave, by who touches what:
+ *   HOT  [PT_PARK_Q] x 64 bytes: o, d, min_t, best, depth/pixel -- all the WALKER reads (one 64-byte line per ray) and
+ *        writes (min_t, best: the same line), and what a resume reads first;
+ *   COLD [PT_PARK_Q] x 32 bytes: T, RNG state -- written at the park, read at the resume, never seen by the walker;
+ *   CHK  [PT_PARK_Q] x 32 bytes: hit.u / hit.v state of the M_CHECKERED kernels (TriLast).
+ * Round 2 kept one 128-byte record per ray: the walker's loads pulled the cold half of every line through the L2 as
+ * well, and its 12-byte result dirtied a 128-byte line. */
 struct ParkRing
 {
-  double *f; /* [PT_PARK_Q][16]: fields 0..12 */
-  uint32_t *u; /* the same memory as words: [PT_PARK_Q][32], fields at words 26..29 */
+  double *f;   /* the wave's PT_PARK_Q x 128 bytes */
+  uint32_t *u; /* the same memory as words */
 };
-__device__ __forceinline__ uint32_t ring_fi(uint32_t field, uint32_t e) { return e * PT_PARK_ENTRY_F64 + field; }
-__device__ __forceinline__ uint32_t ring_ui(uint32_t field, uint32_t e) { return e * (2u * PT_PARK_ENTRY_F64) + 2u * PT_PARK_F64_FIELDS + field; }
+#ifdef PT_PARK_ONE_RECORD /* round 2's layout, for A/B */
+__device__ __forceinline__ uint32_t ring_fi(uint32_t field, uint32_t e) { return e * 16u + field; }
+__device__ __forceinline__ uint32_t ring_ui(uint32_t field, uint32_t e) { return e * 32u + 2u * PT_PARK_F64_FIELDS + field; }
+#else
+__device__ __forceinline__ uint32_t ring_fi(uint32_t field, uint32_t e)
+{ /* fields: 0-2 o, 3-5 d, 6-8 T, 9 rng, 10 min_t, 11-12 last u, v */
+  return field < 6u ? e * 8u + field
+                    : (field == 10u ? e * 8u + 6u
+                                    : (field < 10u ? PT_PARK_Q * 8u + e * 4u + (field - 6u) : PT_PARK_Q * 12u + e * 4u + (field - 11u)));
+}
+__device__ __forceinline__ uint32_t ring_ui(uint32_t field, uint32_t e)
+{ /* fields: 0 best, 1 depth << 6 | pixel slot (+ PT_DIAG flags), 2 last index */
+  return field < 2u ? e * 16u + 14u + field : PT_PARK_Q * 24u + e * 8u + 4u;
+}
+#endif
 
 /* ring loads bypass the vector L1 (agent-scope relaxed = `sc1`): a slot's earlier owner on this CU
  * may have left lines of it there */

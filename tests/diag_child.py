@@ -10,7 +10,7 @@ shim (RT_HIP_SHIM_PATH=.../librt_hip_diag.so, RT_HIP_DIAG_WALK_REJECTED=1) and p
   parked rays, parked rays the probe alone would have let through, rays that left a hull facet, leaf pre-tests.
 
 The PT_DIAG build is a checker's build of the product kernels, not the product: it never runs outside these tests.
-usage: diag_child.py SET   with SET in {configs, fuzz, convex, wide}"""
+usage: diag_child.py SET   with SET in {configs, fullsize, fuzz, convex, wide}"""
 import json
 import os
 import sys
@@ -27,6 +27,8 @@ def scene_sets(which):
     if which == "configs":   # BASELINE configurations 1-5, reduced
         return [("config %d" % c, S.build_scene(c, w, h, spp)) for c, w, h, spp in
                 [(1, 256, 256, 4), (2, 400, 300, 8), (3, 240, 136, 8), (4, 480, 270, 16), (5, 192, 108, 8)]]
+    if which == "fullsize":  # configurations 2-4 at their own image sizes (the tile cones of tile_cull are those of the bench), few samples
+        return [("config %d full size" % c, S.build_scene(c, samples=spp)) for c, spp in [(2, 4), (3, 2), (4, 2)]]
     if which == "fuzz":      # 6 random sphere scenes, 6 random mesh scenes (flat filter and hierarchy), the every-branch scene;
         # materials rotate so that the static (_refr), the pooled _chk and the plain kernel families all come up
         kinds = ["all", "no_glass", "plain"]

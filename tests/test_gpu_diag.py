@@ -1,8 +1,9 @@
 """The exhaustive checks of the kernels' CONSERVATIVE rules, in the driver's suite.
 
 The render kernels may skip exact fp64 tests only through rules that can never change an outcome: the packed-fp32
-phase-1 filter (three forms), the per-lane fp32 Moeller-Trumbore pre-test (small meshes and hierarchy leaves), the
-bounding-sphere probe in front of a hierarchy walk, and the hull-facet rule (a bounce that leaves a convex facet
+phase-1 filter (three forms), the per-tile culling of the primary trips' filter (tile_cull: primitives no camera ray of the
+tile can reach are not even looked at), the per-lane fp32 Moeller-Trumbore pre-test (small meshes and hierarchy leaves),
+the bounding-sphere probe in front of a hierarchy walk, and the hull-facet rule (a bounce that leaves a convex facet
 on its outer side is not walked).  Each rests on a hand-derived error bound (pt_kernel.hip: pt_build_filter,
 tri_may_hit32; rt_hip_shim.hip: mesh_bound_for, hull_margin_for).  The PT_DIAG build of the same kernels
 (`make shim-diag`, part of `make all`: raytracer.c_amd/csrc/librt_hip_diag.so) re-checks every application of every
@@ -77,3 +78,11 @@ def test_diag_convex_bodies_zero_violations():
     assert len(path) == 4
     for r in path:   # thousands of bounces off hull facets each -- all walked under RT_HIP_DIAG_WALK_REJECTED, none found a triangle
         assert r["left_hull_facet"] > 1000 and r["parked"] > 0, r
+
+
+def test_diag_full_size_tile_cones_zero_violations():
+    """configurations 2, 3, 4 at their own image sizes: the per-tile cones of the primary trips are the bench's"""
+    recs = _run("fullsize")
+    _no_violations(recs)
+    path = [r for r in recs if r["integrator"] == "path" and "skipped" not in r]
+    assert {r["kernel"] for r in path} == {"pt_render_tiles", "pt_render_tiles_tri"} and len(path) == 3
