@@ -609,11 +609,17 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
        * exact-then-rounded from the table, which also spares the walls' |L|^2 ~ 1e8 its fp32 rounding) */
       const f32x2 tca = __builtin_elementwise_fma(g.cz, dz, __builtin_elementwise_fma(g.cy, dy, __builtin_elementwise_fma(g.cx, dx, neg_od)));
       const f32x2 ll = __builtin_elementwise_fma(g.cz, m2oz, __builtin_elementwise_fma(g.cy, m2oy, __builtin_elementwise_fma(g.cx, m2ox, g.r2_hi + oo)));
-      const f32x2 q = __builtin_elementwise_fma(tca, tca, -ll);
+      /* ONE sign decides: q'' = tca |tca| - ll.  Where tca32 >= 0 it is q = tca^2 - ll, the reject "d2 > r2_hi" as
+       * before.  Where tca32 < 0 the reference rejects the sphere whatever q says (the pulled-back origin makes
+       * tca32' > 0 for every tca >= 0, scan_filtered), so any sign is right there: -tca^2 - ll is negative for an
+       * origin outside the sphere (ll > 0: dropped, as the tca test did) and may come out positive for an origin
+       * inside it (kept: the exact test rejects it).  Two single fmas with an |.| source modifier (packed
+       * instructions have none) replace one packed fma and the two ORs of the sign words. */
+      const float qx = __builtin_fmaf(tca.x, __builtin_fabsf(tca.x), -ll.x), qy = __builtin_fmaf(tca.y, __builtin_fabsf(tca.y), -ll.y);
       /* pairs arrive in DESCENDING order: shifting sign bits in leaves bit k = primitive k;
        * a set bit means DROP here, the word is inverted after the loop */
-      word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.y) | __float_as_uint(q.y), 31);
-      word = __builtin_amdgcn_alignbit(word, __float_as_uint(tca.x) | __float_as_uint(q.x), 31);
+      word = __builtin_amdgcn_alignbit(word, __float_as_uint(qy), 31);
+      word = __builtin_amdgcn_alignbit(word, __float_as_uint(qx), 31);
       return;
     }
     const f32x2 lx = g.cx - ox, ly = g.cy - oy, lz = g.cz - oz;
@@ -711,9 +717,9 @@ __device__ __forceinline__ void filter_chunk_listed(const f32x2 *__restrict__ fi
       const f32x2 cx = g[0], cy = g[1], cz = g[2], kq = g[5];
       const f32x2 tca = __builtin_elementwise_fma(cz, dz, __builtin_elementwise_fma(cy, dy, __builtin_elementwise_fma(cx, dx, neg_od)));
       const f32x2 ll = __builtin_elementwise_fma(cz, m2oz, __builtin_elementwise_fma(cy, m2oy, __builtin_elementwise_fma(cx, m2ox, kq + oo)));
-      const f32x2 q = __builtin_elementwise_fma(tca, tca, -ll);
-      /* a set sign bit of tca or q means DROP (filter_chunk) */
-      const uint32_t d0 = (__float_as_uint(tca.x) | __float_as_uint(q.x)) >> 31, d1 = (__float_as_uint(tca.y) | __float_as_uint(q.y)) >> 31;
+      /* a set sign bit of q'' = tca |tca| - ll means DROP (filter_chunk) */
+      const float qx = __builtin_fmaf(tca.x, __builtin_fabsf(tca.x), -ll.x), qy = __builtin_fmaf(tca.y, __builtin_fabsf(tca.y), -ll.y);
+      const uint32_t d0 = __float_as_uint(qx) >> 31, d1 = __float_as_uint(qy) >> 31;
       two = (d0 | (d1 << 1)) ^ 3u;
     }
     else
@@ -2336,26 +2342,51 @@ __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
   return 0xFFFFFFFFu;
 }
 
+/* The per-lane traversal stacks of the parked-walk kernels: 24-bit entries (a 16-bit and an 8-bit array, entry-major,
+ * one entry per tree level and lane), because at four workgroups per CU every kilobyte of LDS counts there.  A reference
+ * fits 24 bits while node indices stay below 2^23 and leaf references below 2^23 + 2^20 triangles (PT_WALK_REF_OK,
+ * checked on the host: other meshes take the lane-waiting kernels). */
+struct WalkStack
+{
+  uint16_t *lo; /* [levels][PT_BLOCK] */
+  uint8_t *hi;  /* [levels][PT_BLOCK] */
+};
+#define PT_WALK_LEAF_FLAG24 0x800000u
+__device__ __forceinline__ uint32_t walk_ref24(uint32_t ref) /* PT_BVH_LEAF_FLAG (bit 31) moves to bit 23 */
+{
+  return (ref & 0x7FFFFFu) | ((ref >> 8) & PT_WALK_LEAF_FLAG24);
+}
+__device__ __forceinline__ uint32_t walk_ref32(uint32_t r24) { return (r24 & 0x7FFFFFu) | ((r24 & PT_WALK_LEAF_FLAG24) << 8); }
+__device__ __forceinline__ void walk_push(const WalkStack &st, uint32_t sp, uint32_t ref)
+{
+  const uint32_t r = walk_ref24(ref);
+  st.lo[sp * PT_BLOCK + threadIdx.x] = (uint16_t)r;
+  st.hi[sp * PT_BLOCK + threadIdx.x] = (uint8_t)(r >> 16);
+}
+__device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp)
+{
+  return walk_ref32((uint32_t)st.lo[sp * PT_BLOCK + threadIdx.x] | ((uint32_t)st.hi[sp * PT_BLOCK + threadIdx.x] << 16));
+}
+
 /* The wave walks the n_new parked rays at ring positions first, first + 1, ... (see the header
  * comment): refill, then either one node visit for the lanes that hold an inner node or the exact
- * triangle tests of the lanes that hold a leaf, until every ray has its result in the ring. */
-/* own: this lane could not park its ray (ring full, or no workspace) and walks it from its own
- * registers here, alongside the parked ones -- the correctness path, not the fast one. */
+ * triangle tests of the lanes that hold a leaf, until every ray has its result in the ring.
+ * The caller has put every path the lanes held on the waiting list (render_tiles_queued): nothing of the trip loop
+ * is live in registers while the wave walks. */
 template <bool CHECKER>
 __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &ring, uint32_t first, uint32_t n_new,
-                                            uint32_t (*stack)[PT_BLOCK], unsigned long long *diag_ptr, bool own,
-                                            const V3 &own_o, const V3 &own_d, HitRec &own_hit)
+                                            const WalkStack &stack, unsigned long long *diag_ptr)
 {
   /* parked state written by this wave's lanes (plain stores) must have reached L2 before other
    * lanes load it: workgroup-scope release = s_waitcnt vmcnt(0) */
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   uint32_t next = 0; /* rays handed to lanes so far (wave-uniform) */
-  bool have = own;
+  bool have = false;
   uint32_t e = 0, sp = 0, ref = 0;
-  V3 wo = own_o, wd = own_d;
-  double wmin_t = own_hit.min_t, bu = 0, bv = 0;
-  int wbest = own_hit.best;
-  bool far_origin = !(v_dot(wo, wo) <= S.near_R2);
+  V3 wo = {0, 0, 0}, wd = {0, 0, 1};
+  double wmin_t = 0, bu = 0, bv = 0;
+  int wbest = -1;
+  bool far_origin = false;
   BvhRay R = bvh_ray(wo, wd);
   TriLast last = {-1, 0, 0};
   const bool no_prune = CHECKER && S.stale_uv;
@@ -2419,7 +2450,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         if (hit0 && hit1)
         {
           const bool zero_first = !(tn1 < tn0);
-          stack[sp][threadIdx.x] = zero_first ? r1 : r0;
+          walk_push(stack, sp, zero_first ? r1 : r0);
           sp++;
           ref = zero_first ? r0 : r1;
         }
@@ -2430,7 +2461,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         else
         {
           sp--;
-          ref = stack[sp][threadIdx.x];
+          ref = walk_pop(stack, sp);
         }
       }
     }
@@ -2461,7 +2492,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
       else
       {
         sp--;
-        ref = stack[sp][threadIdx.x];
+        ref = walk_pop(stack, sp);
       }
     }
     if (finished)
@@ -2476,24 +2507,13 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         atomicAdd(&diag_ptr[4 + 12], 1ull); /* a violation of the conservative probe */
       atomicAdd(&diag_ptr[4 + (visits <= 1u ? 19 : (visits <= 3u ? 20 : (visits <= 6u ? 21 : 22)))], 1ull);
 #endif
-      if (own)
+      ring_st(ring, 10u, e, wmin_t);
+      ring_stu(ring, 0u, e, (uint32_t)wbest);
+      if (CHECKER)
       {
-        own_hit.min_t = wmin_t;
-        own_hit.best = wbest;
-        if (CHECKER)
-          own_hit.last = last;
-        own = false;
-      }
-      else
-      {
-        ring_st(ring, 10u, e, wmin_t);
-        ring_stu(ring, 0u, e, (uint32_t)wbest);
-        if (CHECKER)
-        {
-          ring_stu(ring, 2u, e, (uint32_t)last.idx);
-          ring_st(ring, 11u, e, last.u);
-          ring_st(ring, 12u, e, last.v);
-        }
+        ring_stu(ring, 2u, e, (uint32_t)last.idx);
+        ring_st(ring, 11u, e, last.u);
+        ring_st(ring, 12u, e, last.v);
       }
       have = false;
     }
@@ -2508,30 +2528,42 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   /* ONE WAVE = ONE TILE here (a workgroup = four tiles, its waves independent of each other between the
    * barrier after staging and the one before the slot goes back): a wave's pool is its tile's 64 pixels
-   * x samples, four times the 16-pixel strips of the pooled body, so the tail in which the last paths of a
+   * x samples, four times the 16-pixel strips of round 2's pooled body, so the tail in which the last paths of a
    * pool run on with most lanes idle -- each walk costs a park / walk / resume cycle, so the tail is long in
    * these kernels -- weighs a quarter as much.  (The image is 4K-sized or the scene's cost per ray is high
    * wherever these kernels run, so a quarter as many workgroups still fill the chip many times over.) */
   __shared__ unsigned long long pix_sum_all[PT_BLOCK / 64][PT_TILE_PIXELS * 3];
   __shared__ unsigned long long pix_nan_all[PT_BLOCK / 64][3];
-  __shared__ double q_dir[PT_BLOCK / 64][3 * 64];
-  __shared__ unsigned long long q_rng[PT_BLOCK / 64][64];
-  __shared__ uint32_t q_pix[PT_BLOCK / 64][64];
   __shared__ uint32_t park_slot_lds;
   __shared__ double cam_lds[PT_CAM_LDS_DOUBLES]; /* the camera (camera_to_lds) */
-  /* walked rays on their way back into lanes: PT_STAGE at a time are copied from the ring into LDS
-   * (one memory round trip for the batch) and handed out from there -- a few idle lanes taking them
-   * straight from the ring would put that round trip at the head of every trip */
-  constexpr uint32_t STAGE_F = CHECKER ? 13u : 11u, STAGE_U = CHECKER ? 3u : 2u;
-  __shared__ double st_f[PT_BLOCK / 64][STAGE_F][PT_STAGE];
-  __shared__ uint32_t st_u[PT_BLOCK / 64][STAGE_U][PT_STAGE];
+  /* The wave's WAITING LIST in LDS: up to 64 paths that wait for a lane (render_tiles_pooled's, with two more
+   * tenants).  Who puts paths there: (1) the SWAP -- idle lanes, an empty list, jobs left: every busy lane leaves
+   * its path here and all 64 lanes start fresh camera samples, a PRIMARY trip; (2) walked rays on their way back:
+   * up to 64 at a time are copied from the ring in memory (one round trip for the batch; a few idle lanes taking
+   * them straight from the ring would put that round trip at the head of every trip) and resume with the second
+   * half of trace_step; (3) every path the lanes hold when the wave turns to WALKING the parked rays: the walk
+   * needs the registers, and with the paths in LDS nothing of the trip loop is live while it runs -- round 2's kernel
+   * spilled 136 bytes per lane to scratch memory around the walk, 40 GB per 4K x 256 spp frame.
+   * Entry: o, d, T, RNG state, min_t of a scanned ray (or the checker factor of a pending direction) [+ hit.u / hit.v
+   * state]; meta word; best of a scanned ray or material slot of a pending direction. */
+  constexpr uint32_t WAIT_F = CHECKER ? 13u : 11u, WAIT_U = CHECKER ? 3u : 2u;
+  __shared__ double w_f[PT_BLOCK / 64][WAIT_F][64];
+  __shared__ uint32_t w_u[PT_BLOCK / 64][WAIT_U][64];
+  /* meta: pixel slot (6 bits), then: a direction is still to be sampled; a walked ray (scan result known, second half
+   * next); the ray leaves a hull facet for good; a scanned ray that found the ring full and waits to be parked (scan
+   * result known, park next); then the depth */
+  constexpr uint32_t META_NEED_DIR = 64u, META_RESUMED = 128u, META_LEAVING = 256u, META_WAITING = 512u, META_DEPTH_SHIFT = 10u;
 
   const SceneCtx S = stage_scene<true, FILT_LDS, true>(L, lds);
   /* the traversal stacks follow the staged scene (geometry, materials, the spheres' filter pairs) in dynamic LDS:
-   * one entry per tree level and lane */
-  uint32_t (*const stack)[PT_BLOCK] = reinterpret_cast<uint32_t (*)[PT_BLOCK]>(
-      lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
-             pt_filt_pair_slots(S.n_sph)));
+   * one 24-bit entry per tree level and lane (WalkStack) */
+  WalkStack stack;
+  {
+    const uint32_t levels = max(L.scene.bvh_depth, 1u);
+    stack.lo = reinterpret_cast<uint16_t *>(lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
+                                                   pt_filt_pair_slots(S.n_sph)));
+    stack.hi = reinterpret_cast<uint8_t *>(stack.lo + (size_t)levels * PT_BLOCK);
+  }
   {
     unsigned long long *z = &pix_sum_all[0][0];
     for (uint32_t k = threadIdx.x; k < (PT_BLOCK / 64) * PT_TILE_PIXELS * 3; k += PT_BLOCK)
@@ -2559,16 +2591,25 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   const uint32_t s_begin = (uint32_t)(((uint64_t)chunk * spp) / L.sample_chunks);
   const uint32_t s_end = (uint32_t)(((uint64_t)(chunk + 1u) * spp) / L.sample_chunks);
   const uint32_t pool = has_unit ? n_valid * (s_end - s_begin) : 0u;
-  unsigned long long *const pix_sum = pix_sum_all[wave];
-  unsigned long long *const pix_nan = pix_nan_all[wave];
+  /* wave-uniform addresses and tile numbers that the trip loop needs now and then are formed where they are used, from
+   * a wave index the compiler cannot see through (wave_now): hoisted out of the loop they each hold a vector register for
+   * its whole length -- the kernel has none to spare at four waves per SIMD, they were what it spilled */
+  auto wave_now = [] {
+    uint32_t w = threadIdx.x >> 6;
+    asm volatile("" : "+v"(w));
+    return w;
+  };
   const uint32_t park_slot = park_slot_lds;
-  const bool ring_ok = park_slot != 0xFFFFFFFFu;
   ParkRing ring;
   {
-    char *base = L.park_ws + ((size_t)(ring_ok ? park_slot : 0u) * (PT_BLOCK / 64) + wave) * PT_PARK_WAVE_BYTES;
+    /* (the launcher takes these kernels only with a workspace: pt_launch_render; a slot can be missing only through
+     * a sizing bug of the pool, never seen -- then nothing can be parked, and rays that want a walk would wait for
+     * ever: the kernel gives up its tile instead, visibly: see `ring_ok` below) */
+    char *base = L.park_ws + ((size_t)(park_slot != 0xFFFFFFFFu ? park_slot : 0u) * (PT_BLOCK / 64) + wave) * PT_PARK_WAVE_BYTES;
     ring.f = reinterpret_cast<double *>(base);
     ring.u = reinterpret_cast<uint32_t *>(base);
   }
+  const bool ring_ok = park_slot != 0xFFFFFFFFu;
 
   Path P;
   P.o = {0, 0, 0};
@@ -2591,143 +2632,213 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   hit.last.idx = -1;
   hit.last.u = 0;
   hit.last.v = 0;
-  uint32_t next_job = 0, made_jobs = 0; /* wave-uniform, as in render_tiles_pooled */
+  uint32_t next_job = 0;                    /* camera samples started so far (wave-uniform) */
   uint32_t head = 0, n_done = 0, n_new = 0; /* the ring (wave-uniform) */
-  uint32_t n_stage = 0, stage_off = 0;      /* walked rays staged in LDS: ring positions head .. head + n_stage (wave-uniform) */
+  uint32_t n_wait = 0;                      /* paths on the waiting list (wave-uniform) */
   uint32_t pix_slot = 0;
   bool busy = false;
+  bool waiting = false; /* the lane's ray is scanned and wants a walk, but the ring was full: park it next trip */
   int stack_n = 0;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
   const uint32_t lane = threadIdx.x & 63u;
-  double *const qd = q_dir[wave];
-  unsigned long long *const qr = q_rng[wave];
-  uint32_t *const qp = q_pix[wave];
+  double *const wf = &w_f[wave][0][0];
+  uint32_t *const wu = &w_u[wave][0][0];
+
+  /* a busy lane's path -> list entry e (the swap, and before a walk) */
+  auto put_on_list = [&](uint32_t e, bool resumed_now) {
+    wf[0 * 64 + e] = P.o.x; wf[1 * 64 + e] = P.o.y; wf[2 * 64 + e] = P.o.z;
+    wf[3 * 64 + e] = P.d.x; wf[4 * 64 + e] = P.d.y; wf[5 * 64 + e] = P.d.z;
+    wf[6 * 64 + e] = P.T.x; wf[7 * 64 + e] = P.T.y; wf[8 * 64 + e] = P.T.z;
+    wf[9 * 64 + e] = __longlong_as_double((long long)P.rng);
+    uint32_t meta = ((uint32_t)P.depth << META_DEPTH_SHIFT) | (hit.need_dir ? META_NEED_DIR : 0u) | (hit.leaving ? META_LEAVING : 0u) | pix_slot;
+    if (resumed_now || waiting)
+    { /* the scan's result travels with the ray */
+      meta |= resumed_now ? META_RESUMED : META_WAITING;
+      wf[10 * 64 + e] = hit.min_t;
+      wu[64 + e] = (uint32_t)hit.best;
+      if (CHECKER)
+      {
+        wf[(CHECKER ? 11 : 0) * 64 + e] = hit.last.u;
+        wf[(CHECKER ? 12 : 0) * 64 + e] = hit.last.v;
+        wu[(CHECKER ? 2 : 0) * 64 + e] = (uint32_t)hit.last.idx;
+      }
+    }
+    else
+    {
+      wu[64 + e] = hit.dir_slot;
+      if (CHECKER)
+        wf[10 * 64 + e] = hit.dir_scale;
+    }
+    wu[e] = meta;
+  };
 
   for (;;)
   {
-    /* ---- idle lanes take work: walked rays first (that frees the ring), then camera samples ---- */
+    /* ---- idle lanes take work: waiting paths first (walked rays among them: that frees the ring), then, when the
+     * list and the ring's walked part are empty, the swap (render_tiles_pooled) ---- */
     unsigned long long idle = __ballot(!busy);
     bool resumed = false;
-    while (idle != 0 && n_done != 0u)
+    bool primary_trip = false; /* wave-uniform */
+    for (int pass = 0; pass < 2 && idle != 0; pass++)
     {
-      if (n_stage == 0u)
+      if (n_wait == 0u && n_done != 0u)
       {
-        /* stage the next walked rays: lane l copies ring entry head + l */
-        const uint32_t k = min(PT_STAGE, n_done);
+        /* the next walked rays: lane l copies ring entry head + l to list entry l */
+        const uint32_t k = min(64u, n_done);
         if (lane < k)
         {
           const uint32_t e = (head + lane) & (PT_PARK_Q - 1u);
-          for (uint32_t f = 0; f < STAGE_F; f++)
-            st_f[wave][f][lane] = ring_ld(ring, f, e);
-          for (uint32_t f = 0; f < STAGE_U; f++)
-            st_u[wave][f][lane] = ring_ldu(ring, f, e);
+          for (uint32_t f = 0; f < 11u; f++)
+            wf[f * 64u + lane] = ring_ld(ring, f, e);
+          wu[64u + lane] = ring_ldu(ring, 0u, e); /* best */
+          const uint32_t dp = ring_ldu(ring, 1u, e) & 0x3FFFFFFFu; /* depth << 6 | pixel slot; bits 31, 30: PT_DIAG's flags */
+          wu[lane] = (dp & 63u) | META_RESUMED | ((dp >> 6) << META_DEPTH_SHIFT);
+          if (CHECKER)
+          {
+            wf[(CHECKER ? 11u : 0u) * 64u + lane] = ring_ld(ring, 11u, e);
+            wf[(CHECKER ? 12u : 0u) * 64u + lane] = ring_ld(ring, 12u, e);
+            wu[(CHECKER ? 2u : 0u) * 64u + lane] = ring_ldu(ring, 2u, e);
+          }
         }
-        n_stage = k;
-        stage_off = 0u;
+        n_wait = k;
+        head = (head + k) & (PT_PARK_Q - 1u);
+        n_done -= k;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+      if (n_wait == 0u)
+        break;
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-      const uint32_t take = min((uint32_t)__popcll(idle), n_stage);
-      if (!busy && rank < take)
+      if (!busy && rank < n_wait)
       {
-        const uint32_t q = stage_off + rank;
-        P.o = {st_f[wave][0][q], st_f[wave][1][q], st_f[wave][2][q]};
-        P.d = {st_f[wave][3][q], st_f[wave][4][q], st_f[wave][5][q]};
-        P.T = {st_f[wave][6][q], st_f[wave][7][q], st_f[wave][8][q]};
-        P.rng = (uint64_t)__double_as_longlong(st_f[wave][9][q]);
-        hit.min_t = st_f[wave][10][q];
-        hit.best = (int)st_u[wave][0][q];
-        const uint32_t dp = st_u[wave][1][q] & 0x3FFFFFFFu; /* bits 31, 30: PT_DIAG's flags */
-        P.depth = (int)(dp >> 6);
-        pix_slot = dp & 63u;
-        if (CHECKER)
-        {
-          hit.last.idx = (int)st_u[wave][CHECKER ? 2 : 0][q];
-          hit.last.u = st_f[wave][CHECKER ? 11 : 0][q];
-          hit.last.v = st_f[wave][CHECKER ? 12 : 0][q];
-        }
+        const uint32_t e = n_wait - 1u - rank;
+        P.o = {wf[0 * 64 + e], wf[1 * 64 + e], wf[2 * 64 + e]};
+        P.d = {wf[3 * 64 + e], wf[4 * 64 + e], wf[5 * 64 + e]};
+        P.T = {wf[6 * 64 + e], wf[7 * 64 + e], wf[8 * 64 + e]};
+        P.rng = (uint64_t)__double_as_longlong(wf[9 * 64 + e]);
+        const double f10 = wf[10 * 64 + e];
+        const uint32_t meta = wu[e], w1 = wu[64 + e];
+        pix_slot = meta & 63u;
+        P.depth = (int)(meta >> META_DEPTH_SHIFT);
         P.Ls = {0, 0, 0};
-        hit.depth_ok = true;
-        hit.need_dir = false;
+        hit.need_dir = (meta & META_NEED_DIR) != 0u;
+        hit.leaving = (meta & META_LEAVING) != 0u;
+        waiting = (meta & META_WAITING) != 0u;
+        if (meta & (META_RESUMED | META_WAITING))
+        { /* the scan's result is known: a walked ray goes on with the second half, a waiting one with the park */
+          hit.min_t = f10;
+          hit.best = (int)w1;
+          hit.depth_ok = true;
+          if (CHECKER)
+          {
+            hit.last.u = wf[(CHECKER ? 11 : 0) * 64 + e];
+            hit.last.v = wf[(CHECKER ? 12 : 0) * 64 + e];
+            hit.last.idx = (int)wu[(CHECKER ? 2 : 0) * 64 + e];
+          }
+          resumed = (meta & META_RESUMED) != 0u;
+        }
+        else
+        {
+          hit.dir_slot = w1;
+          if (CHECKER)
+            hit.dir_scale = f10;
+        }
         busy = true;
-        resumed = true;
       }
-      stage_off += take;
-      n_stage -= take;
-      head = (head + take) & (PT_PARK_Q - 1u);
-      n_done -= take;
+      n_wait -= min((uint32_t)__popcll(idle), n_wait);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       idle = __ballot(!busy);
     }
-    while (idle != 0 && next_job < pool)
+    /* enough rays are parked (or the ring is full): the wave owes them a walk.  It happens as soon as the list is
+     * empty -- every live path is then in a lane and the list can take them all; until then no swap brings new paths */
+    const bool walk_due = n_new >= PT_PARK_WALK || n_new + n_done >= PT_PARK_Q;
+    if (!walk_due && idle != 0 && n_wait == 0u && n_done == 0u && next_job < pool)
     {
-      if (next_job == made_jobs)
+      /* the swap: busy lanes leave their paths on the list, all 64 lanes start fresh camera samples */
+      const unsigned long long bm = __ballot(busy);
+      if (busy)
+        put_on_list(__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)), resumed);
+      n_wait = (uint32_t)__popcll(bm);
+      resumed = false;
+      waiting = false;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t job = next_job + lane;
+      busy = job < pool;
+      if (busy)
       {
-        const uint32_t job = made_jobs + lane;
-        if (job < pool)
+        DIAG(6, 1);
+        DIAG_LANES(7);
+        uint32_t idx, s;
+        if (n_valid == PT_TILE_PIXELS)
         {
-          DIAG(6, 1);
-          DIAG_LANES(7);
-          uint32_t idx, s;
-          if (n_valid == PT_TILE_PIXELS)
-          {
-            idx = job & 63u;
-            s = job >> 6;
-          }
-          else
-          {
-            s = job / n_valid;
-            idx = job - s * n_valid;
-          }
-          const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
-          const uint32_t col = idx - row * vcols;
-          const uint32_t slot_in_tile = row * PT_TILE + col;
-          Path Q;
-          start_sample(Q, load_camera_lds(cam_lds), rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col),
-                       tx0 + col, ty0 + row, s_begin + s);
-          qd[lane] = Q.d.x;
-          qd[64 + lane] = Q.d.y;
-          qd[128 + lane] = Q.d.z;
-          qr[lane] = Q.rng;
-          qp[lane] = slot_in_tile;
+          idx = job & 63u;
+          s = job >> 6;
         }
-        made_jobs = min(made_jobs + 64u, pool);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-      const uint32_t job = next_job + rank;
-      if (!busy && job < made_jobs)
-      {
-        const uint32_t q = job & 63u;
-        P.o = load_camera_pos_lds(cam_lds);
-        P.d = {qd[q], qd[64 + q], qd[128 + q]};
-        P.rng = qr[q];
-        pix_slot = qp[q];
-        P.T = {1, 1, 1};
-        P.Ls = {0, 0, 0};
-        P.depth = 0;
+        else
+        {
+          s = job / n_valid;
+          idx = job - s * n_valid;
+        }
+        const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
+        const uint32_t col = idx - row * vcols;
+        pix_slot = row * PT_TILE + col;
+        start_sample(P, load_camera_lds(cam_lds), rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col),
+                     tx0 + col, ty0 + row, s_begin + s);
         hit.need_dir = false;
         hit.leaving = false;
-        busy = true;
       }
-      next_job = min(next_job + (uint32_t)__popcll(idle), made_jobs);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      idle = __ballot(!busy);
+      next_job = min(next_job + 64u, pool);
+      primary_trip = true;
     }
-    /* nobody holds a ray: the pool is dry and no walked ray is left (an idle lane would have taken
-     * it).  Parked rays, if any, are walked in this trip; otherwise this is the one exit. */
+    (void)primary_trip;
+    /* nobody holds a ray: the pool is dry, the list and the ring's walked part are empty (an idle lane would have
+     * taken from them).  Parked rays, if any, are walked now; otherwise this is the one exit. */
     const bool drained = __ballot(busy) == 0;
     if (drained && n_new == 0u)
       break;
+    if (!ring_ok)
+      break; /* no workspace slot (see above): the tile stays unrendered rather than the wave spinning */
+
+    /* ---- the wave turns to walking: every path the lanes hold goes to the list first, so that nothing of this
+     * loop is live in registers while walk_parked runs ---- */
+    if (drained || (walk_due && n_wait == 0u))
+    {
+      const unsigned long long bm = __ballot(busy);
+      if (busy)
+        put_on_list(__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)), resumed);
+      n_wait = (uint32_t)__popcll(bm);
+      busy = false;
+      waiting = false;
+      /* the lanes' paths are dead from here (they come back from the list): say so to the register allocator */
+      P.o = {0, 0, 0};
+      P.d = {0, 0, 1};
+      P.T = {1, 1, 1};
+      P.rng = 1;
+      P.depth = 0;
+      pix_slot = 0;
+      hit.min_t = 0;
+      hit.best = -1;
+      hit.need_dir = false;
+      hit.leaving = false;
+      hit.dir_slot = 0;
+      hit.dir_scale = 1.0;
+      hit.last.idx = -1;
+      hit.last.u = 0;
+      hit.last.v = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      walk_parked<CHECKER>(S, ring, (head + n_done) & (PT_PARK_Q - 1u), n_new, stack, diag_ptr);
+      n_done += n_new;
+      n_new = 0u;
+      continue;
+    }
 
     /* ---- first half of trace_path(): depth test + flat scan over the spheres, then the probe ---- */
-    const bool stepping = busy && !hit.need_dir && !resumed;
-    bool want_walk = false;
+    const bool stepping = busy && !hit.need_dir && !resumed && !waiting;
+    bool want_walk = waiting;
 #ifdef PT_DIAG
     bool diag_in_sphere = true;
 #endif
@@ -2759,56 +2870,54 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
                                           (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound);
 #endif
     }
-    /* ---- rays that can reach the mesh are parked; their lanes are idle from here on ---- */
+    /* ---- rays that can reach the mesh are parked; their lanes are idle from here on.  A ray that finds the ring
+     * full keeps its lane and its scan result and tries again next trip (`waiting`): a full ring makes the walk due,
+     * so room comes within a few trips ---- */
     const unsigned long long wants = __ballot(want_walk);
-    bool parked = false;
     if (wants != 0)
     {
-      if (ring_ok)
+      const uint32_t space = PT_PARK_Q - n_done - n_new;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
+      if (want_walk && rank < space)
       {
-        const uint32_t space = PT_PARK_Q - n_done - n_new;
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wants >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wants, 0u));
-        if (want_walk && rank < space)
-        {
-          const uint32_t e = (head + n_done + n_new + rank) & (PT_PARK_Q - 1u);
-          ring_st3(ring, 0u, e, P.o);
-          ring_st3(ring, 3u, e, P.d);
-          ring_st3(ring, 6u, e, P.T);
-          ring_st(ring, 9u, e, __longlong_as_double((long long)P.rng));
-          ring_st(ring, 10u, e, hit.min_t);
-          ring_stu(ring, 0u, e, (uint32_t)hit.best);
+        const uint32_t e = (head + n_done + n_new + rank) & (PT_PARK_Q - 1u);
+        ring_st3(ring, 0u, e, P.o);
+        ring_st3(ring, 3u, e, P.d);
+        ring_st3(ring, 6u, e, P.T);
+        ring_st(ring, 9u, e, __longlong_as_double((long long)P.rng));
+        ring_st(ring, 10u, e, hit.min_t);
+        ring_stu(ring, 0u, e, (uint32_t)hit.best);
 #ifdef PT_DIAG
-          const double diag_lx = (double)S.mesh_bound.cx - P.o.x, diag_ly = (double)S.mesh_bound.cy - P.o.y,
-                       diag_lz = (double)S.mesh_bound.cz - P.o.z; /* bit 30: the ray starts inside the bounding ball */
-          const bool diag_origin_inside = diag_lx * diag_lx + diag_ly * diag_ly + diag_lz * diag_lz <= (double)S.mesh_bound.r2_hi;
-          ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot | (diag_in_sphere ? 0u : 0x80000000u) |
-                                    (diag_origin_inside ? 0x40000000u : 0u));
-          if (diag_in_sphere)
-            DIAG_LANES(23);
+        const double diag_lx = (double)S.mesh_bound.cx - P.o.x, diag_ly = (double)S.mesh_bound.cy - P.o.y,
+                     diag_lz = (double)S.mesh_bound.cz - P.o.z; /* bit 30: the ray starts inside the bounding ball */
+        const bool diag_origin_inside = diag_lx * diag_lx + diag_ly * diag_ly + diag_lz * diag_lz <= (double)S.mesh_bound.r2_hi;
+        /* (a ray that waited a trip for room lost its diag_in_sphere: it counts as inside, i.e. is not checked) */
+        ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot | ((diag_in_sphere || waiting) ? 0u : 0x80000000u) |
+                                  (diag_origin_inside ? 0x40000000u : 0u));
+        if (diag_in_sphere)
+          DIAG_LANES(23);
 #else
-          ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot);
+        ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot);
 #endif
-          parked = true;
-          busy = false;
-          DIAG_LANES(17);
+        if (CHECKER)
+        { /* (the walk overwrites these; a defined value for rays it finds nothing for) */
+          ring_stu(ring, 2u, e, (uint32_t)hit.last.idx);
+          ring_st(ring, 11u, e, hit.last.u);
+          ring_st(ring, 12u, e, hit.last.v);
         }
-        n_new += min((uint32_t)__popcll(wants), space);
+        waiting = false;
+        busy = false;
+        DIAG_LANES(17);
       }
-    }
-    /* ---- the wave turns to walking: enough rays parked, nothing else to do, or a ray that found no
-     * room in the ring (it is walked from its lane's registers, in the same pass) ---- */
-    const bool walk_own = want_walk && !parked;
-    if (n_new >= PT_PARK_WALK || drained || __ballot(walk_own) != 0)
-    {
-      walk_parked<CHECKER>(S, ring, (head + n_done) & (PT_PARK_Q - 1u), n_new, stack, diag_ptr, walk_own, P.o, P.d, hit);
-      n_done += n_new;
-      n_new = 0u;
+      else if (want_walk)
+        waiting = true;
+      n_new += min((uint32_t)__popcll(wants), space);
     }
 
     /* ---- second half: hit record, roulette, material -- for rays scanned now and not parked, and for
      * walked rays resumed at the top of this trip ---- */
     bool step_done = false;
-    if (busy && (stepping || resumed))
+    if (busy && (stepping || resumed) && !waiting)
       step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
 
     /* ---- directions of diffuse hits (see render_tiles_pooled) ---- */
@@ -2843,11 +2952,13 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
        * associate: the sum does not depend on the order or the grouping of the terms) */
       if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
+        unsigned long long *const pix_sum = pix_sum_all[wave_now()];
         atomicAdd(&pix_sum[3 * pix_slot + 0], fixed_term(P.Ls.x, L.acc_scale));
         atomicAdd(&pix_sum[3 * pix_slot + 1], fixed_term(P.Ls.y, L.acc_scale));
         atomicAdd(&pix_sum[3 * pix_slot + 2], fixed_term(P.Ls.z, L.acc_scale));
         if ((int)(P.Ls.x != P.Ls.x) | (int)(P.Ls.y != P.Ls.y) | (int)(P.Ls.z != P.Ls.z))
         {
+          unsigned long long *const pix_nan = pix_nan_all[wave_now()];
           if (P.Ls.x != P.Ls.x) atomicOr(&pix_nan[0], 1ull << pix_slot);
           if (P.Ls.y != P.Ls.y) atomicOr(&pix_nan[1], 1ull << pix_slot);
           if (P.Ls.z != P.Ls.z) atomicOr(&pix_nan[2], 1ull << pix_slot);
@@ -2862,6 +2973,15 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   /* ---- this wave's tile: counters, then the pixels (thread = pixel) ---- */
   if (has_unit)
   {
+    /* the tile's numbers once more (see wave_now) */
+    const uint32_t unit_e = blockIdx.x * (PT_BLOCK / 64) + wave_now();
+    const uint32_t slot = unit_e % L.tile_count, chunk = unit_e / L.tile_count;
+    const uint32_t tile_e = L.tile_first + slot * L.tile_stride;
+    const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - (tile_e % L.tiles_x) * PT_TILE);
+    const uint32_t vrows = min((uint32_t)PT_TILE, (uint32_t)L.height - (tile_e / L.tiles_x) * PT_TILE);
+    const uint32_t n_valid = vcols * vrows;
+    unsigned long long *const pix_sum = pix_sum_all[wave_now()];
+    unsigned long long *const pix_nan = pix_nan_all[wave_now()];
     uint32_t rays_w = n_rays, casts_w = n_casts;
     for (int off = 32; off > 0; off >>= 1)
     {
@@ -3480,9 +3600,10 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
     which = cast_ray ? 18 : 17;
   else if (variant == 0 && !refr && !cast_ray)
     which = 12;
-  else if ((which == 3 || which == 7) && variant != 2 && !scene.wide_range)
-    which = which == 3 ? (scene.mesh_round ? 21 : 19) : 20; /* hierarchy scenes: parked walks (variant 2, and scenes beyond fp32's comfortable range,
-                                   * whose filter needs the NaN-safe compares, keep the lane-waiting pooled kernels) */
+  else if ((which == 3 || which == 7) && variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) && scene.n_triangles < (1u << 20))
+    which = which == 3 ? (scene.mesh_round ? 21 : 19) : 20; /* hierarchy scenes: parked walks (variant 2, scenes beyond fp32's comfortable range,
+                                   * whose filter needs the NaN-safe compares, and meshes whose references do not fit the walk's
+                                   * 24-bit stack entries keep the lane-waiting pooled kernels) */
   if (name)
     *name = names[which];
   return which;
@@ -3545,11 +3666,13 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
                                     pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
                                     pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem,
                                     pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph};
-  const int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr);
+  int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr);
+  if (which >= 19 && (launch.park_ws == nullptr || launch.park_slots_per_xcd == 0u))
+    which = which == 20 ? 7 : 3; /* no ring workspace (its allocation failed): the lane-waiting kernels need none */
   const Kernel kernel = family[which];
-  if (which >= 19) /* the spheres' filter pairs, then per-lane traversal stacks sized by the tree, after the staged scene */
+  if (which >= 19) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
-                 (size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * sizeof(uint32_t);
+                 (((size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u);
   if (lds_bytes > 64 * 1024)
   { /* the attribute belongs to the (kernel, current device) pair: set whenever it is needed -- a process-wide
      * "already raised" note would skip devices 1..N-1 of the multi-device path (round-2 advisor finding) */
