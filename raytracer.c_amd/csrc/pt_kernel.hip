@@ -750,21 +750,27 @@ __device__ __forceinline__ void filter_chunk_listed(const f32x2 *__restrict__ fi
  *   theta of the centre direction a that the farthest corner makes.  A ray from pos with direction within theta of a
  *   can touch the ball (c, R) only if the angle between a and c - pos is at most theta + asin(R / |c - pos|) (or pos is
  *   inside the ball).  R is the sphere's radius, or the radius of a triangle's bounding sphere (entry_src).  Everything
- *   in fp64 (errors ~1e-15 relative) with margins of 1e-5 in the radius, in cos(theta) and in the final comparison:
- *   conservative by ten orders of magnitude over the fp64 rounding of the exact tests that decide, which can accept
- *   nothing farther than ~1e-12 |c| outside a primitive.  Non-finite anything: keep.  (The PT_DIAG build re-checks
+ *   in fp64, square roots and quotients through the hardware's ~2^-26 seeds (errors ~1e-7 relative in all), with margins
+ *   of 1e-5 in the radius, in cos(theta) and in the final comparison: conservative by orders of magnitude over both that
+ *   and the fp64 rounding of the exact tests that decide, which can accept nothing farther than ~1e-12 |c| outside a
+ *   primitive.  Non-finite anything: keep.  (The PT_DIAG build re-checks
  *   every primitive dropped this way with the exact test, like every other dropped primitive.) */
 __device__ __forceinline__ void tile_cull(const double *cam_lds, const double *entry_src, uint32_t n_sph, uint32_t n_entries,
                                           uint32_t tx0, uint32_t ty0, uint32_t *pairs)
 {
+  /* 1 / sqrt and 1 / x from the hardware's seed instructions (v_rsq_f64, v_rcp_f64: ~2^-26 relative): the margins
+   * below are 1e-5, and the correctly rounded expansions of ten square roots and divisions cost several hundred
+   * instructions per workgroup -- 2 % of a low-spp frame */
+  auto rsq = [](double x) { return __builtin_amdgcn_rsq(x); };
+  auto root = [&](double x) { return x > 0.0 ? x * rsq(x) : 0.0; };
   const uint32_t i = threadIdx.x;
   bool keep = false;
   if (i < n_entries)
   {
     const V3 pos = {cam_lds[0], cam_lds[1], cam_lds[2]}, Hh = {cam_lds[3], cam_lds[4], cam_lds[5]},
              Vv = {cam_lds[6], cam_lds[7], cam_lds[8]}, llc = {cam_lds[9], cam_lds[10], cam_lds[11]};
-    const double u0 = (double)tx0 / cam_lds[12], u1 = (double)(tx0 + PT_TILE) / cam_lds[12];
-    const double v0 = (double)ty0 / cam_lds[13], v1 = (double)(ty0 + PT_TILE) / cam_lds[13];
+    const double u0 = (double)tx0 * cam_lds[14], u1 = (double)(tx0 + PT_TILE) * cam_lds[14]; /* x 1 / (W - 1), 1 / (H - 1) */
+    const double v0 = (double)ty0 * cam_lds[15], v1 = (double)(ty0 + PT_TILE) * cam_lds[15];
     V3 w[4];
     for (int k = 0; k < 4; k++)
     {
@@ -772,23 +778,23 @@ __device__ __forceinline__ void tile_cull(const double *cam_lds, const double *e
       w[k] = v_sub(pos, v_add(llc, v_add(v_scale(Hh, u), v_scale(Vv, v))));
     }
     V3 a = v_add(v_add(w[0], w[1]), v_add(w[2], w[3]));
-    a = v_scale(a, 1.0 / sqrt(v_dot(a, a)));
+    a = v_scale(a, rsq(v_dot(a, a)));
     double cos_t = 1.0;
     for (int k = 0; k < 4; k++)
-      cos_t = fmin(cos_t, v_dot(a, w[k]) / sqrt(v_dot(w[k], w[k])));
+      cos_t = fmin(cos_t, v_dot(a, w[k]) * rsq(v_dot(w[k], w[k])));
     cos_t -= 1e-5;
-    const double sin_t = sqrt(fmax(0.0, 1.0 - cos_t * cos_t));
+    const double sin_t = root(1.0 - cos_t * cos_t);
     const double *e = entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz R2 |c| Rb */
-    const double R = (i < n_sph ? sqrt(e[3]) : e[5]) * (1.0 + 1e-5) + 1e-300;
+    const double R = (i < n_sph ? root(e[3]) : e[5]) * (1.0 + 1e-5) + 1e-300;
     const V3 L = v_sub(ld3(e), pos);
-    const double len = sqrt(v_dot(L, L));
-    const double sin_p = R / len; /* NaN / inf: the comparisons below keep the primitive */
-    if (!(sin_p < 1.0) || !(cos_t > 0.0))
-      keep = true; /* the camera inside (or on) the ball; a degenerate cone */
+    const double inv_len = rsq(v_dot(L, L));
+    const double sin_p = R * inv_len; /* NaN / inf: the comparisons below keep the primitive */
+    if (!(sin_p < 0.99999) || !(cos_t > 0.0))
+      keep = true; /* the camera inside (or on, or within 1e-5 of) the ball; a degenerate cone */
     else
     {
-      const double cos_p = sqrt(1.0 - sin_p * sin_p);
-      const double cos_a = v_dot(a, L) / len;
+      const double cos_p = root(1.0 - sin_p * sin_p);
+      const double cos_a = v_dot(a, L) * inv_len;
       keep = !(cos_a < cos_t * cos_p - sin_t * sin_p - 1e-5);
     }
   }
