@@ -187,6 +187,11 @@ struct PtLaunch
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
   uint32_t sample_chunks; /* workgroups per tile: each renders 1/sample_chunks of the samples */
   uint32_t integrator;    /* 0 trace_path (raytracer.c:482-554), 1 cast_ray (:556-641) */
+  /* sign-test kernels: the scene's leading pairs of wall-sized spheres (radius >= 1000) are pruned among themselves before
+   * the exact tests (pt_kernel.hip, BigPrune): how many pairs (0: off), the distance margin, the least distance and per sphere the least q32 of a wall that may prune */
+  uint32_t big_pairs;
+  float big_delta, big_tmin;
+  float big_qmin[8];
   /* parked-walk kernels: workspace of PT_PARK_XCDS x park_slots_per_xcd slots x 4 waves x PT_PARK_WAVE_BYTES and
    * one in-use flag per slot (zero between launches); nullptr: walk in the lanes */
   char *park_ws;

@@ -577,9 +577,38 @@ __device__ __forceinline__ FiltRay filter_ray(const V3 &o, const V3 &d, double f
  * of 64): the conservative packed-fp32 filter, all lanes on the same pair.  Returns the lane's
  * keep mask (bit k = primitive base + k survives).  The ray arrives in fp32, SHIFTed where the
  * sign-test form applies (see scan_filtered); far_origin lanes keep everything. */
+/* PRUNING the wall-sized spheres among themselves (sign-test kernels; the scene's LEADING pairs of spheres with radius
+ * >= 1000, PtLaunch.big_pairs <= PT_BIG_PAIRS of them).  A ray inside a room of six such walls points at about half of
+ * them, every one a true hit the filter must keep, and the exact test -- the kernel's largest block -- then runs for all
+ * of them although only the nearest can win (config 4: 2.47 of a ray's 2.73 candidates are walls, 4.7 exact-test
+ * iterations per trip where 2.9 would do).  The filter already holds, per lane and wall, tca32' and q32 ~ thc^2, and the hit
+ * distance is t = tca - thc ~ t32 := tca32' - sqrt(q32).  With e = 2^-24, A = |c| + near_R + tol, W = r2_hi' - r^2 (the table's
+ * widening), E = 28 e A^2 + 6 e | |c|^2 - r^2 | >= |q32 - (thc^2 + W)| (pt_build_filter; W >= E), and tol |d|^2 the pull-back of
+ * the filter's origin, the same for every sphere of a ray:
+ *   LOWER bound, any wall with q32 >= 0:  sqrt(q32) >= thc (1 - 2 e), so  t >= t32 - tol |d|^2 - 11.2 e A
+ *     (8.2 e A the filter's bound on tca32', 3 e A one ulp of v_sqrt_f32 and the rounding of the difference);
+ *   UPPER bound, a wall whose half-chord is at least r / 16 (q32 > qmin = (r / 16)^2 + W + E: the ray meets it within 86 degrees
+ *     of its normal -- which also makes the hit certain: d2 <= r^2 with room to spare) and that lies ahead (t32 > tmin =
+ *     2 (tol + 11.2 e A), so tca > 0 and t > EPSILON):  sqrt(thc^2 + W + E) - thc <= (W + E) / (2 thc) <= 8 (W + E) / r, so
+ *     t <= t32 - tol |d|^2 + 11.2 e A + 8 (W + E) / r.
+ * So with delta = 1.5 max_k (22.4 e A_k + 8 (W_k + E_k) / r_k), formed on the host (rt_hip_shim.hip, big_prune_for):
+ * t32_j > t32_i + delta, for a wall i that satisfies the conditions of the upper bound and ANY wall j, means t_j > t_i by a
+ * margin that dwarfs the reference's own fp64 rounding (~1e-12 A): wall j can neither be the closest hit nor tie with it,
+ * and its candidate bit is cleared.  (A wall the ray starts inside has t32 < 0: never pruned, never pruning.)  Config 4:
+ * delta = 0.42 in a room of 40 x 20 x 60: two walls survive together only within that distance of a room edge, or when
+ * the nearer one is met at a grazing angle.  The PT_DIAG build puts every pruned wall through the exact test after the
+ * scan: it must come out strictly farther than the scan's result (tests/test_gpu_diag.py). */
+#define PT_BIG_PAIRS 4u
+struct BigPrune
+{
+  const float *tab; /* LDS, 16-byte aligned: delta, tmin, qmin[2 PT_BIG_PAIRS], pad */
+  uint32_t n_pairs; /* 0: off (wave-uniform) */
+};
+
 template <bool TRIS, bool FILT_LDS>
 __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uint32_t base, uint32_t chunk, const FiltRay &fr,
-                                             uint32_t &cand_lo, uint32_t &cand_hi)
+                                             uint32_t &cand_lo, uint32_t &cand_hi, BigPrune big = BigPrune{nullptr, 0u},
+                                             uint32_t *pruned_out = nullptr)
 {
   constexpr bool SHIFT = FILT_LDS && !TRIS;
   const float ox = fr.ox, oy = fr.oy, oz = fr.oz;
@@ -657,7 +686,55 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
       for (; q < count; q++)
         filter_pair(load_pair(top - q), word, 0);
     };
-    run_desc(pairs_lo - 1u, pairs_lo, cand_lo);
+    /* the leading wall pairs come last (descending order) and by a loop of their own, which also estimates their hit distances */
+    const uint32_t nb = (SHIFT && base == 0u) ? min(big.n_pairs, pairs_lo) : 0u;
+    run_desc(pairs_lo - 1u, pairs_lo - nb, cand_lo);
+    uint32_t pruned = 0u;
+    if (SHIFT && nb != 0u)
+    {
+      /* delta, tmin, then qmin per sphere: three 16-byte reads */
+      const float4 c0 = *reinterpret_cast<const float4 *>(big.tab), c1 = *reinterpret_cast<const float4 *>(big.tab + 4),
+                   c2 = *reinterpret_cast<const float4 *>(big.tab + 8);
+      const float delta = c0.x, tmin = c0.y;
+      const float qmin[2 * PT_BIG_PAIRS] = {c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
+      const float quiet_nan = __uint_as_float(0x7FC00000u);
+      /* NaN stands for "takes no part": v_min ignores it and no comparison with it holds */
+      float t32[2 * PT_BIG_PAIRS];
+      float m = __builtin_inff();
+#pragma unroll
+      for (int p = (int)PT_BIG_PAIRS - 1; p >= 0; p--)
+      {
+        t32[2 * p] = quiet_nan;
+        t32[2 * p + 1] = quiet_nan;
+        if ((uint32_t)p < nb) /* wave-uniform */
+        {
+          const PairRec g = load_pair((uint32_t)p);
+          const f32x2 tca = __builtin_elementwise_fma(g.cz, dz, __builtin_elementwise_fma(g.cy, dy, __builtin_elementwise_fma(g.cx, dx, neg_od)));
+          const f32x2 ll = __builtin_elementwise_fma(g.cz, m2oz, __builtin_elementwise_fma(g.cy, m2oy, __builtin_elementwise_fma(g.cx, m2ox, g.r2_hi + oo)));
+          const float qx = __builtin_fmaf(tca.x, __builtin_fabsf(tca.x), -ll.x), qy = __builtin_fmaf(tca.y, __builtin_fabsf(tca.y), -ll.y);
+          cand_lo = __builtin_amdgcn_alignbit(cand_lo, __float_as_uint(qy), 31);
+          cand_lo = __builtin_amdgcn_alignbit(cand_lo, __float_as_uint(qx), 31);
+          /* the distance estimates (q'' = q32 where tca32' > 0; NaN where q'' < 0: such a wall is dropped anyway) ... */
+          const float tx = tca.x - __builtin_amdgcn_sqrtf(qx), ty = tca.y - __builtin_amdgcn_sqrtf(qy);
+          t32[2 * p] = tx;
+          t32[2 * p + 1] = ty;
+          /* ... and, of the walls that may PRUNE (a certain hit ahead with a half-chord of r / 16 at least), the nearest */
+          const float px = ((qx > qmin[2 * p]) & (tx > tmin)) ? tx : quiet_nan;     /* (t32 > tmin > 0 implies tca32' > 0) */
+          const float py = ((qy > qmin[2 * p + 1]) & (ty > tmin)) ? ty : quiet_nan;
+          m = __builtin_fminf(m, __builtin_fminf(px, py));
+        }
+      }
+      const float thr = m + delta;
+#pragma unroll
+      for (int k = 0; k < 2 * (int)PT_BIG_PAIRS; k++)
+        if ((uint32_t)k < 2u * nb) /* wave-uniform */
+          pruned |= (t32[k] > thr) ? (1u << k) : 0u;
+      cand_lo |= pruned; /* drop bits here */
+      if (far_origin)
+        pruned = 0u;
+    }
+    if (pruned_out)
+      *pruned_out = pruned;
     run_desc(n_pairs - 1u, n_pairs - pairs_lo, cand_hi);
     if (SHIFT)
     { /* drop bits -> keep bits */
@@ -871,7 +948,8 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
                                               unsigned long long *diag_ptr, const float *bvh_nodes = nullptr,
                                               uint32_t n_bvh_nodes = 0, const uint32_t *bvh_tri = nullptr,
                                               double filt_shift = 0.0, TriLast *last = nullptr, bool no_prune = false,
-                                              const float4 *tri32 = nullptr, const uint32_t *prim_pairs = nullptr)
+                                              const float4 *tri32 = nullptr, const uint32_t *prim_pairs = nullptr,
+                                              BigPrune big = BigPrune{nullptr, 0u})
 {
   /* prim_pairs (wave-uniform; pooled kernels' primary trips, FILT_LDS only): per chunk the pairs that a camera ray of
    * this tile can reach (tile_cull); nullptr: every pair */
@@ -906,12 +984,13 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     const uint32_t chunk = min(64u, n_entries - base);
     /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
     uint32_t cand_lo, cand_hi;
+    uint32_t pruned = 0u; /* wall-sized spheres of this chunk that cannot be the closest hit (BigPrune): PT_DIAG re-checks them */
     if (SPH_LDS)
       filter_chunk<false, true>(filt, base, chunk, fr, cand_lo, cand_hi);
     else if (FILT_LDS && prim_pairs != nullptr)
       filter_chunk_listed<SHIFT>(filt, base, chunk, prim_pairs[base >> 6], fr, cand_lo, cand_hi);
     else
-      filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, fr, cand_lo, cand_hi);
+      filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, fr, cand_lo, cand_hi, big, &pruned);
     /* triangle candidates of this chunk: bits from entry n_sph on */
     uint32_t tri_lo = 0, tri_hi = 0;
     if (TRIS && !BVH)
@@ -959,7 +1038,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       uint32_t violations = 0;
       for (uint32_t k = 0; k < chunk; k++)
       {
-        const bool kept = k < 32 ? (((cand_lo | tri_lo) >> k) & 1u) : (((cand_hi | tri_hi) >> (k - 32u)) & 1u);
+        const bool kept = k < 32 ? (((cand_lo | tri_lo | pruned) >> k) & 1u) : (((cand_hi | tri_hi) >> (k - 32u)) & 1u);
         double t_probe = 1.7976931348623157e308, pu = 0, pv = 0;
         int b_probe = -1;
         const uint32_t i = base + k;
@@ -1021,6 +1100,19 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       const uint32_t i = base + k;
       exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
     }
+#ifdef PT_DIAG
+    /* a pruned wall must lose STRICTLY against what the scan found */
+    for (uint32_t k = 0; k < 2u * PT_BIG_PAIRS; k++)
+      if ((pruned >> k) & 1u)
+      {
+        double t_probe = 1.7976931348623157e308;
+        int b_probe = -1;
+        exact_sphere(geom + PT_GEOM_STRIDE * (base + k), base + k, o, d, t_probe, b_probe);
+        if (b_probe >= 0 && !(t_probe > min_t))
+          atomicAdd(&diag_ptr[4 + 12], 1ull);
+        atomicAdd(&diag_ptr[4 + 37], 1ull); /* pruned walls */
+      }
+#endif
     /* then its triangle candidates (all of higher index than any sphere: the scan order holds).  Two
      * loops, not one with a branch inside: a wave holding both kinds would pay for both tests in
      * every iteration */
@@ -1068,6 +1160,7 @@ struct SceneCtx
   uint32_t n_sph, n_tri;
   int max_depth;
   bool stale_uv;          /* M_CHECKERED materials AND triangles: hit.u / hit.v follow the TriLast rule */
+  BigPrune big;           /* pruning of the leading wall-sized spheres among themselves (sign-test kernels), or off */
 };
 
 /* GEOM_LDS: sphere geometry and materials are staged in LDS (the pointers are LDS pointers at
@@ -1159,6 +1252,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.n_tri = sc.n_triangles;
   ctx.max_depth = L.max_depth;
   ctx.stale_uv = sc.any_checker != 0 && sc.n_triangles != 0;
+  ctx.big = BigPrune{nullptr, 0u};
   return ctx;
 }
 
@@ -1374,7 +1468,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       else
         scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0, CHECKER && TRIS, SPH_LDS>(
             S.geom, S.tri, (FILT_LDS || SPH_LDS) ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o, d, H.min_t, H.best,
-            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv, S.tri32, prim_pairs);
+            H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv, S.tri32, prim_pairs, S.big);
     }
     if (MODE == 1)
       return false;
@@ -1828,7 +1922,15 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __shared__ uint32_t tile_pairs[PT_FILT_LDS_MAX / 64]; /* tile_cull: pairs a camera ray of this tile can reach, per chunk of 64 entries */
   __shared__ uint32_t wg_next_job;                      /* SWAP: jobs of the tile's pool handed out so far */
 
-  const SceneCtx S = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
+  SceneCtx S_init = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
+  __shared__ __attribute__((aligned(16))) float big_tab[12]; /* BigPrune: delta, tmin, qmin of the leading wall-sized spheres */
+  if (SWAP && FILT_LDS && !TRIS && L.big_pairs != 0u)
+  {
+    if (threadIdx.x < 2 + 2 * PT_BIG_PAIRS)
+      big_tab[threadIdx.x] = threadIdx.x == 0 ? L.big_delta : (threadIdx.x == 1 ? L.big_tmin : L.big_qmin[threadIdx.x - 2]);
+    S_init.big = BigPrune{big_tab, L.big_pairs};
+  }
+  const SceneCtx S = S_init;
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
   if (threadIdx.x == 2)

@@ -65,6 +65,10 @@ struct RtHipScene
   double max_emission = 0; /* max |emission component| over all materials */
   bool any_mirror_glass = false; /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children */
   double max_center = 0; /* max |centre| over the spheres (rounded up) */
+  /* the scene's LEADING wall-sized spheres (radius >= 1000), whole pairs of them, at most 2 PT_BIG_PAIRS: radius and
+   * |centre| -- what big_prune_for needs to bound their hit-distance estimates (pt_kernel.hip, BigPrune) */
+  int n_big = 0;
+  double big_r[8] = {0}, big_c[8] = {0};
   /* bounding sphere of every triangle (bvh_probe): centre, radius, |centre| -- radius < 0: no triangles */
   double mesh_c[3] = {0, 0, 0}, mesh_R = -1, mesh_c_norm = 0;
   bool hull_flags = false; /* tri_object carries PT_HULL_PLUS / PT_HULL_MINUS (pt_build_hull_flags ran) */
@@ -793,6 +797,16 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.any_refract = any_refract ? 1u : 0u;
   sc->view.wide_range = wide_range ? 1u : 0u;
   sc->max_center = max_center;
+  {
+    int nb = 0;
+    while (nb < 8 && (size_t)nb < n_spheres && std::fabs(spheres[nb].radius) >= 1000.0 && std::fabs(spheres[nb].radius) <= 1e17)
+    {
+      sc->big_r[nb] = std::fabs(spheres[nb].radius);
+      sc->big_c[nb] = geom[PT_ENTRY_SRC_STRIDE * (size_t)nb + 4];
+      nb++;
+    }
+    sc->n_big = nb & ~1; /* whole pairs */
+  }
   sc->reach = reach;
   sc->max_emission = max_emission;
   sc->any_mirror_glass = any_mirror_glass;
@@ -905,6 +919,43 @@ static void mesh_bound_for(const RtHipScene *scene, double near_R, float out[5])
   out[4] = -(float)((scene->mesh_R + 10.0 * e * A) * (1.0 + 4.0 * e));
 }
 
+/* BigPrune (pt_kernel.hip, where the bounds are derived): for one near_R, the distance margin delta, the least estimate tmin
+ * and per sphere the least q32 of a leading wall-sized sphere that may prune the others.  With e = 2^-24, A = |c| + near_R +
+ * tol, W >= r2_hi' - r^2 (40 e A^2 + 16 e | |c|^2 - r^2 |: what pt_build_filter widens by, rounded up), E = 28 e A^2 + 6 e | |c|^2 -
+ * r^2 |:  qmin = (r / 16)^2 + W + E,  tmin = 2 (tol + 11.2 e A),  delta = 1.5 max (22.4 e A + 8 (W + E) / r).
+ * Anything non-finite or implausible switches the pruning off. */
+static void big_prune_for(const RtHipScene *scene, double near_R, double filt_shift, PtLaunch &L)
+{
+  L.big_pairs = 0;
+  L.big_delta = L.big_tmin = 0.f;
+  for (int k = 0; k < 8; k++)
+    L.big_qmin[k] = std::numeric_limits<float>::infinity();
+  static const bool off = [] {
+    const char *e = getenv("RT_HIP_NO_BIG_PRUNE"); /* development switch (A/B) */
+    return e && e[0] == '1';
+  }();
+  if (off || scene->n_big < 2 || scene->view.n_triangles != 0 || scene->view.wide_range)
+    return;
+  const double e = 5.9604644775390625e-08, f = 1.0 / 16.0;
+  double delta = 0, tmin = 0;
+  for (int k = 0; k < scene->n_big; k++)
+  {
+    const double r = scene->big_r[k], c = scene->big_c[k], A = c + near_R + filt_shift;
+    const double g = std::fabs(c * c - r * r);
+    const double W = (40.0 * e * A * A + 16.0 * e * g) * 1.001, E = 28.0 * e * A * A + 6.0 * e * g;
+    const double qmin = f * f * r * r + W + E;
+    const double bias = (W + E) / (2.0 * f * r);
+    if (!(qmin < 1e30) || !(bias < 1e3))
+      return;
+    L.big_qmin[k] = (float)(qmin * (1.0 + 4.0 * e));
+    delta = std::fmax(delta, 1.5 * (22.4 * e * A + bias));
+    tmin = std::fmax(tmin, 2.0 * (filt_shift * 1.0001 + 11.2 * e * A));
+  }
+  L.big_delta = (float)(delta * (1.0 + 4.0 * e));
+  L.big_tmin = (float)(tmin * (1.0 + 4.0 * e));
+  L.big_pairs = (uint32_t)scene->n_big / 2u;
+}
+
 /* How far on the outer side of a hull facet F (pt_build_hull_flags) a ray must point, mu < m . d, to be certain
  * not to meet a triangle.  With u = 2^-53, sigma = |e1||e2| / |e1 x e2| <= 16 (the flag's shape limit), D >= |o - v0|
  * and the hit distance (3 (near_R + extent) covers both):
@@ -991,6 +1042,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     L.near_R2 = L.near_R * L.near_R;
     L.filt_shift = 12.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
     mesh_bound_for(scene, L.near_R, L.mesh_bound);
+    big_prune_for(scene, L.near_R, L.filt_shift, L);
     L.hull_margin = hull_margin_for(scene, L.near_R);
     {
       const char *flag = getenv("RT_HIP_DIAG_WALK_REJECTED");

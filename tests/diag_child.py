@@ -6,6 +6,8 @@ shim (RT_HIP_SHIM_PATH=.../librt_hip_diag.so, RT_HIP_DIAG_WALK_REJECTED=1) and p
   violations   stats[4 + 12]: primitives the packed-fp32 filter or an fp32 triangle pre-test dropped although the
                exact fp64 test accepts them, PLUS rays the bounding-sphere probe or the hull-facet rule would not
                have walked that, walked all the same, came back with a triangle.  Must be 0.
+               PLUS wall-sized spheres pruned before the exact tests (BigPrune) that the exact test, run all the same, finds
+               no farther than the scan's result.
   and what shows that the check was not vacuous: candidates per cast (< primitives: the filter dropped some),
   parked rays, parked rays the probe alone would have let through, rays that left a hull facet, leaf pre-tests.
 
@@ -73,7 +75,7 @@ def main():
                               "n_primitives": sc.n_primitives, "casts": st[1], "violations": d[12],
                               "candidates": d[3], "parked": d[17], "parked_probe_would_park": d[23],
                               "left_hull_facet": d[28], "leaf_pretests": d[16], "small_mesh_pretests": d[35],
-                              "walked_found_triangle": d[18]}), flush=True)
+                              "walked_found_triangle": d[18], "walls_pruned": d[37]}), flush=True)
             gs.close()
 
 

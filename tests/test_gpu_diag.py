@@ -2,8 +2,8 @@
 
 The render kernels may skip exact fp64 tests only through rules that can never change an outcome: the packed-fp32
 phase-1 filter (three forms), the per-tile culling of the primary trips' filter (tile_cull: primitives no camera ray of the
-tile can reach are not even looked at), the per-lane fp32 Moeller-Trumbore pre-test (small meshes and hierarchy leaves),
-the bounding-sphere probe in front of a hierarchy walk, and the hull-facet rule (a bounce that leaves a convex facet
+tile can reach are not even looked at), the pruning of wall-sized spheres among themselves by fp32 distance bounds (BigPrune), the per-lane fp32 Moeller-Trumbore
+pre-test (small meshes and hierarchy leaves), the bounding-sphere probe in front of a hierarchy walk, and the hull-facet rule (a bounce that leaves a convex facet
 on its outer side is not walked).  Each rests on a hand-derived error bound (pt_kernel.hip: pt_build_filter,
 tri_may_hit32; rt_hip_shim.hip: mesh_bound_for, hull_margin_for).  The PT_DIAG build of the same kernels
 (`make shim-diag`, part of `make all`: raytracer.c_amd/csrc/librt_hip_diag.so) re-checks every application of every
@@ -49,6 +49,8 @@ def test_diag_configs_1_to_5_zero_violations():
     assert set(path) == {"config %d" % c for c in range(1, 6)}
     for r in path.values():   # the filter really dropped primitives (else the re-check had nothing to check)
         assert 0 < r["candidates"] < r["casts"] * r["n_primitives"], r
+    # config 4's six walls are pruned among themselves before the exact tests: that happened, and every pruned wall lost strictly
+    assert path["config 4"]["walls_pruned"] > path["config 4"]["casts"] // 2
     c3, c5 = path["config 3"], path["config 5"]
     assert c3["kernel"] == "pt_render_tiles_tri" and c3["small_mesh_pretests"] > 0
     assert c5["kernel"] == "pt_render_tiles_tri_queued_sph"
