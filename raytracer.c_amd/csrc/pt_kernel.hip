@@ -986,7 +986,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     uint32_t cand_lo, cand_hi;
     uint32_t pruned = 0u; /* wall-sized spheres of this chunk that cannot be the closest hit (BigPrune): PT_DIAG re-checks them */
     if (SPH_LDS)
-      filter_chunk<false, true>(filt, base, chunk, fr, cand_lo, cand_hi);
+      filter_chunk<false, true>(filt, base, chunk, fr, cand_lo, cand_hi, big, &pruned);
     else if (FILT_LDS && prim_pairs != nullptr)
       filter_chunk_listed<SHIFT>(filt, base, chunk, prim_pairs[base >> 6], fr, cand_lo, cand_hi);
     else
@@ -2662,7 +2662,15 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
    * result known, park next); then the depth */
   constexpr uint32_t META_NEED_DIR = 64u, META_RESUMED = 128u, META_LEAVING = 256u, META_WAITING = 512u, META_DEPTH_SHIFT = 10u;
 
-  const SceneCtx S = stage_scene<true, FILT_LDS, true>(L, lds);
+  SceneCtx S_init = stage_scene<true, FILT_LDS, true>(L, lds);
+  __shared__ __attribute__((aligned(16))) float big_tab[12]; /* BigPrune: delta, tmin, qmin of the leading wall-sized spheres */
+  if (L.big_pairs != 0u)
+  {
+    if (threadIdx.x < 2 + 2 * PT_BIG_PAIRS)
+      big_tab[threadIdx.x] = threadIdx.x == 0 ? L.big_delta : (threadIdx.x == 1 ? L.big_tmin : L.big_qmin[threadIdx.x - 2]);
+    S_init.big = BigPrune{big_tab, L.big_pairs};
+  }
+  const SceneCtx S = S_init;
   /* the traversal stacks follow the staged scene (geometry, materials, the spheres' filter pairs) in dynamic LDS:
    * one 24-bit entry per tree level and lane (WalkStack) */
   WalkStack stack;

@@ -934,7 +934,11 @@ static void big_prune_for(const RtHipScene *scene, double near_R, double filt_sh
     const char *e = getenv("RT_HIP_NO_BIG_PRUNE"); /* development switch (A/B) */
     return e && e[0] == '1';
   }();
-  if (off || scene->n_big < 2 || scene->view.n_triangles != 0 || scene->view.wide_range)
+  /* the kernels whose sphere filter is the sign-test form from LDS: sphere-only small scenes, and hierarchy scenes whose
+   * spheres fit the staging (the parked-walk kernels filter the spheres alone) */
+  const bool sign_form = !scene->view.wide_range && pt_geom_in_lds(scene->view) &&
+                         (scene->view.n_triangles == 0 ? pt_filter_in_lds(scene->view) : !pt_filter_in_lds(scene->view));
+  if (off || scene->n_big < 2 || !sign_form)
     return;
   const double e = 5.9604644775390625e-08, f = 1.0 / 16.0;
   double delta = 0, tmin = 0;
