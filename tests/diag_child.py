@@ -37,6 +37,8 @@ def scene_sets(which):
         sets = [("fuzz %d" % k, _random_scene(k, False, 0, materials=kinds[k % 3])) for k in range(6)]
         sets += [("fuzz mesh %d" % k, _random_scene(k, True, n, materials=kinds[k % 3]))
                  for k, n in zip(range(100, 106), [3, 40, 250, 300, 700, 2000])]
+        from util import walls_scene
+        sets += [("walls %d" % k, walls_scene(k, with_mesh=k >= 4)) for k in range(8)]
         return sets + [("whitted scene", whitted_scene())]
     if which == "convex":    # convex bodies at 64 spp: ~1e6 bounces off hull facets each, all walked
         return [("convex body %d" % k, convex_body_scene(k, 160, 100, 64)[0]) for k in range(4)]

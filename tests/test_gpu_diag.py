@@ -64,7 +64,9 @@ def test_diag_fuzz_scenes_zero_violations():
     recs = _run("fuzz")
     _no_violations(recs)
     done = [r for r in recs if "skipped" not in r]
-    assert len({r["scene"] for r in done}) == 13 and {r["integrator"] for r in done} == {"path", "whitted"}
+    assert len({r["scene"] for r in done}) == 21 and {r["integrator"] for r in done} == {"path", "whitted"}
+    walls = [r for r in done if r["scene"].startswith("walls") and r["integrator"] == "path"]
+    assert len(walls) == 8 and sum(r["walls_pruned"] > 0 for r in walls) >= 6, walls
     kernels = {r["kernel"] for r in done}
     # the static (_refr), pooled (plain / _chk), small-mesh, parked-walk and cast_ray families were all exercised
     assert any(k.startswith("pt_render_tiles_tri_queued") for k in kernels), kernels

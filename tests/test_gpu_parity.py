@@ -1326,3 +1326,16 @@ def test_hull_fuzz_random_convex_meshes(gpu, pt, seed):
         assert p + m < sc.n_triangles
     gs.close()
     _full(gpu, pt, sc)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_leading_walls_pruned_among_themselves(gpu, pt, seed):
+    """rooms of 2-8 leading wall-sized spheres, with near-coincident and duplicated walls, the camera almost on or inside
+    a wall: the kernels prune such walls among themselves by fp32 distance bounds before the exact tests (BigPrune) --
+    images and counters must stay the oracle's; seeds 4-7 add a 300-triangle mesh, i.e. the parked-walk kernels"""
+    from util import walls_scene
+    sc = walls_scene(seed, with_mesh=seed >= 4)
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name().startswith("pt_render_tiles_tri_queued") if seed >= 4 else gs.kernel_name() == "pt_render_tiles"
+    gs.close()
+    _full(gpu, pt, sc, hdr=True)

@@ -202,3 +202,51 @@ def convex_body_scene(seed, width=56, height=36, samples=4):
             dict(flags=abi.M_DEFAULT, radius=6.0, center=tuple(centre + (0, 24, 0)), color=(1, 1, 1), emission=(4, 4, 4))]
     cam = tuple(centre + rng.uniform(-1, 1, 3) * (6, 3, 6) + (0, 4, 22))
     return S.custom_scene(objs, width, height, samples, 8, cam, tuple(centre), meshes=meshes), len(tris)
+
+
+def walls_scene(seed, width=72, height=44, samples=6, with_mesh=False):
+    """a room of LEADING wall-sized spheres (what the kernels prune among themselves before the exact tests, BigPrune):
+    2 to 8 walls of radius 1e3 .. 1e5 at random distances -- some pairs placed so that a camera ray meets both at (nearly)
+    the same distance, exact duplicates included (index ties) --, mirror and diffuse, the camera sometimes almost on a
+    wall or inside one; then lights and small spheres; optionally a mesh of > 256 triangles, which sends the scene
+    to the parked-walk kernels (their sphere filter prunes too)"""
+    from rt_amd import abi, scene as S
+    rng = np.random.default_rng(7000 + seed)
+    n_walls = [6, 2, 8, 4, 6, 3, 8, 6][seed % 8]
+    objs = []
+    axes = [(0, -1, 0), (0, 1, 0), (-1, 0, 0), (1, 0, 0), (0, 0, -1), (0, 0, 1), (0.6, 0.8, 0), (-0.6, 0, 0.8)]
+    for k in range(n_walls):
+        r = float(10.0 ** rng.uniform(3, 5))
+        dist = float(rng.uniform(6, 30))
+        ax = np.array(axes[k % len(axes)], float)
+        c = ax * (r + dist)
+        if k and rng.uniform() < 0.25:   # a second wall through (almost) the same points as the previous one
+            prev = objs[-1]
+            pc, pr = np.array(prev["center"]), prev["radius"]
+            ax = pc / np.linalg.norm(pc)
+            r = pr * float(rng.choice([1.0, 1.0 + 1e-9, 3.0]))
+            c = ax * (np.linalg.norm(pc) - pr + r + float(rng.choice([0.0, 1e-7, 0.05, 0.3])))
+        objs.append(dict(flags=int(rng.choice([abi.M_DEFAULT, abi.M_DEFAULT, abi.M_REFLECTION])), radius=r, center=tuple(c),
+                         color=tuple(rng.uniform(0.3, 0.95, 3))))
+    objs.append(dict(flags=abi.M_DEFAULT, radius=3.0, center=(0, 4, 0), color=(1, 1, 1), emission=(6, 5, 4)))
+    for _ in range(int(rng.integers(2, 12))):
+        objs.append(dict(flags=int(rng.choice([abi.M_DEFAULT, abi.M_REFLECTION])), radius=float(rng.uniform(0.3, 2.5)),
+                         center=tuple(rng.uniform(-5, 5, 3)), color=tuple(rng.uniform(0.2, 1, 3))))
+    cam = rng.uniform(-4, 4, 3)
+    mode = seed % 4
+    if mode == 1:    # a hair in front of the first wall
+        w = objs[0]
+        wc = np.array(w["center"])
+        cam = wc - wc / np.linalg.norm(wc) * (w["radius"] + 1e-3)
+    elif mode == 2:  # inside the first wall
+        w = objs[0]
+        wc = np.array(w["center"])
+        cam = wc - wc / np.linalg.norm(wc) * (w["radius"] - 2.0)
+    meshes = []
+    if with_mesh:
+        tris = []
+        for _ in range(300):
+            b = rng.uniform(-4, 4, 3)
+            tris.append([tuple(b), tuple(b + rng.normal(size=3) * 0.7), tuple(b + rng.normal(size=3) * 0.7)])
+        meshes = [dict(flags=abi.M_DEFAULT, color=(0.7, 0.8, 0.5), triangles=tris)]
+    return S.custom_scene(objs, width, height, samples, 6, tuple(cam), tuple(rng.uniform(-1, 1, 3)), meshes=meshes)
