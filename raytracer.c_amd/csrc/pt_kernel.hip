@@ -1363,7 +1363,14 @@ __device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uin
   const double v = div_small_int((double)py + rnd(P.rng), cam.h_minus_1, cam.inv_h_minus_1);
   const V3 on_plane = v_add(cam.llc, v_add(v_scale(cam.horizontal, u), v_scale(cam.vertical, v)));
   P.o = cam.pos;
-  P.d = v_normalize(v_sub(cam.pos, on_plane));
+  /* vec3_normalize (vector.h:53-58): w * (1.0 / sqrt(w.w)).  Where |w|^2 is in [1e-200, 1e200] -- every sane camera -- the
+   * square root and the reciprocal are hipcc's own expansions without their range scaling (sqrt_unscaled, rcp_unscaled:
+   * the same instructions on the same values, so the same doubles; the selftest compares them with the IEEE results):
+   * ~25 instructions fewer per camera sample, which config 2 and 3 -- most of whose ray-bounces are first bounces --
+   * notice.  Anything else takes the library forms. */
+  const V3 w = v_sub(cam.pos, on_plane);
+  const double ww = v_dot(w, w);
+  P.d = (ww >= 1e-200 && ww <= 1e200) ? v_scale(w, rcp_unscaled(sqrt_unscaled(ww))) : v_scale(w, 1.0 / sqrt(ww));
   P.T = {1, 1, 1};
   P.Ls = {0, 0, 0};
   P.depth = 0;
