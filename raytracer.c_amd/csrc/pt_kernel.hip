@@ -2713,7 +2713,14 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   const uint32_t spp = (uint32_t)L.samples;
   const uint32_t s_begin = (uint32_t)(((uint64_t)chunk * spp) / L.sample_chunks);
   const uint32_t s_end = (uint32_t)(((uint64_t)(chunk + 1u) * spp) / L.sample_chunks);
-  const uint32_t pool = has_unit ? n_valid * (s_end - s_begin) : 0u;
+  const uint32_t park_slot = park_slot_lds;
+  const bool ring_ok = park_slot != 0xFFFFFFFFu;
+  /* (the launcher takes these kernels only with a workspace: pt_launch_render; a slot can be missing only through a sizing
+   * bug of the pool, never seen -- then nothing could be parked and rays that want a walk would wait for ever: the wave
+   * renders nothing instead, and says so: every pixel of its tile comes out NaN, bytes 255) */
+  const uint32_t pool = (has_unit && ring_ok) ? n_valid * (s_end - s_begin) : 0u;
+  if (has_unit && !ring_ok && (threadIdx.x & 63u) < 3u)
+    pix_nan_all[wave][threadIdx.x & 63u] = ~0ull;
   /* wave-uniform addresses and tile numbers that the trip loop needs now and then are formed where they are used, from
    * a wave index the compiler cannot see through (wave_now): hoisted out of the loop they each hold a vector register for
    * its whole length -- the kernel has none to spare at four waves per SIMD, they were what it spilled */
@@ -2722,17 +2729,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     asm volatile("" : "+v"(w));
     return w;
   };
-  const uint32_t park_slot = park_slot_lds;
   ParkRing ring;
   {
-    /* (the launcher takes these kernels only with a workspace: pt_launch_render; a slot can be missing only through
-     * a sizing bug of the pool, never seen -- then nothing can be parked, and rays that want a walk would wait for
-     * ever: the kernel gives up its tile instead, visibly: see `ring_ok` below) */
     char *base = L.park_ws + ((size_t)(park_slot != 0xFFFFFFFFu ? park_slot : 0u) * (PT_BLOCK / 64) + wave) * PT_PARK_WAVE_BYTES;
     ring.f = reinterpret_cast<double *>(base);
     ring.u = reinterpret_cast<uint32_t *>(base);
   }
-  const bool ring_ok = park_slot != 0xFFFFFFFFu;
 
   Path P;
   P.o = {0, 0, 0};
@@ -2922,8 +2924,6 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     const bool drained = __ballot(busy) == 0;
     if (drained && n_new == 0u)
       break;
-    if (!ring_ok)
-      break; /* no workspace slot (see above): the tile stays unrendered rather than the wave spinning */
 
     /* ---- the wave turns to walking: every path the lanes hold goes to the list first, so that nothing of this
      * loop is live in registers while walk_parked runs ---- */
