@@ -938,6 +938,41 @@ __device__ __forceinline__ bool tri_may_hit32(const float4 &r0, const float4 &r1
   return !drop;
 }
 
+/* Two triangles per call: the same arithmetic as tri_may_hit32, element for element (so the same decisions), with triangle
+ * A in the low and B in the high half of packed-fp32 registers -- the cross and dot products, 27 of the ~40 operations of a
+ * pre-test, cost one instruction for both.  (Small-mesh kernels: a lane's candidates go through two at a time.) */
+__device__ __forceinline__ void tri_may_hit32_x2(const float4 *__restrict__ ra, const float4 *__restrict__ rb, f32x2 ox, f32x2 oy,
+                                                 f32x2 oz, f32x2 dx, f32x2 dy, f32x2 dz, bool &may_a, bool &may_b)
+{
+  const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
+  const float a3 = ra[3].x, b3 = rb[3].x;
+  const f32x2 v0x = {a0.x, b0.x}, v0y = {a0.y, b0.y}, v0z = {a0.z, b0.z}, e1x = {a0.w, b0.w}, e1y = {a1.x, b1.x}, e1z = {a1.y, b1.y},
+              e2x = {a1.z, b1.z}, e2y = {a1.w, b1.w}, e2z = {a2.x, b2.x};
+  const f32x2 hx = __builtin_elementwise_fma(dy, e2z, -(dz * e2y)), hy = __builtin_elementwise_fma(dz, e2x, -(dx * e2z)),
+              hz = __builtin_elementwise_fma(dx, e2y, -(dy * e2x));
+  const f32x2 a = __builtin_elementwise_fma(e1z, hz, __builtin_elementwise_fma(e1y, hy, e1x * hx));
+  const f32x2 sx = ox - v0x, sy = oy - v0y, sz = oz - v0z;
+  const f32x2 U = __builtin_elementwise_fma(sz, hz, __builtin_elementwise_fma(sy, hy, sx * hx));
+  const f32x2 qx = __builtin_elementwise_fma(sy, e1z, -(sz * e1y)), qy = __builtin_elementwise_fma(sz, e1x, -(sx * e1z)),
+              qz = __builtin_elementwise_fma(sx, e1y, -(sy * e1x));
+  const f32x2 V = __builtin_elementwise_fma(dz, qz, __builtin_elementwise_fma(dy, qy, dx * qx));
+  const f32x2 T = __builtin_elementwise_fma(e2z, qz, __builtin_elementwise_fma(e2y, qy, e2x * qx));
+  auto decide = [](float a_, float U_, float V_, float T_, float Ea, float KU, float KV, float KT) -> bool {
+    const float abs_a = fabsf(a_);
+    if (!(abs_a > Ea))
+      return true; /* near-parallel, or NaN: the sign of a is not certain */
+    const uint32_t sgn = __float_as_uint(a_) & 0x80000000u;
+    U_ = __uint_as_float(__float_as_uint(U_) ^ sgn);
+    V_ = __uint_as_float(__float_as_uint(V_) ^ sgn);
+    T_ = __uint_as_float(__float_as_uint(T_) ^ sgn);
+    const float lim = abs_a + Ea;
+    const bool drop = (U_ < -KU) | (U_ > lim + KU) | (V_ < -KV) | (U_ + V_ > lim + KU + KV) | (T_ < -KT);
+    return !drop;
+  };
+  may_a = decide(a.x, U.x, V.x, T.x, a2.y, a2.z, a2.w, a3);
+  may_b = decide(a.y, U.y, V.y, T.y, b2.y, b2.z, b2.w, b3);
+}
+
 /* SPH_LDS (hierarchy kernels with parked walks): the flat filter covers the spheres only, and their part of the pair
  * table is staged in LDS and used in the sign-test form, as in the sphere-only kernels. */
 template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true, bool LAST = false, bool SPH_LDS = false>
@@ -1006,7 +1041,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       {
         /* ---- phase 1b: per-lane fp32 pre-test of the lane's own triangle candidates (tri_may_hit32) ---- */
 #ifdef PT_DIAG
-        DIAG(34, wave_max_u32((uint32_t)(__popc(tri_lo) + __popc(tri_hi)))); /* wave-level pre-test iterations */
+        DIAG(34, (wave_max_u32((uint32_t)(__popc(tri_lo) + __popc(tri_hi))) + 1u) / 2u); /* wave-level pre-test iterations: two candidates each */
         {
           uint32_t tot = (uint32_t)(__popc(tri_lo) + __popc(tri_hi));
           for (int off = 32; off > 0; off >>= 1)
@@ -1014,22 +1049,23 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
           DIAG(35, tot); /* lane-level pre-tests */
         }
 #endif
-        uint32_t keep_lo = 0, keep_hi = 0, w_lo = tri_lo, w_hi = tri_hi;
-        while (w_lo | w_hi)
+        /* two candidates per iteration (tri_may_hit32_x2); a lane with an odd one left tests it twice */
+        unsigned long long w = ((unsigned long long)tri_hi << 32) | tri_lo, keep = 0;
+        const f32x2 pox = {ox, ox}, poy = {oy, oy}, poz = {oz, oz};
+        while (w != 0)
         {
-          const bool in_lo = w_lo != 0;
-          const uint32_t word = in_lo ? w_lo : w_hi;
-          const uint32_t bit = (uint32_t)__builtin_ctz(word);
-          const uint32_t cleared = word & (word - 1u);
-          w_lo = in_lo ? cleared : 0u;
-          w_hi = in_lo ? w_hi : cleared;
-          const uint32_t t = base + bit + (in_lo ? 0u : 32u) - n_sph;
-          const bool may = tri_may_hit32(tri32 + (PT_TRI32_STRIDE / 4) * (size_t)t, ox, oy, oz, dx.x, dy.x, dz.x);
-          keep_lo |= (in_lo && may) ? (1u << bit) : 0u;
-          keep_hi |= (!in_lo && may) ? (1u << bit) : 0u;
+          const uint32_t bit_a = (uint32_t)__builtin_ctzll(w);
+          const unsigned long long rest = w & (w - 1ull);
+          const uint32_t bit_b = rest != 0 ? (uint32_t)__builtin_ctzll(rest) : bit_a;
+          w = rest & (rest - 1ull);
+          const uint32_t ta = base + bit_a - n_sph, tb = base + bit_b - n_sph;
+          bool may_a, may_b;
+          tri_may_hit32_x2(tri32 + (PT_TRI32_STRIDE / 4) * (size_t)ta, tri32 + (PT_TRI32_STRIDE / 4) * (size_t)tb, pox, poy, poz, dx, dy, dz,
+                           may_a, may_b);
+          keep |= (may_a ? (1ull << bit_a) : 0ull) | (may_b ? (1ull << bit_b) : 0ull);
         }
-        tri_lo = keep_lo;
-        tri_hi = keep_hi;
+        tri_lo = (uint32_t)keep;
+        tri_hi = (uint32_t)(keep >> 32);
       }
     }
 #ifdef PT_DIAG
