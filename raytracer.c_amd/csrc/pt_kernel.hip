@@ -1849,7 +1849,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
 /* ---- epilogue shared by both kernels: coalesced tile store + counters ------------------- */
 
 /* per-pixel mean (raytracer.c:215) and gamma-5 tonemap (:218-220) of one tile from its
- * fixed-point sums; thread t < 64 handles pixel t */
+ * fixed-point sums; thread 3 t + c handles channel c of pixel t */
 /* nan_mask[c]: bit t set = channel c of pixel t received a NaN sample.  The reference's fp64 sum
  * carries a NaN to the pixel (raytracer.c:212-215) and CLAMP(NaN) = 1 stores byte 255 (:218); an
  * integer sum cannot, so the pooled kernels flag such samples apart and the pixel becomes NaN
@@ -1859,26 +1859,18 @@ __device__ __forceinline__ void finish_pixels(const PtLaunch &L, const unsigned 
                                               const unsigned long long *nan_mask, uint32_t tile, float *out_f,
                                               uint8_t *out_b)
 {
-  if (threadIdx.x < PT_TILE_PIXELS)
+  /* thread = (pixel, channel): 192 threads, one pow each (a pixel per thread kept three waves waiting on the first) */
+  if (threadIdx.x < PT_TILE_PIXELS * 3)
   {
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x / 3u, c = threadIdx.x - 3u * t;
     const bool inside = (tile % L.tiles_x) * PT_TILE + (t & 7u) < (uint32_t)L.width &&
                         (tile / L.tiles_x) * PT_TILE + (t >> 3) < (uint32_t)L.height;
     const double inv_s = 1.0 / (double)L.samples;
-    V3 mean;
-    mean.x = ((double)(long long)sums[3 * t + 0] * L.acc_inv_scale) * inv_s;
-    mean.y = ((double)(long long)sums[3 * t + 1] * L.acc_inv_scale) * inv_s;
-    mean.z = ((double)(long long)sums[3 * t + 2] * L.acc_inv_scale) * inv_s;
+    double mean = ((double)(long long)sums[threadIdx.x] * L.acc_inv_scale) * inv_s;
     const double quiet_nan = __longlong_as_double(0x7FF8000000000000ll);
-    mean.x = ((nan_mask[0] >> t) & 1ull) ? quiet_nan : mean.x;
-    mean.y = ((nan_mask[1] >> t) & 1ull) ? quiet_nan : mean.y;
-    mean.z = ((nan_mask[2] >> t) & 1ull) ? quiet_nan : mean.z;
-    out_f[3 * t + 0] = inside ? (float)mean.x : 0.f;
-    out_f[3 * t + 1] = inside ? (float)mean.y : 0.f;
-    out_f[3 * t + 2] = inside ? (float)mean.z : 0.f;
-    out_b[3 * t + 0] = inside ? tonemap(mean.x) : 0;
-    out_b[3 * t + 1] = inside ? tonemap(mean.y) : 0;
-    out_b[3 * t + 2] = inside ? tonemap(mean.z) : 0;
+    mean = ((nan_mask[c] >> t) & 1ull) ? quiet_nan : mean;
+    out_f[threadIdx.x] = inside ? (float)mean : 0.f;
+    out_b[threadIdx.x] = inside ? tonemap(mean) : 0;
   }
 }
 
