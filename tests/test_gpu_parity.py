@@ -475,6 +475,28 @@ def test_fuzz_sphere_scenes(gpu, pt, seed):
     _full(gpu, pt, _random_scene(seed, False, 0), hdr=True)  # emitters up to 1e3, "fresnel" weights beyond 1
 
 
+@pytest.mark.parametrize("seed,materials", [(s, m) for s in range(200, 208) for m in ("no_glass", "plain")])
+def test_fuzz_sphere_scenes_pooled_kernels(gpu, pt, seed, materials):
+    """the same nasty scenes without M_REFRACTION (which sends a scene to the static kernels): the pooled kernels --
+    swap, primary trips, per-tile culling, wall pruning, integer pixel sums under emitters of up to 1e3"""
+    sc = _random_scene(seed, False, 0, materials=materials)
+    gs = gpu.GpuScene(sc)
+    assert "_refr" not in gs.kernel_name()
+    gs.close()
+    _full(gpu, pt, sc, hdr=True)
+
+
+@pytest.mark.parametrize("seed,n_tris,materials", [(s, n, m) for s, n, m in zip(range(220, 228), [5, 60, 200, 300, 450, 900, 2000, 40],
+                                                                               ["plain", "no_glass"] * 4)])
+def test_fuzz_mesh_scenes_pooled_and_parked_walk_kernels(gpu, pt, seed, n_tris, materials):
+    """random meshes without M_REFRACTION: the small-mesh pooled kernels and the parked-walk kernels (plain and _chk)"""
+    sc = _random_scene(seed, True, n_tris, materials=materials)
+    gs = gpu.GpuScene(sc)
+    assert "_refr" not in gs.kernel_name()
+    gs.close()
+    _full(gpu, pt, sc, hdr=True)
+
+
 @pytest.mark.parametrize("seed,n_tris", [(s, n) for s, n in zip(range(16, 28), [3, 10, 40, 120, 250, 300, 400, 700, 1000, 60, 500, 2000])])
 def test_fuzz_mesh_scenes(gpu, pt, seed, n_tris):
     """small meshes go through the flat filter, larger ones (> 256 primitives) through the hierarchy"""
