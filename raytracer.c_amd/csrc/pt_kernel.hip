@@ -2390,8 +2390,15 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
  * ever has sits behind the same L2 -- plain stores, L1-bypassing loads, no cache write-backs.
  * Radiance is added to the pixel's fixed-point sum term by term (P.Ls is flushed every trip),
  * so a parked ray carries no partial radiance. */
+/* Ring entries per wave (a power of two).  512, not 256, for a GUARANTEE: every live path of a wave is in exactly one place --
+ * a lane (<= 64), the waiting list (<= 64), or the ring -- and new paths come only from a swap, which needs an empty list, no
+ * walked ray left in the ring and fewer than PT_PARK_WALK parked ones: at most 63 + (PT_PARK_WALK - 1) paths live before it,
+ * 64 more after.  So the ring never holds more than PT_PARK_WALK + 126 rays; with 512 entries it is never full, a ray that
+ * wants a walk is always parked at once, and the `waiting` state below (a ray keeps its lane until the ring has room) cannot
+ * occur -- it could otherwise starve a wave whose every lane waits while paths sit on its list.  (Measured against 256
+ * entries, which a mesh-filling view could fill: same time, ring traffic 73 -> 75 GB per 4K x 256 spp launch.) */
 #ifndef PT_PARK_Q
-#define PT_PARK_Q 256u /* ring entries per wave (a power of two) */
+#define PT_PARK_Q 512u
 #endif
 #ifndef PT_PARK_WALK
 #define PT_PARK_WALK 190u /* parked rays that turn the wave to walking (measured at 4K x 256 spp: 32: 664 ms, 64: 553, 128: 529, 190: 521) */
@@ -2408,7 +2415,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 #define PT_PARK_F64_FIELDS 13u /* o xyz, d xyz, T xyz, rng, min_t, (M_CHECKERED kernels: last u, v) */
 #define PT_PARK_U32_FIELDS 4u  /* best, depth << 6 | pixel slot, (last index), pad */
 static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * 128u && PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u <= 128u, "ring bytes per wave");
-static_assert((PT_PARK_Q & (PT_PARK_Q - 1u)) == 0u && PT_PARK_WALK + 64u <= PT_PARK_Q, "ring size");
+static_assert((PT_PARK_Q & (PT_PARK_Q - 1u)) == 0u && PT_PARK_WALK + 126u <= PT_PARK_Q, "ring size: see PT_PARK_Q");
 
 /* Entry-major, in three regions per wave, by who touches what:
  *   HOT  [PT_PARK_Q] x 64 bytes: o, d, min_t, best, depth/pixel -- all the WALKER reads (one 64-byte line per ray) and
