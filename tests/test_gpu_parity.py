@@ -1361,3 +1361,29 @@ def test_leading_walls_pruned_among_themselves(gpu, pt, seed):
     assert gs.kernel_name().startswith("pt_render_tiles_tri_queued") if seed >= 4 else gs.kernel_name() == "pt_render_tiles"
     gs.close()
     _full(gpu, pt, sc, hdr=True)
+
+
+def test_inside_a_mesh_every_ray_is_parked(gpu, pt):
+    """the camera inside a closed, bumpy mesh shell (an icosphere of 1,280 faces with every other vertex pushed in: not
+    convex, so no bounce is spared its walk), lit by a small sphere inside, 48 spp: every ray of every bounce is parked for
+    a hierarchy walk, a wave's pool is thousands of paths -- the ring, the waiting list and the walk-as-swap at their
+    busiest (a ring that could fill up would starve such a wave: PT_PARK_Q in pt_kernel.hip); frame and counters = oracle"""
+    import math
+    from rt_amd import abi, scene as S
+    tris = []
+    for tri in _icosphere(6.0, (0, 0, 0), 3):
+        out = []
+        for (x, y, z) in tri:
+            r = 1.0 - 0.08 * (math.sin(5 * x) * math.sin(7 * y + 1.0) * math.sin(3 * z + 2.0) > 0)  # a deterministic dimple pattern
+            out.append((x * r, y * r, z * r))
+        tris.append(out)  # counter-clockwise seen from outside: the reference's normal formula, cross(v2 - v0, v1 - v0), points INTO the shell
+    meshes = [dict(flags=abi.M_DEFAULT, color=(0.85, 0.8, 0.7), triangles=tris)]
+    objs = [dict(flags=abi.M_DEFAULT, radius=0.8, center=(0.5, 2.0, 0.3), color=(1, 1, 1), emission=(9, 8, 7)),
+            dict(flags=abi.M_REFLECTION, radius=1.0, center=(-2.0, -1.5, 1.0), color=(1, 1, 1))]
+    sc = S.custom_scene(objs, 48, 32, 48, 7, (0.2, -0.3, -3.5), (0.5, 0.5, 2.0), meshes=meshes)
+    assert sc.n_triangles == 1280
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name().startswith("pt_render_tiles_tri_queued")
+    gs.close()
+    st = _full(gpu, pt, sc)
+    assert st["casts"] > 3 * 48 * 32 * 48, "paths should bounce around inside the shell"
