@@ -1,7 +1,7 @@
 #!/bin/bash
 # the round's measurement session: default bench line (as the driver runs it), smoke, then rocprofv3 --stats +
 # PMC passes of configurations 4 (headline), 5 (at 256 spp), 3 and 2.   usage: TAG=r02d bash tools/gpu_profile_all.sh
-TAG=${TAG:-r03b}
+TAG=${TAG:-r03c}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout -k 10 120 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/smoke.log
