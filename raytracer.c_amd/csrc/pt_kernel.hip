@@ -147,6 +147,27 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 #define DIAG_LANES(slot) do { } while (0)
 #endif
 
+/* PT_PHASE builds (make variant NAME=phase DEFS="-DPT_PHASE"; tools/phase.py): where a wave's cycles go, phase by phase.
+ * PHASE(k) charges the shader cycles since the wave's previous mark (s_memtime) to phase k; at the kernel's end the sums go
+ * to stats[64 + k].  The marks cost a few instructions each (~3 % in all): a profile, not a benchmark.  Pooled kernels. */
+#ifdef PT_PHASE
+#define PT_PHASE_SLOTS 16
+__shared__ unsigned long long pt_phase_acc[PT_BLOCK / 64][PT_PHASE_SLOTS];
+__shared__ unsigned long long pt_phase_last[PT_BLOCK / 64];
+#define PHASE(k)                                                                            \
+  do                                                                                        \
+  {                                                                                         \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                             \
+    if ((threadIdx.x & 63u) == 0u)                                                          \
+    {                                                                                       \
+      pt_phase_acc[threadIdx.x >> 6][k] += t_ - pt_phase_last[threadIdx.x >> 6];            \
+      pt_phase_last[threadIdx.x >> 6] = t_;                                                 \
+    }                                                                                       \
+  } while (0)
+#else
+#define PHASE(k) do { } while (0)
+#endif
+
 constexpr double kEps = 1e-8;       /* raytracer.h:24 */
 constexpr double kPi = 3.14159265359; /* raytracer.h:22 */
 
@@ -1123,6 +1144,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       }
     }
 #endif
+    PHASE(1); /* phase 1: the filter */
     /* ---- phase 2: the exact test on each lane's own candidates, in index order: spheres ... ---- */
     while (cand_lo | cand_hi)
     {
@@ -1136,6 +1158,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       const uint32_t i = base + k;
       exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
     }
+    PHASE(2); /* phase 2: exact tests */
 #ifdef PT_DIAG
     /* a pruned wall must lose STRICTLY against what the scan found */
     for (uint32_t k = 0; k < 2u * PT_BIG_PAIRS; k++)
@@ -1957,7 +1980,16 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __shared__ uint32_t tile_pairs[PT_FILT_LDS_MAX / 64]; /* tile_cull: pairs a camera ray of this tile can reach, per chunk of 64 entries */
   __shared__ uint32_t wg_next_job;                      /* SWAP: jobs of the tile's pool handed out so far */
 
+#ifdef PT_PHASE
+  if ((threadIdx.x & 63u) == 0u)
+  {
+    for (int k = 0; k < PT_PHASE_SLOTS; k++)
+      pt_phase_acc[threadIdx.x >> 6][k] = 0;
+    pt_phase_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   SceneCtx S_init = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
+  PHASE(8); /* prologue: staging (scene -> LDS) */
   __shared__ __attribute__((aligned(16))) float big_tab[12]; /* BigPrune: delta, tmin, qmin of the leading wall-sized spheres */
   if (SWAP && FILT_LDS && !TRIS && L.big_pairs != 0u)
   {
@@ -1981,7 +2013,9 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     pix_key[threadIdx.x] = rt_rng_pixel_key(L.seed, ky * (uint32_t)L.width + kx);
   }
   camera_to_lds(L, cam_lds);
+  PHASE(9); /* prologue: pixel keys, camera, wall table */
   __syncthreads();
+  PHASE(10); /* prologue: first barrier */
 
   /* ---- this wave's pixels and job pool ---- */
   const uint32_t wave = threadIdx.x >> 6;
@@ -2049,6 +2083,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   uint32_t n_wait = 0; /* SWAP: paths in this wave's waiting list (wave-uniform) */
   double *const wf = &w_f[SWAP ? wave : 0][0][0];
   uint32_t *const wu = &w_u[SWAP ? wave : 0][0][0];
+  PHASE(11); /* prologue: tile_cull, its barrier, the wave's set-up */
   for (;;)
   {
     /* wave-uniform: this trip every busy lane holds a fresh camera ray of this tile (SWAP kernels) */
@@ -2091,6 +2126,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         __builtin_amdgcn_wave_barrier();
         idle = __ballot(!busy);
       }
+      PHASE(6); /* (of the trip's head: idle lanes take waiting paths from the list) */
       uint32_t batch = 0;
       if (idle != 0 && next_job < pool)
       { /* (idle lanes are left only when the list is dry: n_wait == 0 here) take the tile's next batch of 64 jobs */
@@ -2118,6 +2154,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         n_wait = (uint32_t)__popcll(bm);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        PHASE(7); /* (of the trip's head: the swap -- batch counter, busy lanes to the list) */
         const uint32_t job = batch + lane;
         busy = job < pool;
         if (busy)
@@ -2211,6 +2248,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     if (__ballot(busy) == 0)
       break; /* pool dry and every lane drained (an idle lane would have taken a waiting path): the one exit, reached by all lanes together */
     const uint32_t *const prim_pairs = (SWAP && FILT_LDS && primary_trip) ? tile_pairs : nullptr;
+    PHASE(0); /* the rest of the trip's head: the camera samples of a swap (start_sample) */
 
     bool step_done = false;
     /* lanes still sampling a direction from an earlier trip sit this trip's step out */
@@ -2284,6 +2322,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       n_rays++;
       step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 0, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit, prim_pairs);
     }
+    PHASE(3); /* hit record, roulette, material */
     /* ---- directions of diffuse hits: PT_DIR_ROUNDS rejection rounds per trip ----
      * A lane needs 1.91 rounds on average, but a loop that runs until the wave's last lane has
      * its sample takes ~6.2 (the maximum of ~45 geometric variables) at 20 % lane occupancy.
@@ -2316,6 +2355,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         hit.need_dir = false;
       }
     }
+    PHASE(4); /* direction rounds */
     if (busy)
     {
       /* This trip's radiance terms (emission of a hit that goes on, or what ends the path) go to the
@@ -2339,6 +2379,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         busy = false;
     }
     P.Ls = {0, 0, 0};
+    PHASE(5); /* radiance to the pixel sums */
   }
 
   if (n_rays)
@@ -2347,12 +2388,21 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     atomicAdd(&wg_stats[1], (unsigned long long)n_casts);
   }
   __syncthreads();
+  PHASE(12); /* epilogue: waiting for the workgroup's other waves */
 
   if (L.sample_chunks == 1)
   {
     finish_pixels(L, pix_sum, pix_nan, tile, out_f, out_b);
     __syncthreads();
     store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, true, true);
+    PHASE(13); /* epilogue: mean, tonemap, tile store */
+#ifdef PT_PHASE
+    /* one workgroup in 32 reports: same-address atomics from every wave would queue at one L2 channel and show up
+     * in the very phases measured (they did: 480 k atomics on config 2, prologue and epilogue each 3x too long) */
+    if ((threadIdx.x & 63u) == 0u && L.stats && (blockIdx.x & 31u) == 0u)
+      for (int k = 0; k < PT_PHASE_SLOTS; k++)
+        atomicAdd(&L.stats[64 + k], pt_phase_acc[threadIdx.x >> 6][k]);
+#endif
   }
   else
   {
@@ -2704,7 +2754,16 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
    * result known, park next); then the depth */
   constexpr uint32_t META_NEED_DIR = 64u, META_RESUMED = 128u, META_LEAVING = 256u, META_WAITING = 512u, META_DEPTH_SHIFT = 10u;
 
+#ifdef PT_PHASE
+  if ((threadIdx.x & 63u) == 0u)
+  {
+    for (int k = 0; k < PT_PHASE_SLOTS; k++)
+      pt_phase_acc[threadIdx.x >> 6][k] = 0;
+    pt_phase_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   SceneCtx S_init = stage_scene<true, FILT_LDS, true>(L, lds);
+  PHASE(8);
   __shared__ __attribute__((aligned(16))) float big_tab[12]; /* BigPrune: delta, tmin, qmin of the leading wall-sized spheres */
   if (L.big_pairs != 0u)
   {
@@ -2732,7 +2791,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   if (threadIdx.x == 0)
     park_slot_lds = pt_park_acquire(L);
   camera_to_lds(L, cam_lds);
+  PHASE(9);
   __syncthreads();
+  PHASE(10);
 
   const uint32_t wave = threadIdx.x >> 6;
   /* work units = tile_count x sample_chunks, chunk-major (consecutive units are different tiles); wave w of
@@ -2911,6 +2972,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       __builtin_amdgcn_wave_barrier();
       idle = __ballot(!busy);
     }
+    PHASE(6); /* walked rays from the ring to the list; idle lanes take waiting paths */
     /* enough rays are parked (or the ring is full): the wave owes them a walk.  It happens as soon as the list is
      * empty -- every live path is then in a lane and the list can take them all; until then no swap brings new paths */
     const bool walk_due = n_new >= PT_PARK_WALK || n_new + n_done >= PT_PARK_Q;
@@ -2954,6 +3016,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       primary_trip = true;
     }
     (void)primary_trip;
+    PHASE(7); /* the swap and its camera samples */
     /* nobody holds a ray: the pool is dry, the list and the ring's walked part are empty (an idle lane would have
      * taken from them).  Parked rays, if any, are walked now; otherwise this is the one exit. */
     const bool drained = __ballot(busy) == 0;
@@ -2988,13 +3051,16 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       hit.last.v = 0;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      PHASE(14); /* every path to the list before a walk */
       walk_parked<CHECKER>(S, ring, (head + n_done) & (PT_PARK_Q - 1u), n_new, stack, diag_ptr);
+      PHASE(15); /* walking the parked rays */
       n_done += n_new;
       n_new = 0u;
       continue;
     }
 
     /* ---- first half of trace_path(): depth test + flat scan over the spheres, then the probe ---- */
+    PHASE(0);
     const bool stepping = busy && !hit.need_dir && !resumed && !waiting;
     bool want_walk = waiting;
 #ifdef PT_DIAG
@@ -3072,11 +3138,13 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       n_new += min((uint32_t)__popcll(wants), space);
     }
 
+    PHASE(11); /* depth test, the mesh probe, parking (what the sphere scan's two marks leave) */
     /* ---- second half: hit record, roulette, material -- for rays scanned now and not parked, and for
      * walked rays resumed at the top of this trip ---- */
     bool step_done = false;
     if (busy && (stepping || resumed) && !waiting)
       step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+    PHASE(3);
 
     /* ---- directions of diffuse hits (see render_tiles_pooled) ---- */
     if (busy && hit.need_dir)
@@ -3104,6 +3172,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         hit.leaving = (hit.dir_slot & PT_HULL_PLUS) != 0u && weight > S.hull_margin; /* weight = the new direction . n */
       }
     }
+    PHASE(4);
     if (busy)
     {
       /* this trip's radiance terms go to the pixel's fixed-point sum at once (integer adds commute and
@@ -3126,8 +3195,14 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       if (step_done)
         busy = false;
     }
+    PHASE(5);
   }
 
+#ifdef PT_PHASE
+  if ((threadIdx.x & 63u) == 0u && L.stats && (blockIdx.x & 31u) == 0u)
+    for (int k = 0; k < PT_PHASE_SLOTS; k++)
+      atomicAdd(&L.stats[64 + k], pt_phase_acc[threadIdx.x >> 6][k]);
+#endif
   /* ---- this wave's tile: counters, then the pixels (thread = pixel) ---- */
   if (has_unit)
   {
