@@ -329,8 +329,45 @@ __device__ __forceinline__ BvhRay bvh_ray(const V3 &o, const V3 &d)
   return {{(float)o.x, (float)o.x}, {(float)o.y, (float)o.y}, {(float)o.z, (float)o.z}, {ixs, ixs}, {iys, iys}, {izs, izs}};
 }
 
+/* v_min / v_max / v_min3 / v_max3 as the hardware has them: a NaN operand is ignored (the other comes back), which is
+ * what the slab test relies on (bvh_traverse).  Through the builtins the compiler first "canonicalises" every operand
+ * it cannot prove quiet (v_max_f32 x, x, x): twelve extra instructions per node visit. */
+__device__ __forceinline__ float hw_min(float a, float b)
+{
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_max(float a, float b)
+{
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_min3(float a, float b, float c)
+{
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float hw_max3(float a, float b, float c)
+{
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+/* A float that is not below x, for x > 0 (inf and NaN pass through): the closest hit so far as the slab tests see it.
+ * RN(x) lies at most half an ulp below x, so one ulp up is above it; callers keep the value per ray and renew it when
+ * min_t changes (__double2float_ru is a 15-instruction sequence on this target, and it ran in every node visit). */
+__device__ __forceinline__ float float_above(double x)
+{
+  const float f = (float)x;
+  return f < __builtin_inff() ? __uint_as_float(__float_as_uint(f) + 1u) : f;
+}
+
 /* One visit: the boxes of node `ref`'s two children against the ray (see bvh_traverse for
- * the bounds that make it conservative).  tmax = the closest hit so far rounded up to fp32. */
+ * the bounds that make it conservative).  tmax = a float not below the closest hit so far (float_above). */
 __device__ __forceinline__ void bvh_test_children(const float *__restrict__ nodes, uint32_t ref, const BvhRay &R,
                                                   bool far_origin, float tmax, bool &hit0, bool &hit1, float &tn0,
                                                   float &tn1, uint32_t &r0, uint32_t &r1)
@@ -342,10 +379,10 @@ __device__ __forceinline__ void bvh_test_children(const float *__restrict__ node
   const f32x2 tx1 = (f32x2{px.x, px.y} - R.ox) * R.ix, tx2 = (f32x2{px.z, px.w} - R.ox) * R.ix;
   const f32x2 ty1 = (f32x2{py.x, py.y} - R.oy) * R.iy, ty2 = (f32x2{py.z, py.w} - R.oy) * R.iy;
   const f32x2 tz1 = (f32x2{pz.x, pz.y} - R.oz) * R.iz, tz2 = (f32x2{pz.z, pz.w} - R.oz) * R.iz;
-  tn0 = fmaxf(fmaxf(fminf(tx1.x, tx2.x), fminf(ty1.x, ty2.x)), fminf(tz1.x, tz2.x));
-  float tf0 = fminf(fminf(fmaxf(tx1.x, tx2.x), fmaxf(ty1.x, ty2.x)), fmaxf(tz1.x, tz2.x));
-  tn1 = fmaxf(fmaxf(fminf(tx1.y, tx2.y), fminf(ty1.y, ty2.y)), fminf(tz1.y, tz2.y));
-  float tf1 = fminf(fminf(fmaxf(tx1.y, tx2.y), fmaxf(ty1.y, ty2.y)), fmaxf(tz1.y, tz2.y));
+  tn0 = hw_max3(hw_min(tx1.x, tx2.x), hw_min(ty1.x, ty2.x), hw_min(tz1.x, tz2.x));
+  float tf0 = hw_min3(hw_max(tx1.x, tx2.x), hw_max(ty1.x, ty2.x), hw_max(tz1.x, tz2.x));
+  tn1 = hw_max3(hw_min(tx1.y, tx2.y), hw_min(ty1.y, ty2.y), hw_min(tz1.y, tz2.y));
+  float tf1 = hw_min3(hw_max(tx1.y, tx2.y), hw_max(ty1.y, ty2.y), hw_max(tz1.y, tz2.y));
   tn0 -= fabsf(tn0) * widen;
   tf0 += fabsf(tf0) * widen;
   tn1 -= fabsf(tn1) * widen;
@@ -382,7 +419,7 @@ __device__ __forceinline__ bool bvh_probe(const float *__restrict__ nodes, uint3
   {
     float tn0, tn1;
     uint32_t r0, r1;
-    bvh_test_children(nodes, 0u, bvh_ray(o, d), far_origin, __double2float_ru(min_t), hit0, hit1, tn0, tn1, r0, r1);
+    bvh_test_children(nodes, 0u, bvh_ray(o, d), far_origin, float_above(min_t), hit0, hit1, tn0, tn1, r0, r1);
   }
   const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
   const float lx = mb.cx - (float)o.x, ly = mb.cy - (float)o.y, lz = mb.cz - (float)o.z;
@@ -484,6 +521,7 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
   uint32_t sp = 0;
   uint32_t ref = 0; /* the root node */
   bool done = false;
+  float tmax = (LAST && no_prune) ? 3.4028234663852886e38f : float_above(min_t); /* renewed after every leaf */
   /* "while-while": lanes first descend until each holds a leaf (or has finished), then the
    * leaves are tested together -- the exact triangle test, the expensive block, runs with all
    * the lanes that have one instead of whenever a single lane happens to reach a leaf */
@@ -496,8 +534,7 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
       bool hit0, hit1;
       float tn0, tn1;
       uint32_t r0, r1;
-      bvh_test_children(nodes, ref, R, far_origin, (LAST && no_prune) ? 3.4028234663852886e38f : __double2float_ru(min_t),
-                        hit0, hit1, tn0, tn1, r0, r1);
+      bvh_test_children(nodes, ref, R, far_origin, tmax, hit0, hit1, tn0, tn1, r0, r1);
       if (hit0 && hit1)
       {
         const bool zero_first = !(tn1 < tn0);
@@ -526,6 +563,8 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
       keep &= keep - 1u;
       exact_triangle<true, LAST>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v, last);
     }
+    if (!(LAST && no_prune))
+      tmax = float_above(min_t);
     if (sp == 0)
       break;
     sp--;
@@ -2544,28 +2583,66 @@ __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
 
 /* The per-lane traversal stacks of the parked-walk kernels: 24-bit entries (a 16-bit and an 8-bit array, entry-major,
  * one entry per tree level and lane), because at four workgroups per CU every kilobyte of LDS counts there.  A reference
- * fits 24 bits while node indices stay below 2^23 and leaf references below 2^23 + 2^20 triangles (PT_WALK_REF_OK,
- * checked on the host: other meshes take the lane-waiting kernels). */
+ * fits 24 bits while node indices stay below 2^23 and leaf references below 2^23 + 2^20 triangles (checked on the host,
+ * pt_pick_kernel: other meshes take the lane-waiting kernels).
+ *
+ * Round 3: the bits a mesh's references do not need hold the DISTANCE at which the waiting child's box is entered, so
+ * that a pop can drop it without a visit.  The nearer child is entered first and the other waits; by the time it is
+ * popped the walk has usually found a hit in front of it, yet the pop cost a whole visit (a 64-byte node fetch and ~65
+ * instructions, or a leaf's pre-tests) only to learn that both its children start beyond min_t.  ref_bits = the bits of
+ * the largest reference + the leaf flag (pt_walk_ref_bits, wave-uniform: 18 for config 5's 10,240 triangles), the
+ * remaining 24 - ref_bits (at most 8) hold code(tn) of the waiting box's widened entry distance tn (bvh_test_children),
+ * where code(t) = trunc(min(max(t qs + qb, 0), levels - 1)) maps the ray's chord through the triangles' bounding sphere
+ * (walk_quantiser, per ray at the refill) linearly onto 0 .. levels - 1.  All that safety needs of code() is that it is
+ * MONOTONE (fma, max, min and the truncation all are, for qs >= 0): code(tn) > code(tmax) implies tn > tmax >= min_t, the
+ * very condition under which bvh_test_children rejects a box (a box entered beyond the closest hit cannot hold a
+ * closer one, nor one that ties with it) -- applied with the min_t of the pop instead of that of the push.  A coarse
+ * code only means fewer drops.  NaN -> 0 (v_max returns the other operand): never dropped; far_origin lanes and the
+ * M_CHECKERED / stale-uv walks, which do not prune by min_t at all, store 0. */
+#ifndef PT_POP_DROP
+#define PT_POP_DROP 0 /* 1: form the codes and drop (measured: 13 % fewer node visits, +0.3 % time -- the codes cost what they save) */
+#endif
 struct WalkStack
 {
   uint16_t *lo; /* [levels][PT_BLOCK] */
   uint8_t *hi;  /* [levels][PT_BLOCK] */
+  uint32_t ref_bits; /* wave-uniform */
+  float top_code;    /* levels - 1 as a float */
 };
-#define PT_WALK_LEAF_FLAG24 0x800000u
-__device__ __forceinline__ uint32_t walk_ref24(uint32_t ref) /* PT_BVH_LEAF_FLAG (bit 31) moves to bit 23 */
+/* per ray: code(t) = t qs + qb over the chord [t_in, t_out] of the ray through the bounding sphere (cx cy cz, r2_hi);
+ * anything degenerate (no chord, overflow, NaN) gives qs = qb = 0: every code 0, nothing is ever dropped */
+__device__ __forceinline__ void walk_quantiser(const MeshBound &mb, const V3 &o, const V3 &d, float top_code, float &qs, float &qb)
 {
-  return (ref & 0x7FFFFFu) | ((ref >> 8) & PT_WALK_LEAF_FLAG24);
+  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  const float lx = mb.cx - (float)o.x, ly = mb.cy - (float)o.y, lz = mb.cz - (float)o.z;
+  const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  const float tca = __builtin_fmaf(lz, dz, __builtin_fmaf(ly, dy, lx * dx));
+  const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+  const float disc = __builtin_fmaf(tca, tca, -dd * (ll - mb.r2_hi));
+  const float root = __builtin_amdgcn_sqrtf(disc);
+  const float inv_dd = __builtin_amdgcn_rcpf(dd);
+  const float t_in = fmaxf((tca - root) * inv_dd, 0.0f), t_out = (tca + root) * inv_dd;
+  const float s = (top_code + 1.0f) * __builtin_amdgcn_rcpf(t_out - t_in);
+  const float b = -t_in * s;
+  const bool ok = (s >= 0.0f) & (s < 1e30f) & (b > -1e30f) & (b <= 0.0f); /* false for NaN */
+  qs = ok ? s : 0.0f;
+  qb = ok ? b : 0.0f;
 }
-__device__ __forceinline__ uint32_t walk_ref32(uint32_t r24) { return (r24 & 0x7FFFFFu) | ((r24 & PT_WALK_LEAF_FLAG24) << 8); }
-__device__ __forceinline__ void walk_push(const WalkStack &st, uint32_t sp, uint32_t ref)
+__device__ __forceinline__ uint32_t walk_code(float t, float qs, float qb, float top_code)
 {
-  const uint32_t r = walk_ref24(ref);
+  return (uint32_t)fminf(fmaxf(__builtin_fmaf(t, qs, qb), 0.0f), top_code);
+}
+__device__ __forceinline__ void walk_push(const WalkStack &st, uint32_t sp, uint32_t ref, uint32_t code)
+{ /* PT_BVH_LEAF_FLAG (bit 31) moves to bit ref_bits - 1, the code sits above it */
+  const uint32_t r = (ref & ((1u << (st.ref_bits - 1u)) - 1u)) | ((ref >> 31) << (st.ref_bits - 1u)) | (code << st.ref_bits);
   st.lo[sp * PT_BLOCK + threadIdx.x] = (uint16_t)r;
   st.hi[sp * PT_BLOCK + threadIdx.x] = (uint8_t)(r >> 16);
 }
-__device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp)
+__device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp, uint32_t &code)
 {
-  return walk_ref32((uint32_t)st.lo[sp * PT_BLOCK + threadIdx.x] | ((uint32_t)st.hi[sp * PT_BLOCK + threadIdx.x] << 16));
+  const uint32_t r = (uint32_t)st.lo[sp * PT_BLOCK + threadIdx.x] | ((uint32_t)st.hi[sp * PT_BLOCK + threadIdx.x] << 16);
+  code = r >> st.ref_bits;
+  return (r & ((1u << (st.ref_bits - 1u)) - 1u)) | (((r >> (st.ref_bits - 1u)) & 1u) << 31);
 }
 
 /* The wave walks the n_new parked rays at ring positions first, first + 1, ... (see the header
@@ -2575,7 +2652,7 @@ __device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp)
  * is live in registers while the wave walks. */
 template <bool CHECKER>
 __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &ring, uint32_t first, uint32_t n_new,
-                                            const WalkStack &stack, unsigned long long *diag_ptr)
+                                            const WalkStack &stack, unsigned long long *diag_ptr, bool diag_walk_dropped = false)
 {
   /* parked state written by this wave's lanes (plain stores) must have reached L2 before other
    * lanes load it: workgroup-scope release = s_waitcnt vmcnt(0) */
@@ -2590,6 +2667,48 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
   BvhRay R = bvh_ray(wo, wd);
   TriLast last = {-1, 0, 0};
   const bool no_prune = CHECKER && S.stale_uv;
+  float qs = 0.f, qb = 0.f; /* the ray's distance code (WalkStack) */
+  float wtmax = 0.f;        /* a float not below wmin_t (float_above), renewed when wmin_t changes: what the slab tests prune by */
+  /* the next waiting box that can still matter: entries whose box starts beyond the closest hit so far are dropped
+   * without a visit (WalkStack); none left: the walk is finished */
+#ifdef PT_DIAG
+  /* the re-check of that rule: a dropped box is walked all the same, and nothing found below it may change the result */
+  bool in_dropped = false;
+  uint32_t dropped_sp = 0;
+#endif
+  auto pop_live = [&](bool &finished) {
+    const uint32_t code_now = PT_POP_DROP ? walk_code(wtmax, qs, qb, stack.top_code) : 0u;
+    for (;;)
+    {
+#ifdef PT_DIAG
+      if (in_dropped && sp == dropped_sp)
+        in_dropped = false; /* the dropped box's subtree is done */
+#endif
+      if (sp == 0)
+      {
+        finished = true;
+        return;
+      }
+      sp--;
+      uint32_t code;
+      ref = walk_pop(stack, sp, code);
+      if (!PT_POP_DROP || !(code > code_now))
+        return;
+#ifdef PT_DIAG
+      if (!in_dropped)
+        atomicAdd(&diag_ptr[4 + 38], 1ull); /* waiting boxes dropped at the pop */
+      if (diag_walk_dropped)
+      { /* RT_HIP_DIAG_WALK_REJECTED=1: walked all the same, without pruning, and checked (otherwise: dropped, as shipped) */
+        if (!in_dropped)
+        {
+          in_dropped = true;
+          dropped_sp = sp;
+        }
+        return;
+      }
+#endif
+    }
+  };
 #ifdef PT_DIAG
   uint32_t visits = 0;
   int wbest0 = wbest;
@@ -2611,13 +2730,17 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         wd = ring_ld3(ring, 3u, e);
         wmin_t = ring_ld(ring, 10u, e);
         wbest = (int)ring_ldu(ring, 0u, e);
+        wtmax = no_prune ? 3.4028234663852886e38f : float_above(wmin_t);
         R = bvh_ray(wo, wd);
         far_origin = !(v_dot(wo, wo) <= S.near_R2);
+        if (PT_POP_DROP)
+          walk_quantiser(S.mesh_bound, wo, wd, (far_origin || no_prune) ? -1.0f : stack.top_code, qs, qb); /* (-1: levels = 0, every code 0) */
         sp = 0;
         ref = 0; /* the root */
         last.idx = -1;
         have = true;
 #ifdef PT_DIAG
+        in_dropped = false;
         visits = 0;
         wbest0 = wbest;
         outside_bound = (ring_ldu(ring, 1u, e) & 0x80000000u) != 0u;
@@ -2645,24 +2768,23 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         bool hit0, hit1;
         float tn0, tn1;
         uint32_t r0, r1;
-        bvh_test_children(S.bvh_nodes, ref, R, far_origin, no_prune ? 3.4028234663852886e38f : __double2float_ru(wmin_t), hit0,
-                          hit1, tn0, tn1, r0, r1);
+#ifdef PT_DIAG
+        const bool diag_all = in_dropped; /* below a dropped box: every triangle the ray passes gets its exact test */
+#else
+        const bool diag_all = false;
+#endif
+        bvh_test_children(S.bvh_nodes, ref, R, far_origin, diag_all ? 3.4028234663852886e38f : wtmax, hit0, hit1, tn0, tn1, r0, r1);
         if (hit0 && hit1)
         {
           const bool zero_first = !(tn1 < tn0);
-          walk_push(stack, sp, zero_first ? r1 : r0);
+          walk_push(stack, sp, zero_first ? r1 : r0, PT_POP_DROP ? walk_code(zero_first ? tn1 : tn0, qs, qb, stack.top_code) : 0u);
           sp++;
           ref = zero_first ? r0 : r1;
         }
         else if (hit0 || hit1)
           ref = hit0 ? r0 : r1;
-        else if (sp == 0)
-          finished = true;
         else
-        {
-          sp--;
-          ref = walk_pop(stack, sp);
-        }
+          pop_live(finished);
       }
     }
     else if (at_leaf)
@@ -2679,6 +2801,10 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
           atomicAdd(&diag_ptr[4 + 12], 1ull);
       }
 #endif
+#ifdef PT_DIAG
+      const int diag_best_before = wbest;
+      const double diag_t_before = wmin_t;
+#endif
       while (keep != 0u)
       {
         DIAG(14, 1);
@@ -2687,13 +2813,13 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         const uint32_t t = S.bvh_tri[first_tri + k];
         exact_triangle<true, CHECKER>(S.tri_leaf + 9 * (size_t)(first_tri + k), S.n_sph + t, wo, wd, wmin_t, wbest, bu, bv, &last);
       }
-      if (sp == 0)
-        finished = true;
-      else
-      {
-        sp--;
-        ref = walk_pop(stack, sp);
-      }
+      if (!no_prune)
+        wtmax = float_above(wmin_t);
+#ifdef PT_DIAG
+      if (in_dropped && (wbest != diag_best_before || wmin_t != diag_t_before))
+        atomicAdd(&diag_ptr[4 + 12], 1ull); /* a box dropped at the pop held the closest hit (or a tie that wins) */
+#endif
+      pop_live(finished);
     }
     if (finished)
     {
@@ -2780,6 +2906,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     stack.lo = reinterpret_cast<uint16_t *>(lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
                                                    pt_filt_pair_slots(S.n_sph)));
     stack.hi = reinterpret_cast<uint8_t *>(stack.lo + (size_t)levels * PT_BLOCK);
+    stack.ref_bits = pt_walk_ref_bits(L.scene);
+    stack.top_code = (float)((1u << min(24u - stack.ref_bits, 8u)) - 1u);
   }
   {
     unsigned long long *z = &pix_sum_all[0][0];
@@ -3000,11 +3128,17 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           s = job >> 6;
         }
         else
-        {
-          s = job / n_valid;
-          idx = job - s * n_valid;
+        { /* ragged edge tiles only: the divisors go through a register the compiler cannot see through, or it forms their
+           * reciprocals ahead of the trip loop and keeps them (in scratch memory: the kernel has no register to spare) */
+          uint32_t nv = n_valid;
+          asm volatile("" : "+v"(nv));
+          s = job / nv;
+          idx = job - s * nv;
         }
-        const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
+        uint32_t vc = vcols;
+        if (vcols != PT_TILE)
+          asm volatile("" : "+v"(vc));
+        const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vc);
         const uint32_t col = idx - row * vcols;
         pix_slot = row * PT_TILE + col;
         start_sample(P, load_camera_lds(cam_lds), rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col),
@@ -3052,7 +3186,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       PHASE(14); /* every path to the list before a walk */
-      walk_parked<CHECKER>(S, ring, (head + n_done) & (PT_PARK_Q - 1u), n_new, stack, diag_ptr);
+      walk_parked<CHECKER>(S, ring, (head + n_done) & (PT_PARK_Q - 1u), n_new, stack, diag_ptr, (L.diag_flags & 1u) != 0u);
       PHASE(15); /* walking the parked rays */
       n_done += n_new;
       n_new = 0u;
