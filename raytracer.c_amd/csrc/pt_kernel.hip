@@ -3038,10 +3038,18 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         if (lane < k)
         {
           const uint32_t e = (head + lane) & (PT_PARK_Q - 1u);
+          /* all thirteen loads first, then the stores: written as load / store pairs the compiler keeps each (atomic) load
+           * and the LDS store of its value in program order, i.e. thirteen memory round trips one after the other */
+          double fv[11];
+#pragma unroll
           for (uint32_t f = 0; f < 11u; f++)
-            wf[f * 64u + lane] = ring_ld(ring, f, e);
-          wu[64u + lane] = ring_ldu(ring, 0u, e); /* best */
+            fv[f] = ring_ld(ring, f, e);
+          const uint32_t best_w = ring_ldu(ring, 0u, e);
           const uint32_t dp = ring_ldu(ring, 1u, e) & 0x3FFFFFFFu; /* depth << 6 | pixel slot; bits 31, 30: PT_DIAG's flags */
+#pragma unroll
+          for (uint32_t f = 0; f < 11u; f++)
+            wf[f * 64u + lane] = fv[f];
+          wu[64u + lane] = best_w;
           wu[lane] = (dp & 63u) | META_RESUMED | ((dp >> 6) << META_DEPTH_SHIFT);
           if (CHECKER)
           {
