@@ -2403,9 +2403,11 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
        * radiance lives in registers from one trip to the next. */
       if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
-        atomicAdd(&pix_sum[3 * pix_slot + 0], fixed_term(P.Ls.x, L.acc_scale));
-        atomicAdd(&pix_sum[3 * pix_slot + 1], fixed_term(P.Ls.y, L.acc_scale));
-        atomicAdd(&pix_sum[3 * pix_slot + 2], fixed_term(P.Ls.z, L.acc_scale));
+        /* (3 * pix_slot through v_mul_u32_u24: the compiler's v_mul_lo_u32 issues at a quarter of the rate) */
+        unsigned long long *const px = &pix_sum[__umul24(pix_slot, 3u)];
+        atomicAdd(&px[0], fixed_term(P.Ls.x, L.acc_scale));
+        atomicAdd(&px[1], fixed_term(P.Ls.y, L.acc_scale));
+        atomicAdd(&px[2], fixed_term(P.Ls.z, L.acc_scale));
         /* a NaN term (a ray through a degenerate normal, say) has no integer: flag the pixel, see finish_pixels */
         if ((int)(P.Ls.x != P.Ls.x) | (int)(P.Ls.y != P.Ls.y) | (int)(P.Ls.z != P.Ls.z))
         {
@@ -3322,9 +3324,11 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
         unsigned long long *const pix_sum = pix_sum_all[wave_now()];
-        atomicAdd(&pix_sum[3 * pix_slot + 0], fixed_term(P.Ls.x, L.acc_scale));
-        atomicAdd(&pix_sum[3 * pix_slot + 1], fixed_term(P.Ls.y, L.acc_scale));
-        atomicAdd(&pix_sum[3 * pix_slot + 2], fixed_term(P.Ls.z, L.acc_scale));
+        /* (3 * pix_slot through v_mul_u32_u24: the compiler's v_mul_lo_u32 issues at a quarter of the rate) */
+        unsigned long long *const px = &pix_sum[__umul24(pix_slot, 3u)];
+        atomicAdd(&px[0], fixed_term(P.Ls.x, L.acc_scale));
+        atomicAdd(&px[1], fixed_term(P.Ls.y, L.acc_scale));
+        atomicAdd(&px[2], fixed_term(P.Ls.z, L.acc_scale));
         if ((int)(P.Ls.x != P.Ls.x) | (int)(P.Ls.y != P.Ls.y) | (int)(P.Ls.z != P.Ls.z))
         {
           unsigned long long *const pix_nan = pix_nan_all[wave_now()];
