@@ -606,7 +606,9 @@ struct FiltRay
   f32x2 dx, dy, dz;
   /* sign-test form: o'.d, |o'|^2 and -2 o' of the pulled-back origin o' (see filter_chunk) */
   float od, oo, m2ox, m2oy, m2oz;
-  bool far_origin;
+  /* (a 32-bit member, not a bool: next to a bool the compiler took the neighbouring float to pieces, byte by byte, when it
+   * copied the struct -- nine instructions of shifts and byte selects per trip to put m2oz back together) */
+  uint32_t far_origin;
 };
 
 template <bool SHIFT>
@@ -1544,6 +1546,13 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
   V3 add = {S.bg, S.bg, S.bg}; /* what this call contributes if the path ends here */
   bool path_ends = true;
   const V3 o = P.o, d = P.d;
+  /* DEFER_DIR callers (the pooled and parked-walk kernels) flush a path's radiance to the pixel sums every trip: P.Ls is
+   * zero on entry, and this call's one term -- the hit's emission whether the path goes on or dies in the roulette,
+   * BACKGROUND if it found nothing or ran out of depth -- is the throughput AT ENTRY times `add`.  Formed once, at the
+   * end, instead of accumulated into P.Ls in two places (three products, three "+ 0" the compiler may not fold, three more
+   * additions and six selects per trip).  Scenes with M_REFRACTION (two children share a term) keep the general form. */
+  constexpr bool ONE_TERM = DEFER_DIR && !REFRACT;
+  const V3 T_in = P.T;
   HitRec local;
   HitRec &H = (MODE == 0 && !DEFER_DIR) ? local : *rec;
 
@@ -1695,6 +1704,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           /* reflect :349-352; direction left un-normalised (:542) */
           const double dn = v_dot(d, n);
           nd = v_sub(d, v_scale(n, 2 * dn));
+          if (ONE_TERM)
+            P.T = v_mul(P.T, albedo); /* here, under the branch's own lane mask, instead of three products and six selects below */
           /* nd . n = -(d . n) up to rounding far below the margin */
           if (TRIS && (MODE != 0 || DEFER_DIR))
             H.leaving = (hull & PT_HULL_PLUS) ? (-dn > S.hull_margin) : ((hull & PT_HULL_MINUS) ? (dn > S.hull_margin) : false);
@@ -1728,8 +1739,9 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
         /* L = e + albedo (.) (L_next * cos)  ==>  forward form */
         if (!split)
         {
-          P.Ls = v_add(P.Ls, v_mul(P.T, emission));
-          if (!(DEFER_DIR && dir_deferred))
+          if (!ONE_TERM)
+            P.Ls = v_add(P.Ls, v_mul(P.T, emission));
+          if (!ONE_TERM && !(DEFER_DIR && dir_deferred))
             P.T = v_mul(P.T, (flags & PT_FLAG_MIRROR) ? albedo : v_scale(albedo, weight));
         }
         P.o = p;
@@ -1738,9 +1750,12 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       }
     }
   }
+  if (ONE_TERM)
+    P.Ls = v_mul(T_in, add); /* (add = the hit's emission, or BACKGROUND) */
   if (path_ends)
   {
-    P.Ls = v_add(P.Ls, v_mul(P.T, add));
+    if (!ONE_TERM)
+      P.Ls = v_add(P.Ls, v_mul(P.T, add));
     if (REFRACT && stack_n > 0)
     {
       /* this branch of the tree is done: resume the most recent pending child; the RNG
