@@ -278,7 +278,12 @@ struct TriLast
   double u, v; /* its barycentrics */
 };
 
-template <bool TIE = false, bool LAST = false>
+/* UNSCALED: 1.0 / a through rcp_unscaled -- the same quotient for 2^-500 <= |a| <= 2^500 (either sign: the scaling steps it
+ * leaves out act on magnitudes only; checked on the device, test_device_math_shortcuts_are_bit_exact).  |a| >= 1e-8 here, and
+ * the kernels that pass true run only scenes whose every centre, radius and bounding sphere is within 1e17
+ * (PtSceneView.wide_range == 0: pt_filter_in_lds, pt_pick_kernel), so |a| <= |e1||e2||d| < 1e36.  (a = NaN or inf: no hit
+ * either way -- t comes out NaN or 0, never above EPSILON.)  Four instructions less per test than the general division. */
+template <bool TIE = false, bool LAST = false, bool UNSCALED = false>
 __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, const V3 &o, const V3 &d,
                                                double &min_t, int &best, double &bary_u, double &bary_v,
                                                TriLast *last = nullptr)
@@ -288,7 +293,7 @@ __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, 
   double a = v_dot(e1, h);
   if (!(a > -kEps && a < kEps))
   {
-    double f = 1.0 / a;
+    double f = UNSCALED ? rcp_unscaled(a) : 1.0 / a;
     V3 sv = v_sub(o, v0);
     double u = f * v_dot(sv, h);
     if (!(u < 0.0 || u > 1.0))
@@ -783,7 +788,7 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
           /* ... and, of the walls that may PRUNE (a certain hit ahead with a half-chord of r / 16 at least), the nearest */
           const float px = ((qx > qmin[2 * p]) & (tx > tmin)) ? tx : quiet_nan;     /* (t32 > tmin > 0 implies tca32' > 0) */
           const float py = ((qy > qmin[2 * p + 1]) & (ty > tmin)) ? ty : quiet_nan;
-          m = __builtin_fminf(m, __builtin_fminf(px, py));
+          m = hw_min(m, hw_min(px, py)); /* (v_min_f32 itself: NaN-ignoring, and no canonicalising v_max x, x before it) */
         }
       }
       const float thr = m + delta;
@@ -1226,7 +1231,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
         tri_lo = in_lo ? cleared : 0u;
         tri_hi = in_lo ? tri_hi : cleared;
         const uint32_t i = base + k;
-        exact_triangle<false, LAST>(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v, last);
+        exact_triangle<false, LAST, FILT_LDS>(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v, last); /* (FILT_LDS: no wide-range scene) */
       }
   }
   if (BVH && WALK) /* WALK = false: the caller walks the hierarchy itself, later (render_tiles_pooled) */
@@ -2608,7 +2613,7 @@ __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
  * popped the walk has usually found a hit in front of it, yet the pop cost a whole visit (a 64-byte node fetch and ~65
  * instructions, or a leaf's pre-tests) only to learn that both its children start beyond min_t.  ref_bits = the bits of
  * the largest reference + the leaf flag (pt_walk_ref_bits, wave-uniform: 18 for config 5's 10,240 triangles), the
- * remaining 24 - ref_bits (at most 8) hold code(tn) of the waiting box's widened entry distance tn (bvh_test_children),
+ * remaining bits (24 less those; at most 8) hold code(tn) of the waiting box's widened entry distance tn (bvh_test_children),
  * where code(t) = trunc(min(max(t qs + qb, 0), levels - 1)) maps the ray's chord through the triangles' bounding sphere
  * (walk_quantiser, per ray at the refill) linearly onto 0 .. levels - 1.  All that safety needs of code() is that it is
  * MONOTONE (fma, max, min and the truncation all are, for qs >= 0): code(tn) > code(tmax) implies tn > tmax >= min_t, the
@@ -2828,7 +2833,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         const uint32_t k = (uint32_t)__builtin_ctz(keep);
         keep &= keep - 1u;
         const uint32_t t = S.bvh_tri[first_tri + k];
-        exact_triangle<true, CHECKER>(S.tri_leaf + 9 * (size_t)(first_tri + k), S.n_sph + t, wo, wd, wmin_t, wbest, bu, bv, &last);
+        exact_triangle<true, CHECKER, true>(S.tri_leaf + 9 * (size_t)(first_tri + k), S.n_sph + t, wo, wd, wmin_t, wbest, bu, bv, &last); /* (parked-walk kernels: no wide-range scene) */
       }
       if (!no_prune)
         wtmax = float_above(wmin_t);

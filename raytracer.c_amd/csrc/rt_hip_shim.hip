@@ -605,7 +605,11 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     for (size_t k = 0; k < 3 * meshes[m].num_triangles; k++)
     {
       const double *q = meshes[m].vertices[k].pos;
-      reach = std::fmax(reach, std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]));
+      const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+      reach = std::fmax(reach, len);
+      /* a vertex beyond 1e17 (or non-finite): the scene takes the kernels with NaN-safe compares and the general fp64
+       * division in the triangle test (exact_triangle's UNSCALED form assumes |e1||e2| < 1e36) */
+      wide_range |= !(len <= 1e17);
     }
   for (size_t m = 0; m < n_meshes; m++)
   {

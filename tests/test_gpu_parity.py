@@ -413,6 +413,9 @@ def test_device_math_shortcuts_are_bit_exact(gpu):
     y = np.concatenate([lens, 10.0 ** rng.uniform(-150, 150, 200000),
                         np.array([2.0 ** -30, 1.0, 1.0 - 2.0 ** -53, 2.0 ** -500, 2.0 ** 500, 3.0, 1.0 / 3.0])])
     assert np.array_equal(run(5, y, y), 1.0 / y), "unscaled reciprocal differs from IEEE division"
+    # ... and of either sign: intersect_triangle's 1.0 / a (exact_triangle<.., UNSCALED>), |a| >= 1e-8
+    z = np.concatenate([-y, 10.0 ** rng.uniform(-8, 36, 200000) * rng.choice([-1.0, 1.0], 200000), np.array([1e-8, -1e-8, -3.0])])
+    assert np.array_equal(run(5, z, z), 1.0 / z), "unscaled reciprocal of a negative value differs from IEEE division"
 
 
 def _random_scene(seed, with_mesh, n_tris, extra_flags=(), materials="all"):
@@ -699,6 +702,14 @@ def test_wide_range_scene_keeps_the_nan_safe_filter(gpu, pt):
     tri = [[(-3, -4.9, 3, 0, 0), (3, -4.9, 3, 1, 0), (0, 2, 3, 0, 1)], [(-3, -4.9, 3, 0, 0), (0, 2, 3, 0, 1), (3, -4.9, 3, 1, 0)]]
     meshes = [dict(flags=abi.M_DEFAULT, color=(0.9, 0.8, 0.2), triangles=tri)]
     _full(gpu, pt, S.custom_scene(objs, 48, 32, 4, 4, (0, 4, 30), (0, 0, 0), meshes=meshes))
+    # (a mesh vertex that far out is refused like the small sphere: triangles always count towards near_R -- which is also
+    # what bounds |e1||e2| in the triangle test's unscaled reciprocal, exact_triangle<.., UNSCALED>)
+    far_tri = [[(-3, -4.9, 3, 0, 0), (1e18, -4.9, 3, 1, 0), (0, 2, 3, 0, 1)]]
+    gs = gpu.GpuScene(S.custom_scene(objs[1:4], 16, 16, 1, 2, (0, 4, 30), (0, 0, 0),
+                                     meshes=[dict(flags=abi.M_DEFAULT, color=(0.9, 0.8, 0.2), triangles=far_tri)]))
+    with pytest.raises(gpu.ShimError, match="finite bound"):
+        gs.render_image(SEED)
+    gs.close()
 
 
 def test_bench_two_ranks_rehearsal(gpu):
