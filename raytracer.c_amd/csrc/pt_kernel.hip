@@ -208,9 +208,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
  * only acts below 2^-767.  Same instructions on the same values => the same result as
  * sqrt(x) there.  In intersect_sphere x = r*r - d2 is zero or at least half an ulp of r*r, and
  * rt_hip_scene_create rejects radii below 1e-100, so the precondition always holds. */
+/* x == 0 without a select: the seed is taken of max(x, 4.9e-324) (the integer inline constant 1 read as a double: the least
+ * denormal; v_max_f64 ignores a NaN operand, and fp64 denormals are on in this mode), so it is finite where 1 / sqrt(0) would
+ * be inf, and everything after it multiplies by x itself: g = 0 * y = 0, both corrections are 0, the result is x (+0 or -0),
+ * as IEEE sqrt has it.  For x >= 2^-767 the maximum is x: nothing changes.  NaN still comes out NaN (g = x * y).  One
+ * instruction instead of a compare and two selects in every exact sphere test, every normal and every accepted direction. */
 __device__ __forceinline__ double sqrt_unscaled(double x)
 {
-  const double y = __builtin_amdgcn_rsq(x);
+  double xs;
+  asm("v_max_f64 %0, %1, 1" : "=v"(xs) : "v"(x));
+  const double y = __builtin_amdgcn_rsq(xs);
   double g = x * y;
   double h = y * 0.5;
   const double r = __builtin_fma(-h, g, 0.5);
@@ -220,7 +227,7 @@ __device__ __forceinline__ double sqrt_unscaled(double x)
   g = __builtin_fma(d0, h, g);
   const double d1 = __builtin_fma(-g, g, x);
   g = __builtin_fma(d1, h, g);
-  return x == 0.0 ? x : g;
+  return g;
 }
 
 /* 1.0 / x, correctly rounded, for 2^-500 <= x <= 2^500: hipcc's fp64 division expansion
