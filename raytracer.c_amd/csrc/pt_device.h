@@ -140,22 +140,6 @@ static inline bool pt_filter_in_lds(const PtSceneView &sc)
   return (uint64_t)sc.n_spheres + sc.n_triangles <= PT_FILT_LDS_MAX && !sc.wide_range && pt_geom_in_lds(sc);
 }
 
-/* Bits of a traversal-stack entry of the parked-walk kernels that the mesh's references need: the largest inner-node index
- * or leaf payload (first << PT_BVH_COUNT_BITS | count), plus the leaf flag.  The rest of the 24 bits hold a distance code
- * (pt_kernel.hip, WalkStack).  Meshes that need more than 24 bits do not take those kernels (pt_pick_kernel). */
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-static inline uint32_t pt_walk_ref_bits(const PtSceneView &sc)
-{
-  const uint32_t top_inner = sc.n_bvh_nodes ? sc.n_bvh_nodes - 1u : 0u;
-  const uint32_t top_leaf = sc.n_triangles ? (((sc.n_triangles - 1u) << PT_BVH_COUNT_BITS) | ((1u << PT_BVH_COUNT_BITS) - 1u)) : 0u;
-  uint32_t top = top_inner > top_leaf ? top_inner : top_leaf, bits = 1u;
-  while (top >>= 1)
-    bits++;
-  return bits + 1u;
-}
-
 /* The filter buffer of a small scene (pt_filter_in_lds) holds two tables: the pair table of
  * phase 1 (PT_FILT_STRIDE f32x2 per primitive pair, + the look-ahead pair), then, 16-byte aligned,
  * the fp32 triangle table of the per-lane pre-test (PT_TRI32_STRIDE floats per triangle). */

@@ -2612,66 +2612,28 @@ __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
 
 /* The per-lane traversal stacks of the parked-walk kernels: 24-bit entries (a 16-bit and an 8-bit array, entry-major,
  * one entry per tree level and lane), because at four workgroups per CU every kilobyte of LDS counts there.  A reference
- * fits 24 bits while node indices stay below 2^23 and leaf references below 2^23 + 2^20 triangles (checked on the host,
- * pt_pick_kernel: other meshes take the lane-waiting kernels).
- *
- * Round 3: the bits a mesh's references do not need hold the DISTANCE at which the waiting child's box is entered, so
- * that a pop can drop it without a visit.  The nearer child is entered first and the other waits; by the time it is
- * popped the walk has usually found a hit in front of it, yet the pop cost a whole visit (a 64-byte node fetch and ~65
- * instructions, or a leaf's pre-tests) only to learn that both its children start beyond min_t.  ref_bits = the bits of
- * the largest reference + the leaf flag (pt_walk_ref_bits, wave-uniform: 18 for config 5's 10,240 triangles), the
- * remaining bits (24 less those; at most 8) hold code(tn) of the waiting box's widened entry distance tn (bvh_test_children),
- * where code(t) = trunc(min(max(t qs + qb, 0), levels - 1)) maps the ray's chord through the triangles' bounding sphere
- * (walk_quantiser, per ray at the refill) linearly onto 0 .. levels - 1.  All that safety needs of code() is that it is
- * MONOTONE (fma, max, min and the truncation all are, for qs >= 0): code(tn) > code(tmax) implies tn > tmax >= min_t, the
- * very condition under which bvh_test_children rejects a box (a box entered beyond the closest hit cannot hold a
- * closer one, nor one that ties with it) -- applied with the min_t of the pop instead of that of the push.  A coarse
- * code only means fewer drops.  NaN -> 0 (v_max returns the other operand): never dropped; far_origin lanes and the
- * M_CHECKERED / stale-uv walks, which do not prune by min_t at all, store 0. */
-#ifndef PT_POP_DROP
-#define PT_POP_DROP 0 /* 1: form the codes and drop (measured: 13 % fewer node visits, +0.3 % time -- the codes cost what they save) */
-#endif
+ * fits 24 bits while node indices stay below 2^23 and leaf references below 2^23 + 2^20 triangles (PT_WALK_REF_OK,
+ * checked on the host: other meshes take the lane-waiting kernels). */
 struct WalkStack
 {
   uint16_t *lo; /* [levels][PT_BLOCK] */
   uint8_t *hi;  /* [levels][PT_BLOCK] */
-  uint32_t ref_bits; /* wave-uniform */
-  float top_code;    /* levels - 1 as a float */
 };
-/* per ray: code(t) = t qs + qb over the chord [t_in, t_out] of the ray through the bounding sphere (cx cy cz, r2_hi);
- * anything degenerate (no chord, overflow, NaN) gives qs = qb = 0: every code 0, nothing is ever dropped */
-__device__ __forceinline__ void walk_quantiser(const MeshBound &mb, const V3 &o, const V3 &d, float top_code, float &qs, float &qb)
+#define PT_WALK_LEAF_FLAG24 0x800000u
+__device__ __forceinline__ uint32_t walk_ref24(uint32_t ref) /* PT_BVH_LEAF_FLAG (bit 31) moves to bit 23 */
 {
-  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
-  const float lx = mb.cx - (float)o.x, ly = mb.cy - (float)o.y, lz = mb.cz - (float)o.z;
-  const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-  const float tca = __builtin_fmaf(lz, dz, __builtin_fmaf(ly, dy, lx * dx));
-  const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
-  const float disc = __builtin_fmaf(tca, tca, -dd * (ll - mb.r2_hi));
-  const float root = __builtin_amdgcn_sqrtf(disc);
-  const float inv_dd = __builtin_amdgcn_rcpf(dd);
-  const float t_in = fmaxf((tca - root) * inv_dd, 0.0f), t_out = (tca + root) * inv_dd;
-  const float s = (top_code + 1.0f) * __builtin_amdgcn_rcpf(t_out - t_in);
-  const float b = -t_in * s;
-  const bool ok = (s >= 0.0f) & (s < 1e30f) & (b > -1e30f) & (b <= 0.0f); /* false for NaN */
-  qs = ok ? s : 0.0f;
-  qb = ok ? b : 0.0f;
+  return (ref & 0x7FFFFFu) | ((ref >> 8) & PT_WALK_LEAF_FLAG24);
 }
-__device__ __forceinline__ uint32_t walk_code(float t, float qs, float qb, float top_code)
+__device__ __forceinline__ uint32_t walk_ref32(uint32_t r24) { return (r24 & 0x7FFFFFu) | ((r24 & PT_WALK_LEAF_FLAG24) << 8); }
+__device__ __forceinline__ void walk_push(const WalkStack &st, uint32_t sp, uint32_t ref)
 {
-  return (uint32_t)fminf(fmaxf(__builtin_fmaf(t, qs, qb), 0.0f), top_code);
-}
-__device__ __forceinline__ void walk_push(const WalkStack &st, uint32_t sp, uint32_t ref, uint32_t code)
-{ /* PT_BVH_LEAF_FLAG (bit 31) moves to bit ref_bits - 1, the code sits above it */
-  const uint32_t r = (ref & ((1u << (st.ref_bits - 1u)) - 1u)) | ((ref >> 31) << (st.ref_bits - 1u)) | (code << st.ref_bits);
+  const uint32_t r = walk_ref24(ref);
   st.lo[sp * PT_BLOCK + threadIdx.x] = (uint16_t)r;
   st.hi[sp * PT_BLOCK + threadIdx.x] = (uint8_t)(r >> 16);
 }
-__device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp, uint32_t &code)
+__device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp)
 {
-  const uint32_t r = (uint32_t)st.lo[sp * PT_BLOCK + threadIdx.x] | ((uint32_t)st.hi[sp * PT_BLOCK + threadIdx.x] << 16);
-  code = r >> st.ref_bits;
-  return (r & ((1u << (st.ref_bits - 1u)) - 1u)) | (((r >> (st.ref_bits - 1u)) & 1u) << 31);
+  return walk_ref32((uint32_t)st.lo[sp * PT_BLOCK + threadIdx.x] | ((uint32_t)st.hi[sp * PT_BLOCK + threadIdx.x] << 16));
 }
 
 /* The wave walks the n_new parked rays at ring positions first, first + 1, ... (see the header
@@ -2681,7 +2643,7 @@ __device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp, u
  * is live in registers while the wave walks. */
 template <bool CHECKER>
 __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &ring, uint32_t first, uint32_t n_new,
-                                            const WalkStack &stack, unsigned long long *diag_ptr, bool diag_walk_dropped = false)
+                                            const WalkStack &stack, unsigned long long *diag_ptr)
 {
   /* parked state written by this wave's lanes (plain stores) must have reached L2 before other
    * lanes load it: workgroup-scope release = s_waitcnt vmcnt(0) */
@@ -2696,48 +2658,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
   BvhRay R = bvh_ray(wo, wd);
   TriLast last = {-1, 0, 0};
   const bool no_prune = CHECKER && S.stale_uv;
-  float qs = 0.f, qb = 0.f; /* the ray's distance code (WalkStack) */
   float wtmax = 0.f;        /* a float not below wmin_t (float_above), renewed when wmin_t changes: what the slab tests prune by */
-  /* the next waiting box that can still matter: entries whose box starts beyond the closest hit so far are dropped
-   * without a visit (WalkStack); none left: the walk is finished */
-#ifdef PT_DIAG
-  /* the re-check of that rule: a dropped box is walked all the same, and nothing found below it may change the result */
-  bool in_dropped = false;
-  uint32_t dropped_sp = 0;
-#endif
-  auto pop_live = [&](bool &finished) {
-    const uint32_t code_now = PT_POP_DROP ? walk_code(wtmax, qs, qb, stack.top_code) : 0u;
-    for (;;)
-    {
-#ifdef PT_DIAG
-      if (in_dropped && sp == dropped_sp)
-        in_dropped = false; /* the dropped box's subtree is done */
-#endif
-      if (sp == 0)
-      {
-        finished = true;
-        return;
-      }
-      sp--;
-      uint32_t code;
-      ref = walk_pop(stack, sp, code);
-      if (!PT_POP_DROP || !(code > code_now))
-        return;
-#ifdef PT_DIAG
-      if (!in_dropped)
-        atomicAdd(&diag_ptr[4 + 38], 1ull); /* waiting boxes dropped at the pop */
-      if (diag_walk_dropped)
-      { /* RT_HIP_DIAG_WALK_REJECTED=1: walked all the same, without pruning, and checked (otherwise: dropped, as shipped) */
-        if (!in_dropped)
-        {
-          in_dropped = true;
-          dropped_sp = sp;
-        }
-        return;
-      }
-#endif
-    }
-  };
 #ifdef PT_DIAG
   uint32_t visits = 0;
   int wbest0 = wbest;
@@ -2762,14 +2683,11 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         wtmax = no_prune ? 3.4028234663852886e38f : float_above(wmin_t);
         R = bvh_ray(wo, wd);
         far_origin = !(v_dot(wo, wo) <= S.near_R2);
-        if (PT_POP_DROP)
-          walk_quantiser(S.mesh_bound, wo, wd, (far_origin || no_prune) ? -1.0f : stack.top_code, qs, qb); /* (-1: levels = 0, every code 0) */
         sp = 0;
         ref = 0; /* the root */
         last.idx = -1;
         have = true;
 #ifdef PT_DIAG
-        in_dropped = false;
         visits = 0;
         wbest0 = wbest;
         outside_bound = (ring_ldu(ring, 1u, e) & 0x80000000u) != 0u;
@@ -2797,23 +2715,23 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         bool hit0, hit1;
         float tn0, tn1;
         uint32_t r0, r1;
-#ifdef PT_DIAG
-        const bool diag_all = in_dropped; /* below a dropped box: every triangle the ray passes gets its exact test */
-#else
-        const bool diag_all = false;
-#endif
-        bvh_test_children(S.bvh_nodes, ref, R, far_origin, diag_all ? 3.4028234663852886e38f : wtmax, hit0, hit1, tn0, tn1, r0, r1);
+        bvh_test_children(S.bvh_nodes, ref, R, far_origin, wtmax, hit0, hit1, tn0, tn1, r0, r1);
         if (hit0 && hit1)
         {
           const bool zero_first = !(tn1 < tn0);
-          walk_push(stack, sp, zero_first ? r1 : r0, PT_POP_DROP ? walk_code(zero_first ? tn1 : tn0, qs, qb, stack.top_code) : 0u);
+          walk_push(stack, sp, zero_first ? r1 : r0);
           sp++;
           ref = zero_first ? r0 : r1;
         }
         else if (hit0 || hit1)
           ref = hit0 ? r0 : r1;
+        else if (sp == 0)
+          finished = true;
         else
-          pop_live(finished);
+        {
+          sp--;
+          ref = walk_pop(stack, sp);
+        }
       }
     }
     else if (at_leaf)
@@ -2830,10 +2748,6 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
           atomicAdd(&diag_ptr[4 + 12], 1ull);
       }
 #endif
-#ifdef PT_DIAG
-      const int diag_best_before = wbest;
-      const double diag_t_before = wmin_t;
-#endif
       while (keep != 0u)
       {
         DIAG(14, 1);
@@ -2844,11 +2758,13 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
       }
       if (!no_prune)
         wtmax = float_above(wmin_t);
-#ifdef PT_DIAG
-      if (in_dropped && (wbest != diag_best_before || wmin_t != diag_t_before))
-        atomicAdd(&diag_ptr[4 + 12], 1ull); /* a box dropped at the pop held the closest hit (or a tie that wins) */
-#endif
-      pop_live(finished);
+      if (sp == 0)
+        finished = true;
+      else
+      {
+        sp--;
+        ref = walk_pop(stack, sp);
+      }
     }
     if (finished)
     {
@@ -2935,8 +2851,6 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     stack.lo = reinterpret_cast<uint16_t *>(lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
                                                    pt_filt_pair_slots(S.n_sph)));
     stack.hi = reinterpret_cast<uint8_t *>(stack.lo + (size_t)levels * PT_BLOCK);
-    stack.ref_bits = pt_walk_ref_bits(L.scene);
-    stack.top_code = (float)((1u << min(24u - stack.ref_bits, 8u)) - 1u);
   }
   {
     unsigned long long *z = &pix_sum_all[0][0];
@@ -3223,7 +3137,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       PHASE(14); /* every path to the list before a walk */
-      walk_parked<CHECKER>(S, ring, (head + n_done) & (PT_PARK_Q - 1u), n_new, stack, diag_ptr, (L.diag_flags & 1u) != 0u);
+      walk_parked<CHECKER>(S, ring, (head + n_done) & (PT_PARK_Q - 1u), n_new, stack, diag_ptr);
       PHASE(15); /* walking the parked rays */
       n_done += n_new;
       n_new = 0u;

@@ -25,8 +25,7 @@ names = ["loop iters (wave)", "loop lanes", "phase2 iters (wave)", "phase2 cands
          "parked from outside the ball, found a triangle", "parked from outside the ball, found none",
          "rays leaving a hull facet (no probe)", "phase-2 iters if each lane kept one wall (wave)", "phase-2 iters of non-wall candidates alone (wave)",
          "phase-2 iters of wall candidates alone (wave)", "wall candidates (lane)", "non-wall candidates (lane)", "small-mesh fp32 pre-test iters (wave)",
-         "small-mesh fp32 pre-tests (lane)", "small-mesh exact triangle iters (wave)", "wall-sized spheres pruned before the exact tests (lane)",
-         "waiting boxes dropped at the pop (lane)"]
+         "small-mesh fp32 pre-tests (lane)", "small-mesh exact triangle iters (wave)", "wall-sized spheres pruned before the exact tests (lane)"]
 for n, v in zip(names, d):
     print(f"{n:28s} {v:15d}")
 assert d[12] == 0, 'the conservative filter dropped a sphere the exact test accepts'
@@ -46,8 +45,6 @@ if d[17]:
               f"inside the bounding sphere: {d[23] / d[17]:.3f} of them)")
     print(f"parked rays per cast {d[17] / casts:.3f}; of the walked rays {d[18] / d[17]:.3f} return with a triangle; walks by node "
           f"visits 1: {d[19] / d[17]:.3f}  2-3: {d[20] / d[17]:.3f}  4-6: {d[21] / d[17]:.3f}  7+: {d[22] / d[17]:.3f}")
-if d[38]:
-    print(f"waiting boxes dropped at the pop per walked ray: {d[38] / d[17]:.2f}")
 if d[29]:
     print(f"sphere candidates per ray: walls (r > 1000) {d[32] / casts:.2f}, others {d[33] / casts:.2f}; phase-2 iterations per trip: "
           f"now {d[2] / it:.2f}, walls alone {d[31] / it:.2f}, others alone {d[30] / it:.2f}, with one wall per lane {d[29] / it:.2f}")
