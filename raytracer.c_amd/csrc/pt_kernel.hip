@@ -1466,10 +1466,28 @@ __device__ __forceinline__ double div_small_int(double a, double b, double y)
 }
 
 /* raytracer.c:203-206 + get_camera_ray :375-384, stream re-seeded per (pixel, sample) */
-__device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uint64_t pixel_key, uint32_t px,
-                                             uint32_t py, uint32_t s)
+/* the sample half of the stream key (rt_rng.h, rt_rng_sample_state): pixel_key + 0xD1B5... * (sample + 1).  Callers whose
+ * sample index is wave-uniform (a batch of a full tile = one sample index of every pixel) form it once, as scalar work:
+ * as vector work it is two quarter-rate 64-bit multiplies per lane */
+__device__ __forceinline__ uint64_t sample_term(uint32_t s) { return 0xD1B54A32D192ED03ull * ((uint64_t)s + 1u); }
+/* the same for a wave-uniform sample index given in the lanes' registers: formed by the scalar unit, and pinned there (or
+ * the compiler merges it with the per-lane form of the ragged-tile branch and multiplies in the vector unit after all) */
+__device__ __forceinline__ uint64_t sample_term_uniform(uint32_t s_any_lane)
 {
-  P.rng = rt_rng_sample_state(pixel_key, s);
+  const uint64_t t = sample_term((uint32_t)__builtin_amdgcn_readfirstlane((int)s_any_lane));
+  uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t sample_state_from_term(uint64_t pixel_key, uint64_t term)
+{
+  const uint64_t h = rt_mix64(pixel_key + term);
+  return h ? h : 0x9E3779B97F4A7C15ull; /* = rt_rng_sample_state(pixel_key, s) for term = sample_term(s) */
+}
+__device__ __forceinline__ void start_sample(Path &P, const CameraRegs &cam, uint64_t pixel_key, uint32_t px,
+                                             uint32_t py, uint64_t term)
+{
+  P.rng = sample_state_from_term(pixel_key, term);
   /* (x + rnd) / (W - 1): exactly the reference's quotient, see div_small_int */
   const double u = div_small_int((double)px + rnd(P.rng), cam.w_minus_1, cam.inv_w_minus_1);
   const double v = div_small_int((double)py + rnd(P.rng), cam.h_minus_1, cam.inv_h_minus_1);
@@ -2227,21 +2245,24 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         {
           DIAG(6, 1);
           DIAG_LANES(7);
-          uint32_t idx, s;
+          uint32_t idx;
+          uint64_t term;
           if (n_valid == PT_TILE_PIXELS)
           {
             idx = job & 63u;
-            s = job >> 6;
+            /* (a batch of a full tile is one sample index of every pixel: wave-uniform, sample_term) */
+            term = sample_term_uniform(s_begin + (job >> 6));
           }
           else
           {
-            s = job / n_valid;
+            const uint32_t s = job / n_valid;
             idx = job - s * n_valid;
+            term = sample_term(s_begin + s);
           }
           const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
-          const uint32_t col = idx - row * vcols;
+          const uint32_t col = idx - __umul24(row, vcols); /* (v_mul_u32_u24: full rate) */
           pix_slot = row * PT_TILE + col;
-          start_sample(P, load_camera_lds(cam_lds), pix_key[pix_slot], tx0 + col, ty0 + row, s_begin + s);
+          start_sample(P, load_camera_lds(cam_lds), pix_key[pix_slot], tx0 + col, ty0 + row, term);
           hit.need_dir = false;
         }
         primary_trip = FILT_LDS;
@@ -2277,10 +2298,10 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
               idx = job - s * n_valid;
             }
             const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vcols);
-            const uint32_t col = idx - row * vcols;
+            const uint32_t col = idx - __umul24(row, vcols); /* (v_mul_u32_u24: full rate) */
             const uint32_t slot_in_tile = (2u * wave + row) * PT_TILE + col;
             Path Q;
-            start_sample(Q, load_camera_lds(cam_lds), pix_key[slot_in_tile], tx0 + col, ty0 + row, s_begin + s);
+            start_sample(Q, load_camera_lds(cam_lds), pix_key[slot_in_tile], tx0 + col, ty0 + row, sample_term(s_begin + s));
             qd[lane] = Q.d.x;
             qd[64 + lane] = Q.d.y;
             qd[128 + lane] = Q.d.z;
@@ -3072,28 +3093,30 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       {
         DIAG(6, 1);
         DIAG_LANES(7);
-        uint32_t idx, s;
+        uint32_t idx;
+        uint64_t term;
         if (n_valid == PT_TILE_PIXELS)
         {
           idx = job & 63u;
-          s = job >> 6;
+          term = sample_term_uniform(s_begin + (job >> 6)); /* (wave-uniform: see render_tiles_pooled) */
         }
         else
         { /* ragged edge tiles only: the divisors go through a register the compiler cannot see through, or it forms their
            * reciprocals ahead of the trip loop and keeps them (in scratch memory: the kernel has no register to spare) */
           uint32_t nv = n_valid;
           asm volatile("" : "+v"(nv));
-          s = job / nv;
+          const uint32_t s = job / nv;
           idx = job - s * nv;
+          term = sample_term(s_begin + s);
         }
         uint32_t vc = vcols;
         if (vcols != PT_TILE)
           asm volatile("" : "+v"(vc));
         const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vc);
-        const uint32_t col = idx - row * vcols;
+        const uint32_t col = idx - __umul24(row, vcols); /* (v_mul_u32_u24: full rate) */
         pix_slot = row * PT_TILE + col;
         start_sample(P, load_camera_lds(cam_lds), rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col),
-                     tx0 + col, ty0 + row, s_begin + s);
+                     tx0 + col, ty0 + row, term);
         hit.need_dir = false;
         hit.leaving = false;
       }
@@ -3454,7 +3477,7 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
     {
       DIAG(6, 1);
       DIAG_LANES(7);
-      start_sample(P, cam, rt_rng_pixel_key(L.seed, pixel), px, py, s);
+      start_sample(P, cam, rt_rng_pixel_key(L.seed, pixel), px, py, sample_term((uint32_t)s));
       fresh = false;
     }
     n_rays++;
