@@ -77,7 +77,7 @@
 /* parked-walk kernels (pt_render_tiles_tri_queued*): bytes of ring per wave in the workspace, slots
  * (workgroups) per XCD the pool provides: 32 CUs x at most 5 resident workgroups, with slack */
 #ifndef PT_PARK_WAVE_BYTES
-#define PT_PARK_WAVE_BYTES 65536u /* 512 entries of 128 bytes (pt_kernel.hip, PT_PARK_Q: why 512) */
+#define PT_PARK_WAVE_BYTES (65536u + 512u) /* 512 entries of 128 bytes (pt_kernel.hip, PT_PARK_Q: why 512), then the tile's 64 per-pixel RNG keys */
 #endif
 #define PT_PARK_SLOTS_PER_XCD 192u
 #define PT_PARK_XCDS 8u

@@ -906,48 +906,52 @@ __device__ __forceinline__ void filter_chunk_listed(const f32x2 *__restrict__ fi
  *   and the fp64 rounding of the exact tests that decide, which can accept nothing farther than ~1e-12 |c| outside a
  *   primitive.  Non-finite anything: keep.  (The PT_DIAG build re-checks
  *   every primitive dropped this way with the exact test, like every other dropped primitive.) */
-__device__ __forceinline__ void tile_cull(const double *cam_lds, const double *entry_src, uint32_t n_sph, uint32_t n_entries,
-                                          uint32_t tx0, uint32_t ty0, uint32_t *pairs)
+/* (the test itself, for one ball: centre c, radius R already widened by its margin) */
+__device__ __forceinline__ bool tile_cone_reaches_ball(const double *cam_lds, uint32_t tx0, uint32_t ty0, const V3 &c, double R)
 {
   /* 1 / sqrt and 1 / x from the hardware's seed instructions (v_rsq_f64, v_rcp_f64: ~2^-26 relative): the margins
    * below are 1e-5, and the correctly rounded expansions of ten square roots and divisions cost several hundred
    * instructions per workgroup -- 2 % of a low-spp frame */
   auto rsq = [](double x) { return __builtin_amdgcn_rsq(x); };
   auto root = [&](double x) { return x > 0.0 ? x * rsq(x) : 0.0; };
+  const V3 pos = {cam_lds[0], cam_lds[1], cam_lds[2]}, Hh = {cam_lds[3], cam_lds[4], cam_lds[5]},
+           Vv = {cam_lds[6], cam_lds[7], cam_lds[8]}, llc = {cam_lds[9], cam_lds[10], cam_lds[11]};
+  const double u0 = (double)tx0 * cam_lds[14], u1 = (double)(tx0 + PT_TILE) * cam_lds[14]; /* x 1 / (W - 1), 1 / (H - 1) */
+  const double v0 = (double)ty0 * cam_lds[15], v1 = (double)(ty0 + PT_TILE) * cam_lds[15];
+  V3 w[4];
+  for (int k = 0; k < 4; k++)
+  {
+    const double u = (k & 1) ? u1 : u0, v = (k & 2) ? v1 : v0;
+    w[k] = v_sub(pos, v_add(llc, v_add(v_scale(Hh, u), v_scale(Vv, v))));
+  }
+  V3 a = v_add(v_add(w[0], w[1]), v_add(w[2], w[3]));
+  a = v_scale(a, rsq(v_dot(a, a)));
+  double cos_t = 1.0;
+  for (int k = 0; k < 4; k++)
+    cos_t = fmin(cos_t, v_dot(a, w[k]) * rsq(v_dot(w[k], w[k])));
+  cos_t -= 1e-5;
+  const double sin_t = root(1.0 - cos_t * cos_t);
+  const V3 L = v_sub(c, pos);
+  const double inv_len = rsq(v_dot(L, L));
+  const double sin_p = R * inv_len; /* NaN / inf: the comparisons below keep the primitive */
+  if (!(sin_p < 0.99999) || !(cos_t > 0.0))
+    return true; /* the camera inside (or on, or within 1e-5 of) the ball; a degenerate cone */
+  const double cos_p = root(1.0 - sin_p * sin_p);
+  const double cos_a = v_dot(a, L) * inv_len;
+  return !(cos_a < cos_t * cos_p - sin_t * sin_p - 1e-5);
+}
+
+__device__ __forceinline__ void tile_cull(const double *cam_lds, const double *entry_src, uint32_t n_sph, uint32_t n_entries,
+                                          uint32_t tx0, uint32_t ty0, uint32_t *pairs)
+{
+  auto root = [](double x) { return x > 0.0 ? x * __builtin_amdgcn_rsq(x) : 0.0; };
   const uint32_t i = threadIdx.x;
   bool keep = false;
   if (i < n_entries)
   {
-    const V3 pos = {cam_lds[0], cam_lds[1], cam_lds[2]}, Hh = {cam_lds[3], cam_lds[4], cam_lds[5]},
-             Vv = {cam_lds[6], cam_lds[7], cam_lds[8]}, llc = {cam_lds[9], cam_lds[10], cam_lds[11]};
-    const double u0 = (double)tx0 * cam_lds[14], u1 = (double)(tx0 + PT_TILE) * cam_lds[14]; /* x 1 / (W - 1), 1 / (H - 1) */
-    const double v0 = (double)ty0 * cam_lds[15], v1 = (double)(ty0 + PT_TILE) * cam_lds[15];
-    V3 w[4];
-    for (int k = 0; k < 4; k++)
-    {
-      const double u = (k & 1) ? u1 : u0, v = (k & 2) ? v1 : v0;
-      w[k] = v_sub(pos, v_add(llc, v_add(v_scale(Hh, u), v_scale(Vv, v))));
-    }
-    V3 a = v_add(v_add(w[0], w[1]), v_add(w[2], w[3]));
-    a = v_scale(a, rsq(v_dot(a, a)));
-    double cos_t = 1.0;
-    for (int k = 0; k < 4; k++)
-      cos_t = fmin(cos_t, v_dot(a, w[k]) * rsq(v_dot(w[k], w[k])));
-    cos_t -= 1e-5;
-    const double sin_t = root(1.0 - cos_t * cos_t);
     const double *e = entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz R2 |c| Rb */
     const double R = (i < n_sph ? root(e[3]) : e[5]) * (1.0 + 1e-5) + 1e-300;
-    const V3 L = v_sub(ld3(e), pos);
-    const double inv_len = rsq(v_dot(L, L));
-    const double sin_p = R * inv_len; /* NaN / inf: the comparisons below keep the primitive */
-    if (!(sin_p < 0.99999) || !(cos_t > 0.0))
-      keep = true; /* the camera inside (or on, or within 1e-5 of) the ball; a degenerate cone */
-    else
-    {
-      const double cos_p = root(1.0 - sin_p * sin_p);
-      const double cos_a = v_dot(a, L) * inv_len;
-      keep = !(cos_a < cos_t * cos_p - sin_t * sin_p - 1e-5);
-    }
+    keep = tile_cone_reaches_ball(cam_lds, tx0, ty0, ld3(e), R);
   }
   unsigned long long m = __ballot(keep);
   /* entry mask -> pair mask: OR neighbouring bits, then gather the even positions */
@@ -2553,7 +2557,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 #endif
 #define PT_PARK_F64_FIELDS 13u /* o xyz, d xyz, T xyz, rng, min_t, (M_CHECKERED kernels: last u, v) */
 #define PT_PARK_U32_FIELDS 4u  /* best, depth << 6 | pixel slot, (last index), pad */
-static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * 128u && PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u <= 128u, "ring bytes per wave");
+static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * 128u + PT_TILE_PIXELS * 8u && PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u <= 128u, "ring bytes per wave");
 static_assert((PT_PARK_Q & (PT_PARK_Q - 1u)) == 0u && PT_PARK_WALK + 126u <= PT_PARK_Q, "ring size: see PT_PARK_Q");
 
 /* Entry-major, in three regions per wave, by who touches what:
@@ -2611,6 +2615,7 @@ __device__ __forceinline__ void ring_st3(const ParkRing &r, uint32_t field, uint
 /* The workgroup's workspace slot, or 0xFFFFFFFF when there is none (no workspace, or -- a sizing
  * bug, never seen -- every slot of this XCD taken after a bounded search: the kernel then walks in
  * the lanes, slower but correct, rather than spin).  Thread 0 only. */
+__device__ __forceinline__ uint32_t lane_of_thread() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
 {
   if (L.park_ws == nullptr || L.park_slots_per_xcd == 0u)
@@ -2923,6 +2928,21 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     ring.f = reinterpret_cast<double *>(base);
     ring.u = reinterpret_cast<uint32_t *>(base);
   }
+  /* can a camera ray of this wave's tile reach the triangles' bounding ball at all?  (tile_cull's cone test, for the probe's
+   * own ball: its r2_hi is the radius squared plus the filter's widening, far more than the centre's rounding to fp32) */
+  const bool tile_sees_mesh =
+      tile_cone_reaches_ball(cam_lds, tx0, ty0, V3{(double)S.mesh_bound.cx, (double)S.mesh_bound.cy, (double)S.mesh_bound.cz},
+                             sqrt((double)S.mesh_bound.r2_hi) * (1.0 + 1e-5) + 1e-300);
+  /* The tile's 64 per-pixel RNG keys (rt_rng_pixel_key: a splitmix64 finaliser, six quarter-rate multiplies) are formed
+   * once, by lane = pixel slot, and kept behind the wave's ring (this kernel has neither a register pair nor 512 bytes of
+   * LDS per wave to spare for them); a swap reads its lane's key back -- one load that hits the XCD's L2 -- instead
+   * of hashing it again for every camera sample. */
+  if (has_unit && ring_ok)
+  {
+    const uint32_t kx = tx0 + (lane_of_thread() & 7u), ky = ty0 + (lane_of_thread() >> 3);
+    reinterpret_cast<unsigned long long *>(ring.f + PT_PARK_Q * 16u)[lane_of_thread()] = rt_rng_pixel_key(L.seed, ky * (uint32_t)L.width + kx);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* in L2 before any lane reads a key another lane wrote */
+  }
 
   Path P;
   P.o = {0, 0, 0};
@@ -3115,15 +3135,15 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vc);
         const uint32_t col = idx - __umul24(row, vcols); /* (v_mul_u32_u24: full rate) */
         pix_slot = row * PT_TILE + col;
-        start_sample(P, load_camera_lds(cam_lds), rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col),
-                     tx0 + col, ty0 + row, term);
+        const uint64_t pixel_key = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ring.f + PT_PARK_Q * 16u) + pix_slot,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* (L1-bypassing, like every ring load) */
+        start_sample(P, load_camera_lds(cam_lds), pixel_key, tx0 + col, ty0 + row, term);
         hit.need_dir = false;
         hit.leaving = false;
       }
       next_job = min(next_job + 64u, pool);
       primary_trip = true;
     }
-    (void)primary_trip;
     PHASE(7); /* the swap and its camera samples */
     /* nobody holds a ray: the pool is dry, the list and the ring's walked part are empty (an idle lane would have
      * taken from them).  Parked rays, if any, are walked now; otherwise this is the one exit. */
@@ -3181,7 +3201,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       n_rays++;
       /* a ray that left a hull facet on its outer side cannot meet a triangle: no probe, no walk (set by the
        * second half of the previous step; the first half does not touch it) */
-      const bool no_mesh = hit.leaving && !(CHECKER && S.stale_uv);
+      /* ... and a fresh camera ray of a tile whose cone cannot reach the triangles' bounding ball (tile_sees_mesh, once
+       * per wave: a primary trip's 64 rays are all such rays) cannot either: most of the image's primary trips skip the probe */
+      const bool no_mesh = (hit.leaving && !(CHECKER && S.stale_uv)) || (primary_trip && !tile_sees_mesh);
       (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
       const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
 #ifdef PT_DIAG
@@ -3194,7 +3216,10 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       { /* walked all the same under RT_HIP_DIAG_WALK_REJECTED=1, and counted as a violation if it finds a triangle */
         diag_in_sphere = false;
         want_walk = want_walk && (L.diag_flags & 1u) != 0u;
-        DIAG_LANES(28);
+        if (hit.leaving)
+          DIAG_LANES(28); /* rays leaving a hull facet */
+        else
+          DIAG_LANES(38); /* camera rays of tiles that cannot see the mesh */
       }
 #else
       want_walk = hit.depth_ok && !no_mesh &&

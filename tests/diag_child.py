@@ -76,7 +76,7 @@ def main():
             print(json.dumps({"scene": name, "integrator": integrator, "kernel": gs.kernel_name(integrator),
                               "n_primitives": sc.n_primitives, "casts": st[1], "violations": d[12],
                               "candidates": d[3], "parked": d[17], "parked_probe_would_park": d[23],
-                              "left_hull_facet": d[28], "leaf_pretests": d[16], "small_mesh_pretests": d[35],
+                              "left_hull_facet": d[28], "tile_cannot_see_mesh": d[38], "leaf_pretests": d[16], "small_mesh_pretests": d[35],
                               "walked_found_triangle": d[18], "walls_pruned": d[37]}), flush=True)
             gs.close()
 

@@ -57,6 +57,9 @@ def test_diag_configs_1_to_5_zero_violations():
     # rays the probe's bounding sphere rejects were walked too (parked > what the shipped build parks), bounces off hull
     # facets were seen, leaves were pre-tested, and walks did find triangles
     assert c5["parked"] > c5["parked_probe_would_park"] > 0 and c5["left_hull_facet"] > 0
+    # camera rays of tiles whose cone cannot reach the mesh's bounding ball go without a probe: such tiles were seen (and,
+    # walked all the same here, their rays found nothing: no violations above)
+    assert c5["tile_cannot_see_mesh"] > 0
     assert c5["leaf_pretests"] > 0 and c5["walked_found_triangle"] > 0
 
 

@@ -25,7 +25,8 @@ names = ["loop iters (wave)", "loop lanes", "phase2 iters (wave)", "phase2 cands
          "parked from outside the ball, found a triangle", "parked from outside the ball, found none",
          "rays leaving a hull facet (no probe)", "phase-2 iters if each lane kept one wall (wave)", "phase-2 iters of non-wall candidates alone (wave)",
          "phase-2 iters of wall candidates alone (wave)", "wall candidates (lane)", "non-wall candidates (lane)", "small-mesh fp32 pre-test iters (wave)",
-         "small-mesh fp32 pre-tests (lane)", "small-mesh exact triangle iters (wave)", "wall-sized spheres pruned before the exact tests (lane)"]
+         "small-mesh fp32 pre-tests (lane)", "small-mesh exact triangle iters (wave)", "wall-sized spheres pruned before the exact tests (lane)",
+         "camera rays of tiles that cannot see the mesh (no probe)"]
 for n, v in zip(names, d):
     print(f"{n:28s} {v:15d}")
 assert d[12] == 0, 'the conservative filter dropped a sphere the exact test accepts'
