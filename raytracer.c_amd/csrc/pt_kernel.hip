@@ -1203,6 +1203,15 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
 #endif
     PHASE(1); /* phase 1: the filter */
     /* ---- phase 2: the exact test on each lane's own candidates, in index order: spheres ... ---- */
+    /* (chunks of at most 32 entries -- every configuration but the headline's 38 spheres -- have no high word: the
+     * candidate loop is then a bit scan of one register, five instructions per iteration less than the two-word form) */
+    if (chunk <= 32u)
+      while (cand_lo)
+      {
+        const uint32_t k = (uint32_t)__builtin_ctz(cand_lo);
+        cand_lo &= cand_lo - 1u;
+        exact_sphere(geom + PT_GEOM_STRIDE * (base + k), base + k, o, d, min_t, best);
+      }
     while (cand_lo | cand_hi)
     {
       /* lowest set bit of the 64-bit mask, branch-free */
