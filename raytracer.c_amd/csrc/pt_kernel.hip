@@ -623,7 +623,7 @@ struct FiltRay
   uint32_t far_origin;
 };
 
-template <bool SHIFT>
+template <bool SHIFT, bool FAR32 = false>
 __device__ __forceinline__ FiltRay filter_ray(const V3 &o, const V3 &d, double filt_shift, double near_R2)
 {
   FiltRay r;
@@ -643,7 +643,14 @@ __device__ __forceinline__ FiltRay filter_ray(const V3 &o, const V3 &d, double f
   }
   else
     r.od = r.oo = r.m2ox = r.m2oy = r.m2oz = 0.f;
-  r.far_origin = !(v_dot(o, o) <= near_R2); /* also true for NaN */
+  /* "the origin is beyond near_R": outside the table's error bounds, the ray keeps every primitive.  The sign-test form has
+   * |o'|^2 in fp32 already (o' = o pulled back by filt_shift ~ 1e-6 near_R: |o'|^2 and |o|^2 agree to ~3e-6 relative, fp32
+   * rounding included), so it asks that instead of a second, fp64 dot product: with a margin of 1e-4 a ray it lets through
+   * has |o|^2 <= near_R2 for certain; the thin shell it turns away loses only the filter's help, never a hit.  NaN: true. */
+  if (SHIFT && FAR32) /* (the parked-walk kernels need the fp64 dot product for their probe anyway: they keep it) */
+    r.far_origin = !(r.oo <= (float)(near_R2 * 0.9999));
+  else
+    r.far_origin = !(v_dot(o, o) <= near_R2); /* also true for NaN */
   return r;
 }
 
@@ -1087,7 +1094,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
    * outside fp32's comfortable range never use this form (pt_filter_in_lds). */
   static_assert(!SPH_LDS || (BVH && !FILT_LDS), "SPH_LDS is the sphere filter of the hierarchy kernels");
   constexpr bool SHIFT = (FILT_LDS && !TRIS) || SPH_LDS;
-  const FiltRay fr = filter_ray<SHIFT>(o, d, filt_shift, near_R2);
+  const FiltRay fr = filter_ray<SHIFT, SHIFT && !SPH_LDS>(o, d, filt_shift, near_R2);
   const float ox = fr.ox, oy = fr.oy, oz = fr.oz;
   const f32x2 dx = fr.dx, dy = fr.dy, dz = fr.dz;
   const bool far_origin = fr.far_origin;
