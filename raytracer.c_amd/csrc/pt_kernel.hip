@@ -610,6 +610,36 @@ __device__ __forceinline__ uint32_t push_keep_bit(uint32_t word, float tca, floa
   return word;
 }
 
+/* A per-ray value as the LOW half of a packed-fp32 operand.  The sign-test filter multiplies two spheres (the halves of
+ * one register pair) by the same per-ray value; the compiler's way is to copy that value into both halves first -- eight
+ * v_mov per trip -- although the hardware can read the low half for both results (op_sel_hi = 0).  The compiler does not
+ * use that, so these few instructions are written out; the high half of such an operand is never read. */
+__device__ __forceinline__ f32x2 lo_half(float x)
+{
+  f32x2 r;
+  r.x = x; /* (the high half stays undefined on purpose: nothing initialises it, nothing keeps it alive) */
+  return r;
+}
+/* a * b.lo + c.lo, a * b.lo + c, a + b.lo -- per half of a */
+__device__ __forceinline__ f32x2 pk_fma_lo_lo(f32x2 a, f32x2 b, f32x2 c)
+{
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 a, f32x2 b, f32x2 c)
+{
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_add_lo(f32x2 a, f32x2 b)
+{
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 /* the ray as phase 1 of scan_filtered sees it: fp32 (round to nearest: relative error <= 2^-24,
  * part of the bound), origin pulled back by filt_shift along d in the sign-test form */
 struct FiltRay
@@ -627,9 +657,10 @@ template <bool SHIFT, bool FAR32 = false>
 __device__ __forceinline__ FiltRay filter_ray(const V3 &o, const V3 &d, double filt_shift, double near_R2)
 {
   FiltRay r;
-  r.ox = SHIFT ? (float)(o.x - filt_shift * d.x) : (float)o.x;
-  r.oy = SHIFT ? (float)(o.y - filt_shift * d.y) : (float)o.y;
-  r.oz = SHIFT ? (float)(o.z - filt_shift * d.z) : (float)o.z;
+  /* (fused: the pulled-back origin only feeds the conservative filter, where one fp64 ulp is 2^-29 of the fp32 rounding that follows) */
+  r.ox = SHIFT ? (float)__builtin_fma(-filt_shift, d.x, o.x) : (float)o.x;
+  r.oy = SHIFT ? (float)__builtin_fma(-filt_shift, d.y, o.y) : (float)o.y;
+  r.oz = SHIFT ? (float)__builtin_fma(-filt_shift, d.z, o.z) : (float)o.z;
   r.dx = {(float)d.x, (float)d.x};
   r.dy = {(float)d.y, (float)d.y};
   r.dz = {(float)d.z, (float)d.z};
@@ -696,8 +727,8 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
   const f32x2 dx = fr.dx, dy = fr.dy, dz = fr.dz;
   const bool far_origin = fr.far_origin;
   /* sign-test form: per-ray terms of the expanded products, both halves alike */
-  const f32x2 neg_od = {-fr.od, -fr.od}, oo = {fr.oo, fr.oo};
-  const f32x2 m2ox = {fr.m2ox, fr.m2ox}, m2oy = {fr.m2oy, fr.m2oy}, m2oz = {fr.m2oz, fr.m2oz};
+  const f32x2 dxl = lo_half(fr.dx.x), dyl = lo_half(fr.dy.x), dzl = lo_half(fr.dz.x), neg_odl = lo_half(-fr.od), ool = lo_half(fr.oo),
+              m2oxl = lo_half(fr.m2ox), m2oyl = lo_half(fr.m2oy), m2ozl = lo_half(fr.m2oz);
   /* ---- phase 1: conservative packed-fp32 filter, all lanes on the same pair ---- */
   cand_lo = 0;
   cand_hi = 0;
@@ -717,8 +748,8 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
       /* the products expanded: tca' = c.d - o'.d and |c - o'|^2 - r2_hi = (|c|^2 - r2_hi) + |o'|^2 - 2 c.o', so the
        * per-sphere work is two 3-term chains on c alone (8 packed ops per pair instead of 10; |c|^2 - r2_hi comes
        * exact-then-rounded from the table, which also spares the walls' |L|^2 ~ 1e8 its fp32 rounding) */
-      const f32x2 tca = __builtin_elementwise_fma(g.cz, dz, __builtin_elementwise_fma(g.cy, dy, __builtin_elementwise_fma(g.cx, dx, neg_od)));
-      const f32x2 ll = __builtin_elementwise_fma(g.cz, m2oz, __builtin_elementwise_fma(g.cy, m2oy, __builtin_elementwise_fma(g.cx, m2ox, g.r2_hi + oo)));
+      const f32x2 tca = pk_fma_lo(g.cz, dzl, pk_fma_lo(g.cy, dyl, pk_fma_lo_lo(g.cx, dxl, neg_odl)));
+      const f32x2 ll = pk_fma_lo(g.cz, m2ozl, pk_fma_lo(g.cy, m2oyl, pk_fma_lo(g.cx, m2oxl, pk_add_lo(g.r2_hi, ool))));
       /* ONE sign decides: q'' = tca |tca| - ll.  Where tca32 >= 0 it is q = tca^2 - ll, the reject "d2 > r2_hi" as
        * before.  Where tca32 < 0 the reference rejects the sphere whatever q says (the pulled-back origin makes
        * tca32' > 0 for every tca >= 0, scan_filtered), so any sign is right there: -tca^2 - ll is negative for an
@@ -790,8 +821,8 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
         if ((uint32_t)p < nb) /* wave-uniform */
         {
           const PairRec g = load_pair((uint32_t)p);
-          const f32x2 tca = __builtin_elementwise_fma(g.cz, dz, __builtin_elementwise_fma(g.cy, dy, __builtin_elementwise_fma(g.cx, dx, neg_od)));
-          const f32x2 ll = __builtin_elementwise_fma(g.cz, m2oz, __builtin_elementwise_fma(g.cy, m2oy, __builtin_elementwise_fma(g.cx, m2ox, g.r2_hi + oo)));
+          const f32x2 tca = pk_fma_lo(g.cz, dzl, pk_fma_lo(g.cy, dyl, pk_fma_lo_lo(g.cx, dxl, neg_odl)));
+          const f32x2 ll = pk_fma_lo(g.cz, m2ozl, pk_fma_lo(g.cy, m2oyl, pk_fma_lo(g.cx, m2oxl, pk_add_lo(g.r2_hi, ool))));
           const float qx = __builtin_fmaf(tca.x, __builtin_fabsf(tca.x), -ll.x), qy = __builtin_fmaf(tca.y, __builtin_fabsf(tca.y), -ll.y);
           cand_lo = __builtin_amdgcn_alignbit(cand_lo, __float_as_uint(qy), 31);
           cand_lo = __builtin_amdgcn_alignbit(cand_lo, __float_as_uint(qx), 31);
@@ -860,8 +891,8 @@ __device__ __forceinline__ void filter_chunk_listed(const f32x2 *__restrict__ fi
                                                     const FiltRay &fr, uint32_t &cand_lo, uint32_t &cand_hi)
 {
   const f32x2 dx = fr.dx, dy = fr.dy, dz = fr.dz;
-  const f32x2 neg_od = {-fr.od, -fr.od}, oo = {fr.oo, fr.oo};
-  const f32x2 m2ox = {fr.m2ox, fr.m2ox}, m2oy = {fr.m2oy, fr.m2oy}, m2oz = {fr.m2oz, fr.m2oz};
+  const f32x2 dxl = lo_half(fr.dx.x), dyl = lo_half(fr.dy.x), dzl = lo_half(fr.dz.x), neg_odl = lo_half(-fr.od), ool = lo_half(fr.oo),
+              m2oxl = lo_half(fr.m2ox), m2oyl = lo_half(fr.m2oy), m2ozl = lo_half(fr.m2oz);
   unsigned long long keep = 0;
   uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_mask);
   while (pm != 0u)
@@ -873,8 +904,8 @@ __device__ __forceinline__ void filter_chunk_listed(const f32x2 *__restrict__ fi
     if (SHIFT)
     {
       const f32x2 cx = g[0], cy = g[1], cz = g[2], kq = g[5];
-      const f32x2 tca = __builtin_elementwise_fma(cz, dz, __builtin_elementwise_fma(cy, dy, __builtin_elementwise_fma(cx, dx, neg_od)));
-      const f32x2 ll = __builtin_elementwise_fma(cz, m2oz, __builtin_elementwise_fma(cy, m2oy, __builtin_elementwise_fma(cx, m2ox, kq + oo)));
+      const f32x2 tca = pk_fma_lo(cz, dzl, pk_fma_lo(cy, dyl, pk_fma_lo_lo(cx, dxl, neg_odl)));
+      const f32x2 ll = pk_fma_lo(cz, m2ozl, pk_fma_lo(cy, m2oyl, pk_fma_lo(cx, m2oxl, pk_add_lo(kq, ool))));
       /* a set sign bit of q'' = tca |tca| - ll means DROP (filter_chunk) */
       const float qx = __builtin_fmaf(tca.x, __builtin_fabsf(tca.x), -ll.x), qy = __builtin_fmaf(tca.y, __builtin_fabsf(tca.y), -ll.y);
       const uint32_t d0 = __float_as_uint(qx) >> 31, d1 = __float_as_uint(qy) >> 31;
