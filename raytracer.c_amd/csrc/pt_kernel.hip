@@ -1629,11 +1629,10 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
   const V3 o = P.o, d = P.d;
   /* DEFER_DIR callers (the pooled and parked-walk kernels) flush a path's radiance to the pixel sums every trip: P.Ls is
    * zero on entry, and this call's one term -- the hit's emission whether the path goes on or dies in the roulette,
-   * BACKGROUND if it found nothing or ran out of depth -- is the throughput AT ENTRY times `add`.  Formed once, at the
-   * end, instead of accumulated into P.Ls in two places (three products, three "+ 0" the compiler may not fold, three more
+   * BACKGROUND if it found nothing or ran out of depth -- is the throughput AT ENTRY times `add`.  Formed once (below,
+   * before the throughput changes) instead of accumulated into P.Ls in two places (three products, three "+ 0" the compiler may not fold, three more
    * additions and six selects per trip).  Scenes with M_REFRACTION (two children share a term) keep the general form. */
   constexpr bool ONE_TERM = DEFER_DIR && !REFRACT;
-  const V3 T_in = P.T;
   HitRec local;
   HitRec &H = (MODE == 0 && !DEFER_DIR) ? local : *rec;
 
@@ -1672,6 +1671,11 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
   const int best = H.best;
   if (TRIS && (MODE != 0 || DEFER_DIR))
     H.leaving = false;
+  /* ONE_TERM: BACKGROUND for every lane here, the hit's emission over it inside the hit's own branch below -- both before
+   * anything touches the throughput, so no second copy of it has to live to the end of the call (nine 64-bit register
+   * moves per trip), and written under the branches' lane masks, so no selects either */
+  if (ONE_TERM)
+    P.Ls = v_scale(P.T, S.bg);
 
   if (H.depth_ok)
   {
@@ -1716,6 +1720,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       const uint32_t flags = (uint32_t)__double_as_longlong(m[7]);
 
       add = emission; /* a path that dies in the roulette returns emission (:502) */
+      if (ONE_TERM)
+        P.Ls = v_mul(P.T, emission);
       /* russian roulette :497-502: the draw is always consumed */
       if (rnd(P.rng) < prob)
       {
@@ -1831,8 +1837,6 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       }
     }
   }
-  if (ONE_TERM)
-    P.Ls = v_mul(T_in, add); /* (add = the hit's emission, or BACKGROUND) */
   if (path_ends)
   {
     if (!ONE_TERM)
