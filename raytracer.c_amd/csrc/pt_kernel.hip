@@ -1589,9 +1589,12 @@ __device__ __forceinline__ V3 hemisphere_from_sample(const V3 &q, double len2, c
    * vector negates its dot product exactly, so the second dot product is the first with the
    * sign the flip gave it */
   const double side = v_dot(nd, n);
-  if (side < 0)
-    nd = v_scale(nd, -1);
-  weight = side < 0 ? -side : side;
+  /* (the conditional negations as one sign mask XORed into the four high words: the same doubles -- negation is the
+   * sign bit -- in five instructions instead of four negations and four selects) */
+  const uint32_t flip = side < 0 ? 0x80000000u : 0u;
+  auto signed_by = [flip](double x) { return __hiloint2double((int)((uint32_t)__double2hiint(x) ^ flip), __double2loint(x)); };
+  nd = {signed_by(nd.x), signed_by(nd.y), signed_by(nd.z)};
+  weight = signed_by(side);
   return nd;
 }
 
