@@ -488,27 +488,39 @@ __device__ __forceinline__ uint32_t leaf_pretest(const float4 *__restrict__ tri3
     return keep;
   const float fdx = (float)d.x, fdy = (float)d.y, fdz = (float)d.z;
   const float4 *rec = tri32 + (PT_TRI32_STRIDE / 4) * (size_t)first;
-  float4 c0 = rec[0], c1 = rec[1], c2 = rec[2];
-  float c3 = rec[3].x;
-  for (uint32_t k = 0; k < count; k++)
+  /* two buffers used in turn, two triangles per iteration: record k + 1 is on its way while k is tested, and no record is
+   * copied from a "next" to a "current" set of registers (as one buffer pair the loop spent 13 v_mov per triangle on that) */
+  float4 a0 = rec[0], a1 = rec[1], a2 = rec[2];
+  float a3 = rec[3].x;
+  float4 b0 = a0, b1 = a1, b2 = a2;
+  float b3 = a3;
+  for (uint32_t k = 0; k < count; k += 2u)
   {
     DIAG(16, 1);
-    float4 n0 = c0, n1 = c1, n2 = c2;
-    float n3 = c3;
-    if (k + 1u < count)
+    const bool second = k + 1u < count;
+    if (second)
     {
-      rec += PT_TRI32_STRIDE / 4;
-      n0 = rec[0];
-      n1 = rec[1];
-      n2 = rec[2];
-      n3 = rec[3].x;
+      b0 = rec[4];
+      b1 = rec[5];
+      b2 = rec[6];
+      b3 = rec[7].x;
     }
-    if (!tri_may_hit32(c0, c1, c2, c3, R.ox.x, R.oy.x, R.oz.x, fdx, fdy, fdz))
+    if (!tri_may_hit32(a0, a1, a2, a3, R.ox.x, R.oy.x, R.oz.x, fdx, fdy, fdz))
       keep &= ~(1u << k);
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
-    c3 = n3;
+    if (second)
+    {
+      DIAG(16, 1);
+      if (k + 2u < count)
+      {
+        a0 = rec[8];
+        a1 = rec[9];
+        a2 = rec[10];
+        a3 = rec[11].x;
+      }
+      if (!tri_may_hit32(b0, b1, b2, b3, R.ox.x, R.oy.x, R.oz.x, fdx, fdy, fdz))
+        keep &= ~(2u << k);
+    }
+    rec += 2 * (PT_TRI32_STRIDE / 4);
   }
   (void)diag_ptr;
   return keep;
@@ -1520,7 +1532,12 @@ __device__ __forceinline__ double div_small_int(double a, double b, double y)
 /* the sample half of the stream key (rt_rng.h, rt_rng_sample_state): pixel_key + 0xD1B5... * (sample + 1).  Callers whose
  * sample index is wave-uniform (a batch of a full tile = one sample index of every pixel) form it once, as scalar work:
  * as vector work it is two quarter-rate 64-bit multiplies per lane */
-__device__ __forceinline__ uint64_t sample_term(uint32_t s) { return 0xD1B54A32D192ED03ull * ((uint64_t)s + 1u); }
+__device__ __forceinline__ uint64_t sample_term(uint32_t s)
+{ /* (s + 1 in 32 bits -- sample indices are below 2^31 -- so that the product has no 64-bit addend: written as
+   * C * ((uint64_t)s + 1) the compiler keeps C itself in a register pair for the "+ C" of s * C + C) */
+  const uint32_t s1 = s + 1u;
+  return 0xD1B54A32D192ED03ull * (uint64_t)s1;
+}
 /* the same for a wave-uniform sample index given in the lanes' registers: formed by the scalar unit, and pinned there (or
  * the compiler merges it with the per-lane form of the ragged-tile branch and multiplies in the vector unit after all) */
 __device__ __forceinline__ uint64_t sample_term_uniform(uint32_t s_any_lane)
@@ -2776,9 +2793,15 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
       }
       next = min(n_new, next + (uint32_t)__popcll(need));
     }
-    const unsigned long long active = __ballot(have);
-    if (active == 0)
+    if (__ballot(have) == 0)
       break; /* every ray walked: the one exit, reached by all lanes together */
+    /* Steps until the next refill is due, in a loop of their own: what belongs to the lane's ray (origin and direction in
+     * fp64 and in the slab test's fp32 form, its ring entry: 27 registers) does not change in here.  In one loop with the
+     * refill, which assigns them under a lane mask, the compiler moved all of them to other registers and back on every
+     * iteration -- some forty v_mov per node visit of sixty instructions. */
+    for (;;)
+    {
+    const unsigned long long active = __ballot(have);
     const bool at_leaf = have && (ref & PT_BVH_LEAF_FLAG) != 0u;
     const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
     const uint32_t n_inner = (uint32_t)__popcll(active) - n_leaf;
@@ -2867,6 +2890,10 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
         ring_st(ring, 12u, e, last.v);
       }
       have = false;
+    }
+    const unsigned long long free_now = __ballot(!have);
+    if (free_now == ~0ull || (next < n_new && (uint32_t)__popcll(free_now) >= PT_REFILL_BATCH))
+      break; /* nobody holds a ray any more, or a batch of lanes is free and rays are left: back to the refill */
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* results in L2 before anyone resumes them */
@@ -3181,7 +3208,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           asm volatile("" : "+v"(nv));
           const uint32_t s = job / nv;
           idx = job - s * nv;
-          term = sample_term(s_begin + s);
+          uint32_t sv = s_begin + s;
+          asm volatile("" : "+v"(sv)); /* (or the constant part of the product is formed ahead of the loop and kept, in scratch memory) */
+          term = sample_term(sv);
         }
         uint32_t vc = vcols;
         if (vcols != PT_TILE)
@@ -3189,8 +3218,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         const uint32_t row = (vcols == PT_TILE) ? (idx >> 3) : (idx / vc);
         const uint32_t col = idx - __umul24(row, vcols); /* (v_mul_u32_u24: full rate) */
         pix_slot = row * PT_TILE + col;
-        const uint64_t pixel_key = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ring.f + PT_PARK_Q * 16u) + pix_slot,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* (L1-bypassing, like every ring load) */
+        /* (the keys' offset behind the ring through a register the compiler cannot see through: hoisted out of the loop, the
+         * sum would be one more address held for its whole length -- in scratch memory, this kernel has no register left) */
+        uint32_t key_at = PT_PARK_Q * 16u + pix_slot;
+        asm volatile("" : "+v"(key_at));
+        const uint64_t pixel_key = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ring.f) + key_at, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT); /* (L1-bypassing, like every ring load) */
         start_sample(P, load_camera_lds(cam_lds), pixel_key, tx0 + col, ty0 + row, term);
         hit.need_dir = false;
         hit.leaving = false;
