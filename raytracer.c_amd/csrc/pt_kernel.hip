@@ -1705,6 +1705,10 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       DIAG_LANES(9);
       /* ---- the winner's hit record (:406-411 / :428-431) ---- */
       V3 p = v_add(o, v_scale(d, min_t)); /* point_at :257 */
+      /* (ONE_TERM kernels: the hit point becomes the path's origin here, for every lane that hit -- a path that ends below
+       * never reads it again -- so that it is formed in the origin's own registers instead of copied there at the end) */
+      if (ONE_TERM)
+        P.o = p;
       V3 n;
       uint32_t slot, hull = 0u;
       double tex_u = 0, tex_v = 0;
@@ -1851,7 +1855,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           if (!ONE_TERM && !(DEFER_DIR && dir_deferred))
             P.T = v_mul(P.T, (flags & PT_FLAG_MIRROR) ? albedo : v_scale(albedo, weight));
         }
-        P.o = p;
+        if (!ONE_TERM)
+          P.o = p;
         P.d = nd;
         P.depth++;
       }
@@ -3222,8 +3227,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
          * sum would be one more address held for its whole length -- in scratch memory, this kernel has no register left) */
         uint32_t key_at = PT_PARK_Q * 16u + pix_slot;
         asm volatile("" : "+v"(key_at));
+#ifndef PT_KEYS_RECOMPUTED /* (A/B: hash the key again for every camera sample, as before) */
         const uint64_t pixel_key = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ring.f) + key_at, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT); /* (L1-bypassing, like every ring load) */
+#else
+        const uint64_t pixel_key = rt_rng_pixel_key(L.seed, (ty0 + row) * (uint32_t)L.width + tx0 + col);
+#endif
         start_sample(P, load_camera_lds(cam_lds), pixel_key, tx0 + col, ty0 + row, term);
         hit.need_dir = false;
         hit.leaving = false;
