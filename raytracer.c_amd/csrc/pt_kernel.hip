@@ -2620,7 +2620,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 #define PT_PARK_Q 512u
 #endif
 #ifndef PT_PARK_WALK
-#define PT_PARK_WALK 190u /* parked rays that turn the wave to walking (measured at 4K x 256 spp: 32: 664 ms, 64: 553, 128: 529, 190: 521) */
+#define PT_PARK_WALK 256u /* parked rays that turn the wave to walking (round 2's kernel at 4K x 256 spp: 32: 664 ms, 64: 553, 128: 529, 190: 521;
+                          * round 3's last, with 512 ring entries: 128: 222.9, 190: 220.5, 256: 219.2, 320: 219.1, 384: 219.0 -- 256 is also the best at 64 spp) */
 #endif
 #ifndef PT_STAGE
 #define PT_STAGE 32u /* walked rays copied from the ring to LDS at a time (<= 64) */
@@ -2629,7 +2630,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 #define PT_REFILL_BATCH 16u /* free lanes that trigger a refill from the ring inside a walk phase */
 #endif
 #ifndef PT_LEAF_BATCH
-#define PT_LEAF_BATCH 24u /* lanes holding a leaf that trigger a round of exact triangle tests */
+#define PT_LEAF_BATCH 32u /* lanes holding a leaf that trigger a round of exact triangle tests (16: 223.1 ms, 24: 220.5, 32: 220.1 at 4K x 256 spp) */
 #endif
 #define PT_PARK_F64_FIELDS 13u /* o xyz, d xyz, T xyz, rng, min_t, (M_CHECKERED kernels: last u, v) */
 #define PT_PARK_U32_FIELDS 4u  /* best, depth << 6 | pixel slot, (last index), pad */
