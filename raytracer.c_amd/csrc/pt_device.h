@@ -56,16 +56,18 @@
 #define PT_MAT_STRIDE 8     /* doubles per material record */
 #define PT_FILT_LDS_MAX 256  /* primitives up to which the filter table is also staged in LDS */
 #ifndef PT_BVH_LEAF
-#define PT_BVH_LEAF 7         /* max triangles per BVH leaf (<= 7: the count has 3 bits); config 5 at 4K x 256 spp: 2: 435 ms,
+#define PT_BVH_LEAF 15        /* max triangles per BVH leaf (< 2^PT_BVH_COUNT_BITS); config 5 at 4K x 256 spp: 2: 435 ms,
                                * 3: 428, 4: 428, 7: 420 (round 1's kernel).  With the pipelined fp32 pre-test at the leaves
                                * (round 2: a leaf visit costs one exposed round trip whatever its size) at 64 / 256 spp:
                                * 2: 88.3 / 326.7 ms, 4: 86.5 / 321.0, 7 (5 per leaf in config 5): 71.9 / 268.2,
-                               * 15 with PT_BVH_COUNT_BITS 4 (10 per leaf): 71.4 / 266.8, 31 with 5 bits (20 per leaf): 73.2 / 273.9 */
+                               * 15 with PT_BVH_COUNT_BITS 4 (10 per leaf): 71.4 / 266.8, 31 with 5 bits (20 per leaf): 73.2 / 273.9.
+                               * End of round 3 (node visits and pre-tests trimmed, the walk waits for its node fetches more
+                               * than it computes): 4: 70.2 / 261.1 ms, 7: 58.5 / 219.3, 15: 58.4 / 217.7, 31: 60.3 / 225.3 -> 15 */
 #endif
 #define PT_BVH_NODE_WORDS 16  /* 64-byte device node: 6 f32x2 planes (child 0, child 1) + 2 refs + pad */
 #define PT_BVH_SRC_DOUBLES 16 /* fp64 source node: 2 x (min xyz, max xyz), refs, pad */
 #ifndef PT_BVH_COUNT_BITS
-#define PT_BVH_COUNT_BITS 3 /* bits of a leaf reference that hold its triangle count (PT_BVH_LEAF < 2^bits) */
+#define PT_BVH_COUNT_BITS 4 /* bits of a leaf reference that hold its triangle count (PT_BVH_LEAF < 2^bits) */
 #endif
 #define PT_BVH_LEAF_FLAG 0x80000000u
 #define PT_BVH_STACK 24       /* per-lane traversal stack (LDS): tree depth limit */

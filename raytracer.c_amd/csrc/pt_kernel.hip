@@ -2715,8 +2715,8 @@ __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
 
 /* The per-lane traversal stacks of the parked-walk kernels: 24-bit entries (a 16-bit and an 8-bit array, entry-major,
  * one entry per tree level and lane), because at four workgroups per CU every kilobyte of LDS counts there.  A reference
- * fits 24 bits while node indices stay below 2^23 and leaf references below 2^23 + 2^20 triangles (PT_WALK_REF_OK,
- * checked on the host: other meshes take the lane-waiting kernels). */
+ * fits 24 bits while node indices stay below 2^23 and meshes below 2^(23 - PT_BVH_COUNT_BITS) triangles
+ * (checked on the host, pt_pick_kernel: other meshes take the lane-waiting kernels). */
 struct WalkStack
 {
   uint16_t *lo; /* [levels][PT_BLOCK] */
@@ -4065,7 +4065,7 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
     which = cast_ray ? 18 : 17;
   else if (variant == 0 && !refr && !cast_ray)
     which = 12;
-  else if ((which == 3 || which == 7) && variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) && scene.n_triangles < (1u << 20))
+  else if ((which == 3 || which == 7) && variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) && scene.n_triangles < (1u << (23 - PT_BVH_COUNT_BITS)))
     which = which == 3 ? (scene.mesh_round ? 21 : 19) : 20; /* hierarchy scenes: parked walks (variant 2, scenes beyond fp32's comfortable range,
                                    * whose filter needs the NaN-safe compares, and meshes whose references do not fit the walk's
                                    * 24-bit stack entries keep the lane-waiting pooled kernels) */

@@ -691,8 +691,8 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
       bvh.order[k] = k;
       bvh.tri_box(k);
     }
-    if (n_tri >= (1u << 28))
-      return fail(RT_HIP_ELIMIT, "%zu triangles exceed the hierarchy's leaf references (2^28)", n_tri);
+    if (n_tri >= (1u << (31 - PT_BVH_COUNT_BITS)))
+      return fail(RT_HIP_ELIMIT, "%zu triangles exceed the hierarchy's leaf references (2^%d)", n_tri, 31 - PT_BVH_COUNT_BITS);
     bvh.build_root((uint32_t)n_tri);
     if (bvh.depth > PT_BVH_STACK)
       return fail(RT_HIP_ELIMIT, "triangle hierarchy depth %d exceeds the traversal stack (%d)", bvh.depth, PT_BVH_STACK);
