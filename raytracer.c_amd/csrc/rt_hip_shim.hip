@@ -894,9 +894,10 @@ uint32_t rt_hip_suggest_chunks(const RtHipScene *scene, uint32_t tile_count, int
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, scene->device) != hipSuccess)
     return 1;
-  /* aim for >= 12 workgroups per resident slot (5 per CU), so the last, partly filled round
-   * of the launch is a small fraction of it; keep >= 64 samples per chunk */
-  const uint64_t want = 12ull * 5ull * (uint64_t)prop.multiProcessorCount;
+  /* aim for >= 20 workgroups per resident slot (5 per CU), so the last, partly filled round
+   * of the launch is a small fraction of it; keep >= 64 samples per chunk.  (One rank's share of the headline frame at
+   * N = 8 / 4 / 2, ms by chunks: 2: 30.0, 4: 29.3, 6: 29.4, 8: 29.6, 16: 30.9 / 1: 59.1, 2: 57.7, 4: 57.5 / 1: 114.7, 2: 113.4.) */
+  const uint64_t want = 20ull * 5ull * (uint64_t)prop.multiProcessorCount;
   uint64_t chunks = (want + tile_count - 1) / tile_count;
   const uint64_t cap = (uint64_t)samples / 64;
   if (chunks > cap) chunks = cap;
