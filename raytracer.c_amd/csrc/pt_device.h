@@ -142,6 +142,30 @@ static inline bool pt_filter_in_lds(const PtSceneView &sc)
   return (uint64_t)sc.n_spheres + sc.n_triangles <= PT_FILT_LDS_MAX && !sc.wide_range && pt_geom_in_lds(sc);
 }
 
+/* Sign-test form of the phase-1 filter (small sphere scenes; pt_build_filter writes the table, the kernels' BigPrune
+ * and the host's big_prune_for reason about it): how far a sphere's squared radius is widened in its table entry
+ * kq = |c|^2 - r2_hi', with e = 2^-24, A = |c| + near_R and g = | |c|^2 - r^2 |.  ONE definition for the device code that
+ * builds the table and the host code that bounds hit-distance estimates by it (round-3 advisor finding: the two used to
+ * be maintained by hand in separate files):
+ *   pt_sign_widen_r2    what is added to r^2 before the subtraction from |c|^2 (the fp32 arithmetic's error bound,
+ *                       derivation at pt_build_filter);
+ *   pt_sign_widen_kq    what is taken off kq afterwards, for the chain's own roundings of kq;
+ *   pt_sign_widen_total their sum: r2_hi' - r^2 as the table has it, before kq's final rounding DOWN to fp32 (one more
+ *                       2 e |kq|: callers that need an upper bound on the widening multiply by 1.001). */
+#define PT_E32 5.9604644775390625e-08 /* 2^-24 */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline double pt_sign_widen_r2(double A, double g) { return (40.0 * PT_E32 * A * A + 8.0 * PT_E32 * g) * (1.0 + 8.0 * PT_E32); }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline double pt_sign_widen_kq(double g) { return 4.0 * PT_E32 * g; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline double pt_sign_widen_total(double A, double g) { return pt_sign_widen_r2(A, g) + pt_sign_widen_kq(g); }
+
 /* The filter buffer of a small scene (pt_filter_in_lds) holds two tables: the pair table of
  * phase 1 (PT_FILT_STRIDE f32x2 per primitive pair, + the look-ahead pair), then, 16-byte aligned,
  * the fp32 triangle table of the per-lane pre-test (PT_TRI32_STRIDE floats per triangle). */
@@ -195,7 +219,8 @@ struct PtLaunch
   float big_delta, big_tmin;
   float big_qmin[8];
   /* parked-walk kernels: workspace of PT_PARK_XCDS x park_slots_per_xcd slots x 4 waves x PT_PARK_WAVE_BYTES and
-   * one in-use flag per slot (zero between launches); nullptr: walk in the lanes */
+   * one in-use flag per slot (zero between launches).  nullptr (the allocation failed): pt_launch_render takes the
+   * lane-waiting _tri_big kernels instead, which need no workspace -- the parked-walk kernels never run without one */
   char *park_ws;
   uint32_t *park_flags;
   uint32_t park_slots_per_xcd;
@@ -213,7 +238,7 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
 hipError_t pt_launch_build_hull_flags(const double *tri_geom, const double *tri_normal, uint32_t n_tri, double tau,
                                       uint32_t *tri_object, hipStream_t stream);
 hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream);
-const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant);
+const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws = true);
 hipError_t pt_launch_selftest_xcc(unsigned int *counts, uint32_t n_workgroups, hipStream_t stream);
 hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream);
 hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,

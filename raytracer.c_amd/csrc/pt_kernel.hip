@@ -287,8 +287,9 @@ struct TriLast
 
 /* UNSCALED: 1.0 / a through rcp_unscaled -- the same quotient for 2^-500 <= |a| <= 2^500 (either sign: the scaling steps it
  * leaves out act on magnitudes only; checked on the device, test_device_math_shortcuts_are_bit_exact).  |a| >= 1e-8 here, and
- * the kernels that pass true run only scenes whose every centre, radius and bounding sphere is within 1e17
- * (PtSceneView.wide_range == 0: pt_filter_in_lds, pt_pick_kernel), so |a| <= |e1||e2||d| < 1e36.  (a = NaN or inf: no hit
+ * |a| <= |e1||e2||d| < 2e30: every launch refuses near_R >= 1e15 (rt_hip_render_tiles_chunked; the static_assert next to
+ * RT_NEAR_R_LIMIT in rt_hip_shim.hip does the arithmetic), and every vertex lies within near_R / 1.5 of the origin -- that
+ * check, not PtSceneView.wide_range (which speaks of spheres only), is what the range rests on.  (a = NaN or inf: no hit
  * either way -- t comes out NaN or 0, never above EPSILON.)  Four instructions less per test than the general division. */
 template <bool TIE = false, bool LAST = false, bool UNSCALED = false>
 __device__ __forceinline__ void exact_triangle(const double *g, uint32_t index, const V3 &o, const V3 &d,
@@ -497,6 +498,7 @@ __device__ __forceinline__ uint32_t leaf_pretest(const float4 *__restrict__ tri3
   for (uint32_t k = 0; k < count; k += 2u)
   {
     DIAG(16, 1);
+    DIAG_LANES(40); /* lane-level leaf pre-tests */
     const bool second = k + 1u < count;
     if (second)
     {
@@ -510,6 +512,7 @@ __device__ __forceinline__ uint32_t leaf_pretest(const float4 *__restrict__ tri3
     if (second)
     {
       DIAG(16, 1);
+      DIAG_LANES(40);
       if (k + 2u < count)
       {
         a0 = rec[8];
@@ -583,6 +586,7 @@ __device__ __forceinline__ void bvh_traverse(const float *__restrict__ nodes, ui
     while (keep != 0u)
     {
       DIAG(14, 1);
+      DIAG_LANES(41); /* lane-level exact triangle tests */
       const uint32_t t = tri_order[first + (uint32_t)__builtin_ctz(keep)];
       keep &= keep - 1u;
       exact_triangle<true, LAST>(tri_geom + 9 * (size_t)t, n_sph + t, o, d, min_t, best, bary_u, bary_v, last);
@@ -1197,6 +1201,9 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       }
     }
 #ifdef PT_DIAG
+    /* lane-level filter evaluations: (lane, primitive) pairs that went through the packed-fp32 test */
+    DIAG(39, (unsigned long long)__popcll(__ballot(1)) *
+                 ((FILT_LDS && !SPH_LDS && prim_pairs != nullptr) ? 2u * (uint32_t)__popc(prim_pairs[base >> 6]) : chunk));
     {
       /* exactness check of the filter: any primitive it dropped that the exact test accepts? */
       uint32_t violations = 0;
@@ -1260,6 +1267,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       {
         const uint32_t k = (uint32_t)__builtin_ctz(cand_lo);
         cand_lo &= cand_lo - 1u;
+        DIAG_LANES(43); /* lane-level exact sphere tests */
         exact_sphere(geom + PT_GEOM_STRIDE * (base + k), base + k, o, d, min_t, best);
       }
     while (cand_lo | cand_hi)
@@ -1272,6 +1280,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       cand_lo = in_lo ? cleared : 0u;
       cand_hi = in_lo ? cand_hi : cleared;
       const uint32_t i = base + k;
+      DIAG_LANES(43);
       exact_sphere(geom + PT_GEOM_STRIDE * i, i, o, d, min_t, best);
     }
     PHASE(2); /* phase 2: exact tests */
@@ -1301,6 +1310,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
         tri_lo = in_lo ? cleared : 0u;
         tri_hi = in_lo ? tri_hi : cleared;
         const uint32_t i = base + k;
+        DIAG_LANES(41);
         exact_triangle<false, LAST, FILT_LDS>(tri_geom + 9 * (size_t)(i - n_sph), i, o, d, min_t, best, bary_u, bary_v, last); /* (FILT_LDS: no wide-range scene) */
       }
   }
@@ -2689,9 +2699,11 @@ __device__ __forceinline__ void ring_st3(const ParkRing &r, uint32_t field, uint
   ring_st(r, field + 2u, e, v.z);
 }
 
-/* The workgroup's workspace slot, or 0xFFFFFFFF when there is none (no workspace, or -- a sizing
- * bug, never seen -- every slot of this XCD taken after a bounded search: the kernel then walks in
- * the lanes, slower but correct, rather than spin).  Thread 0 only. */
+/* The workgroup's workspace slot, or 0xFFFFFFFF when there is none: no workspace (cannot happen: without one
+ * pt_launch_render takes the lane-waiting _tri_big kernels), or -- a sizing bug of the pool, never seen: it has
+ * PT_PARK_SLOTS_PER_XCD = 192 slots for at most 160 resident workgroups -- every slot of this XCD taken after a bounded
+ * search.  The waves of such a workgroup render nothing and say so: every pixel of their tiles comes out NaN (bytes 255;
+ * render_tiles_queued), rather than spin for ever or walk rays from registers the kernel does not have.  Thread 0 only. */
 __device__ __forceinline__ uint32_t lane_of_thread() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
 {
@@ -2860,6 +2872,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
       while (keep != 0u)
       {
         DIAG(14, 1);
+        DIAG_LANES(41);
         const uint32_t k = (uint32_t)__builtin_ctz(keep);
         keep &= keep - 1u;
         const uint32_t t = S.bvh_tri[first_tri + k];
@@ -3309,6 +3322,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       want_walk = hit.depth_ok && bvh_probe<SPHERE_PROBE>(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
                                                           (CHECKER && S.stale_uv) ? S.t_start : hit.min_t, S.mesh_bound,
                                                           (L.diag_flags & 1u) ? &diag_in_sphere : nullptr);
+      if (hit.depth_ok && !no_mesh)
+        DIAG_LANES(42); /* lane-level probe evaluations of the shipped build */
       if (no_mesh)
       { /* walked all the same under RT_HIP_DIAG_WALK_REJECTED=1, and counted as a violation if it finds a triangle */
         diag_in_sphere = false;
@@ -3970,8 +3985,10 @@ extern "C" __global__ __launch_bounds__(256) void pt_build_filter(const double *
       f[6] = (float)((src[3] + 32.0 * e * A * A) * (1.0 + 8.0 * e));
       f[8] = -(float)((src[5] + 10.0 * e * A) * (1.0 + 4.0 * e));
       /* sign-test form (spheres, small scenes): kq = |c|^2 - r2_hi', formed in fp64 and rounded DOWN, with its
-       * own widening r2_hi' = R2 + 40 e A^2 + 8 e | |c|^2 - R2 |.  Bound behind it (e = 2^-24, A = |c| + near_R +
-       * tol_max, every input rounded to fp32, fused 3-term chains, o' the pulled-back origin):
+       * own widening r2_hi' = R2 + 40 e A^2 + 8 e | |c|^2 - R2 | (pt_sign_widen_r2).  Bound behind it (e = 2^-24, every input
+       * rounded to fp32, fused 3-term chains, o' the pulled-back origin, |o'| <= near_R + tol_max; the bound is stated with
+       * A' = |c| + near_R + tol_max while the code forms A = |c| + near_R: tol_max = 12 e (max |c| + near_R) <= 7.2e-7 A, so
+       * A'^2 <= (1 + 1.5e-6) A^2 -- inside the 40 over 28 slack of the widening by five orders of magnitude):
        *   tca32 = fma(cz,dz, fma(cy,dy, fma(cx,dx, -o'.d))):  |tca32 - tca'| <= 8.2 e A   (2 e |c| inputs, 3 e A chain,
        *           5.1 e |o'| for o'.d);
        *   ll32  = fma(cz,-2oz, fma(cy,-2oy, fma(cx,-2ox, kq + |o'|^2))):
@@ -3982,8 +3999,9 @@ extern "C" __global__ __launch_bounds__(256) void pt_build_filter(const double *
        * dropped sphere with the exact test: 0 violations). */
       {
         const double cc = src[4] * src[4]; /* |c| was rounded up by 1e-12: inside the slack */
-        const double widen = (40.0 * e * A * A + 8.0 * e * fabs(cc - src[3])) * (1.0 + 8.0 * e);
-        f[10] = __double2float_rd((cc - (src[3] + widen)) - 4.0 * e * fabs(cc - src[3]));
+        const double g = fabs(cc - src[3]);
+        /* pt_device.h: the widening shared with the host's big_prune_for (= (40 e A^2 + 8 e g)(1 + 8 e), then 4 e g) */
+        f[10] = __double2float_rd((cc - (src[3] + pt_sign_widen_r2(A, g))) - pt_sign_widen_kq(g));
       }
     }
     else
@@ -4045,7 +4063,8 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
 
 /* which member of the kernel family a launch of this scene takes (the selection of
  * pt_launch_render, also reported by rt_hip_kernel_name for profiles and bench lines) */
-static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name)
+/* have_park_ws = false: the parked-walk kernels' workspace is missing (its allocation failed): the lane-waiting kernels */
+static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name, bool have_park_ws = true)
 {
   static const char *const names[22] = {
       "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
@@ -4069,15 +4088,17 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
     which = which == 3 ? (scene.mesh_round ? 21 : 19) : 20; /* hierarchy scenes: parked walks (variant 2, scenes beyond fp32's comfortable range,
                                    * whose filter needs the NaN-safe compares, and meshes whose references do not fit the walk's
                                    * 24-bit stack entries keep the lane-waiting pooled kernels) */
+  if (which >= 19 && !have_park_ws)
+    which = which == 20 ? 7 : 3; /* no ring workspace: the lane-waiting kernels need none */
   if (name)
     *name = names[which];
   return which;
 }
 
-const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant)
+const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws)
 {
   const char *name = nullptr;
-  (void)pt_pick_kernel(scene, integrator, variant, &name);
+  (void)pt_pick_kernel(scene, integrator, variant, &name, have_park_ws);
   return name;
 }
 
@@ -4131,9 +4152,8 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
                                     pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
                                     pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem,
                                     pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph};
-  int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr);
-  if (which >= 19 && (launch.park_ws == nullptr || launch.park_slots_per_xcd == 0u))
-    which = which == 20 ? 7 : 3; /* no ring workspace (its allocation failed): the lane-waiting kernels need none */
+  const int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr,
+                                   launch.park_ws != nullptr && launch.park_slots_per_xcd != 0u);
   const Kernel kernel = family[which];
   if (which >= 19) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +

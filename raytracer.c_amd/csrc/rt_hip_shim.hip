@@ -26,6 +26,11 @@ static_assert(sizeof(RtHipSphere) == 88, "RtHipSphere must match the reference O
 static_assert(sizeof(RtHipVertex) == 40, "RtHipVertex must match the reference Vertex");
 static_assert(sizeof(RtHipCamera) == 96, "RtHipCamera must match the reference Camera");
 static_assert(RT_HIP_TILE == PT_TILE && RT_HIP_TILE_PIXELS == PT_TILE_PIXELS, "tile shape");
+/* exact_triangle<UNSCALED> divides through rcp_unscaled, valid for 2^-500 <= |a| <= 2^500 with |a| <= |e1||e2||d|: a launch
+ * refuses near_R >= RT_NEAR_R_LIMIT, vertices lie within near_R / 1.5, so |e1|, |e2| < 2 near_R / 1.5 and |d| <= 1.0001 */
+#define RT_NEAR_R_LIMIT 1e15
+static_assert((2.0 * RT_NEAR_R_LIMIT / 1.5) * (2.0 * RT_NEAR_R_LIMIT / 1.5) * 1.0001 < 3.2e150 /* < 2^500 */,
+              "the near_R limit keeps |e1||e2||d| inside rcp_unscaled's range");
 
 /* The camera-dependent tables of a scene (packed-fp32 filter table, fp32 hierarchy nodes; both
  * depend on near_R, i.e. on the camera's distance) for one near_R.  Built once on the stream of
@@ -56,8 +61,11 @@ struct RtHipScene
   mutable std::vector<TableSet> tables;
   mutable uint64_t table_clock = 0;
   size_t filt_bytes = 0, bvh_nodes_bytes = 0;
-  /* workspace of the parked-walk kernels (scenes with a triangle hierarchy), allocated at the first
-   * launch that can use it: in-use flags, then the rings (pt_device.h) */
+  /* workspace of the parked-walk kernels (scenes with a triangle hierarchy): in-use flags, then the rings
+   * (pt_device.h).  ONE per device, shared by every scene on it and counted (park_acquire_ws / park_drop_ws): the 406 MB
+   * used to be allocated per scene -- a test suite's every 48 x 32 fuzz scene paid it, and scenes alive at the same
+   * time each held a copy (round-3 advisor finding).  Sharing is safe between concurrent launches of different scenes:
+   * a workgroup takes a slot with an atomic flag, and the pool has more slots per XCD than workgroups can be resident. */
   mutable char *park_ws = nullptr;
   mutable bool park_tried = false;
   void *blob = nullptr; /* one device allocation holding every array */
@@ -396,20 +404,26 @@ int acquire_tables(const RtHipScene *scene, double near_R, hipStream_t stream, f
 /* after the render that reads table set `slot` has been submitted to `stream` */
 void release_tables(const RtHipScene *scene, size_t slot, hipStream_t stream)
 {
-  std::lock_guard<std::mutex> lock(scene->table_mutex);
-  if (slot < scene->tables.size())
+  std::unique_lock<std::mutex> lock(scene->table_mutex);
+  if (slot >= scene->tables.size())
+    return;
+  hipEvent_t ev = nullptr;
   {
     TableSet &t = scene->tables[slot];
-    hipEvent_t ev = nullptr;
     for (auto &r : t.readers)
       if (r.first == stream)
         ev = r.second;
     if (!ev && t.readers.size() >= 32)
-    { /* a caller cycling through many streams: wait out the oldest reader and hand its event to this stream */
-      (void)hipEventSynchronize(t.readers.front().second);
-      ev = t.readers.front().second;
+    { /* a caller cycling through many streams: take the oldest reader's event out of the set, wait it out WITHOUT
+       * the lock (other threads' launches of this scene go on meanwhile; the set cannot be recycled under the
+       * waited-for reader because this launch still counts in `users`), and hand the event to this stream */
+      hipEvent_t old = t.readers.front().second;
       t.readers.erase(t.readers.begin());
-      t.readers.emplace_back(stream, ev);
+      lock.unlock();
+      (void)hipEventSynchronize(old);
+      lock.lock();
+      ev = old;
+      scene->tables[slot].readers.emplace_back(stream, ev);
     }
     else if (!ev)
     {
@@ -419,12 +433,76 @@ void release_tables(const RtHipScene *scene, size_t slot, hipStream_t stream)
       { /* no event to remember this reader by: let it finish before the set can be recycled */
         ev = nullptr;
         (void)hipGetLastError();
+        lock.unlock();
         (void)hipStreamSynchronize(stream);
+        lock.lock();
       }
     }
-    if (ev)
-      (void)hipEventRecord(ev, stream);
-    t.users--;
+  }
+  TableSet &t = scene->tables[slot]; /* (the vector may have grown while the lock was away) */
+  if (ev)
+    (void)hipEventRecord(ev, stream);
+  t.users--;
+}
+
+/* the per-device workspace of the parked-walk kernels (RtHipScene::park_ws) */
+struct ParkPool
+{
+  char *ws = nullptr;
+  int users = 0;
+};
+std::mutex g_park_mutex;
+ParkPool g_park[64];
+
+size_t park_flag_bytes()
+{
+  return ((size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD * sizeof(uint32_t) + 255) & ~(size_t)255;
+}
+
+/* -> the device's workspace (allocated and its flags zeroed at the first call), or nullptr when the allocation fails:
+ * the scene then renders on the lane-waiting kernels, and rt_hip_kernel_name says so.  The current device is `device`. */
+char *park_acquire_ws(int device)
+{
+  if (device < 0 || device >= 64)
+    return nullptr;
+  /* RT_HIP_NO_PARK_WS=1 (tests): behave as if the allocation had failed */
+  const char *no_ws = getenv("RT_HIP_NO_PARK_WS");
+  if (no_ws && no_ws[0] == '1')
+    return nullptr;
+  std::lock_guard<std::mutex> lock(g_park_mutex);
+  ParkPool &p = g_park[device];
+  if (!p.ws)
+  {
+    const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD;
+    char *ws = nullptr;
+    if (hipMalloc(&ws, park_flag_bytes() + n_slots * (PT_BLOCK / 64) * (size_t)PT_PARK_WAVE_BYTES) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    /* the flags must be zero before a kernel on ANY stream looks at them (kernels leave them zero) */
+    if (hipMemset(ws, 0, park_flag_bytes()) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+    {
+      (void)hipFree(ws);
+      return nullptr;
+    }
+    p.ws = ws;
+  }
+  p.users++;
+  return p.ws;
+}
+
+/* a scene that held the device's workspace goes away (its launches have been waited for): the last one frees it */
+void park_drop_ws(int device)
+{
+  if (device < 0 || device >= 64)
+    return;
+  std::lock_guard<std::mutex> lock(g_park_mutex);
+  ParkPool &p = g_park[device];
+  if (p.users > 0 && --p.users == 0)
+  {
+    (void)hipFree(p.ws);
+    p.ws = nullptr;
   }
 }
 
@@ -606,10 +684,10 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     {
       const double *q = meshes[m].vertices[k].pos;
       const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+      /* (a vertex far out, or non-finite, needs no flag of its own: it is part of `reach`, and a launch refuses
+       * near_R = 1.5 (|camera| + reach) + 1 >= 1e15 as "not a usable finite bound" -- so every vertex a kernel ever sees
+       * lies within 6.7e14 of the origin, which is what exact_triangle's UNSCALED division rests on, see below) */
       reach = std::fmax(reach, len);
-      /* a vertex beyond 1e17 (or non-finite): the scene takes the kernels with NaN-safe compares and the general fp64
-       * division in the triangle test (exact_triangle's UNSCALED form assumes |e1||e2| < 1e36) */
-      wide_range |= !(len <= 1e17);
     }
   for (size_t m = 0; m < n_meshes; m++)
   {
@@ -844,7 +922,11 @@ void rt_hip_scene_destroy(RtHipScene *scene)
         (void)hipFree(t.bvh_nodes);
       }
     }
-    (void)hipFree(scene->park_ws);
+    if (scene->park_ws)
+    { /* every launch of this scene must be past its last ring access before the pool can go */
+      (void)hipDeviceSynchronize();
+      park_drop_ws(scene->device);
+    }
     (void)hipFree(scene->blob);
   }
   delete scene;
@@ -879,7 +961,16 @@ int rt_hip_scene_hull_facets(const RtHipScene *scene, uint32_t *n_plus, uint32_t
 
 const char *rt_hip_kernel_name(const RtHipScene *scene, uint32_t integrator)
 {
-  return scene ? pt_kernel_name(scene->view, integrator, kernel_variant()) : "";
+  if (!scene)
+    return "";
+  /* a scene whose parked-walk workspace could not be allocated runs on the lane-waiting kernels (pt_launch_render):
+   * report what is launched, so that an out-of-memory fallback cannot pass as a measurement of the parked-walk kernels */
+  bool no_ws;
+  {
+    std::lock_guard<std::mutex> lock(scene->table_mutex);
+    no_ws = scene->park_tried && scene->park_ws == nullptr;
+  }
+  return pt_kernel_name(scene->view, integrator, kernel_variant(), !no_ws);
 }
 
 size_t rt_hip_chunk_workspace_bytes(uint32_t tile_count)
@@ -926,7 +1017,7 @@ static void mesh_bound_for(const RtHipScene *scene, double near_R, float out[5])
 
 /* BigPrune (pt_kernel.hip, where the bounds are derived): for one near_R, the distance margin delta, the least estimate tmin
  * and per sphere the least q32 of a leading wall-sized sphere that may prune the others.  With e = 2^-24, A = |c| + near_R +
- * tol, W >= r2_hi' - r^2 (40 e A^2 + 16 e | |c|^2 - r^2 |: what pt_build_filter widens by, rounded up), E = 28 e A^2 + 6 e | |c|^2 -
+ * tol, W >= r2_hi' - r^2 (pt_sign_widen_total of pt_device.h, the very function pt_build_filter widens by, x 1.001), E = 28 e A^2 + 6 e | |c|^2 -
  * r^2 |:  qmin = (r / 16)^2 + W + E,  tmin = 2 (tol + 11.2 e A),  delta = 1.5 max (22.4 e A + 8 (W + E) / r).
  * Anything non-finite or implausible switches the pruning off. */
 static void big_prune_for(const RtHipScene *scene, double near_R, double filt_shift, PtLaunch &L)
@@ -951,7 +1042,9 @@ static void big_prune_for(const RtHipScene *scene, double near_R, double filt_sh
   {
     const double r = scene->big_r[k], c = scene->big_c[k], A = c + near_R + filt_shift;
     const double g = std::fabs(c * c - r * r);
-    const double W = (40.0 * e * A * A + 16.0 * e * g) * 1.001, E = 28.0 * e * A * A + 6.0 * e * g;
+    /* W >= r2_hi' - r^2 of the table: pt_build_filter widens by pt_sign_widen_total(A_table, g) with A_table = |c| + near_R <= A
+     * (the function is increasing in A), then rounds kq DOWN to fp32 (at most 2 e |kq| more: inside the factor 1.001) */
+    const double W = pt_sign_widen_total(A, g) * 1.001, E = 28.0 * e * A * A + 6.0 * e * g;
     const double qmin = f * f * r * r + W + E;
     const double bias = (W + E) / (2.0 * f * r);
     if (!(qmin < 1e30) || !(bias < 1e3))
@@ -1046,7 +1139,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     const double *c = camera->position;
     const double cam = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
     L.near_R = 1.5 * (cam + scene->reach) + 1.0;
-    if (!(L.near_R < 1e15))
+    if (!(L.near_R < RT_NEAR_R_LIMIT))
       return fail(RT_HIP_EINVAL, "scene extent %g is not a usable finite bound", L.near_R);
     L.near_R2 = L.near_R * L.near_R;
     L.filt_shift = 12.0 * 5.9604644775390625e-08 * (scene->max_center + L.near_R) * (1.0 + 1e-9);
@@ -1101,35 +1194,20 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   HIP_TRY(scope.status);
   if (scene->view.n_bvh_nodes != 0 && !cast_ray)
   {
-    /* parked-walk workspace: flags (zeroed once; the kernels leave them zero) + rings.  Without it the
-     * kernel still renders, walking in the lanes. */
+    /* parked-walk workspace: the device's shared pool (flags + rings).  Without it pt_launch_render takes the
+     * lane-waiting kernels, and rt_hip_kernel_name reports those. */
     std::lock_guard<std::mutex> lock(scene->table_mutex);
     if (!scene->park_tried)
     {
       scene->park_tried = true;
-      const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD;
-      const size_t flag_bytes = (n_slots * sizeof(uint32_t) + 255) & ~(size_t)255;
-      char *ws = nullptr;
-      /* RT_HIP_NO_PARK_WS=1 (tests): behave as if the allocation had failed */
-      const char *no_ws = getenv("RT_HIP_NO_PARK_WS");
-      if (no_ws && no_ws[0] == '1')
-        ;
-      else if (hipMalloc(&ws, flag_bytes + n_slots * (PT_BLOCK / 64) * (size_t)PT_PARK_WAVE_BYTES) == hipSuccess)
-      {
-        /* the flags must be zero before a kernel on ANY stream looks at them */
-        if (hipMemset(ws, 0, flag_bytes) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess)
-          scene->park_ws = ws;
-        else
-          (void)hipFree(ws);
-      }
-      else
-        (void)hipGetLastError();
+      scene->park_ws = park_acquire_ws(scene->device);
     }
     if (scene->park_ws)
     {
       const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD;
+      (void)n_slots;
       L.park_flags = reinterpret_cast<uint32_t *>(scene->park_ws);
-      L.park_ws = scene->park_ws + ((n_slots * sizeof(uint32_t) + 255) & ~(size_t)255);
+      L.park_ws = scene->park_ws + park_flag_bytes();
       L.park_slots_per_xcd = PT_PARK_SLOTS_PER_XCD;
     }
   }
@@ -1309,8 +1387,7 @@ struct ImageCtx
   };
   int G = 0, W = 0, H = 0;
   bool force_comm = false; /* RT_HIP_FORCE_COMM=1: communicators and the gather's send/recv block even with one device */
-  uint64_t scene_hash = 0;
-  std::vector<unsigned char> scene_bytes; /* what the hash was taken over: compared on a hash match */
+  std::vector<unsigned char> scene_bytes; /* the scene this context was built for (scene_walk's runs): compared run by run */
   std::vector<Dev> dev;
   std::vector<ncclComm_t> comms;
   float *all_tiles = nullptr, *image = nullptr;
@@ -1353,35 +1430,55 @@ void ctx_release(ImageCtx &c)
   c.builds = builds;
 }
 
-/* Everything that defines the scene, serialised (`bytes`), and FNV-1a over it.  The cached context is reused only
- * when the hash AND the bytes match: a collision must not render another scene. */
-uint64_t scene_fingerprint(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes,
-                           std::vector<unsigned char> &bytes)
+/* Everything that defines the scene, field by field (struct padding is not part of the scene), as runs of bytes handed
+ * to `f(ptr, n)` in a fixed order.  The cached context keeps the concatenation (ImageCtx::scene_bytes) and is reused only
+ * while a call's scene equals it byte for byte: scene_matches() compares run by run (memcmp, stopping at the first
+ * difference) against the kept copy -- no per-call serialisation, no hashing: a frame of config 5's mesh used to rebuild
+ * and hash 1.2 MB on the host inside every rt_hip_render_image() call (round-3 advisor finding). */
+template <class F>
+void scene_walk(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes, F &&f)
 {
-  uint64_t h = 1469598103934665603ull;
-  bytes.clear();
-  auto mix = [&](const void *p, size_t n) {
-    const unsigned char *b = static_cast<const unsigned char *>(p);
-    for (size_t i = 0; i < n; i++)
-      h = (h ^ b[i]) * 1099511628211ull;
-    bytes.insert(bytes.end(), b, b + n);
-  };
-  mix(&n_spheres, sizeof n_spheres);
-  mix(&n_meshes, sizeof n_meshes);
+  f(&n_spheres, sizeof n_spheres);
+  f(&n_meshes, sizeof n_meshes);
   for (size_t i = 0; i < n_spheres; i++)
-  { /* field by field: struct padding is not part of the scene */
-    mix(&spheres[i].flags, sizeof spheres[i].flags);
-    mix(&spheres[i].radius, sizeof(double) * 10); /* radius, center, color, emission are contiguous doubles */
+  {
+    f(&spheres[i].flags, sizeof spheres[i].flags);
+    f(&spheres[i].radius, sizeof(double) * 10); /* radius, center, color, emission are contiguous doubles */
   }
   for (size_t m = 0; m < n_meshes; m++)
   {
-    mix(&meshes[m].flags, sizeof meshes[m].flags);
-    mix(meshes[m].color, sizeof(double) * 6); /* color, emission */
-    mix(&meshes[m].num_triangles, sizeof meshes[m].num_triangles);
+    f(&meshes[m].flags, sizeof meshes[m].flags);
+    f(meshes[m].color, sizeof(double) * 6); /* color, emission */
+    f(&meshes[m].num_triangles, sizeof meshes[m].num_triangles);
     if (meshes[m].vertices)
-      mix(meshes[m].vertices, meshes[m].num_triangles * 3 * sizeof(RtHipVertex));
+      f(meshes[m].vertices, meshes[m].num_triangles * 3 * sizeof(RtHipVertex));
   }
-  return h;
+}
+
+bool scene_matches(const std::vector<unsigned char> &kept, const RtHipSphere *spheres, size_t n_spheres,
+                   const RtHipMesh *meshes, size_t n_meshes)
+{
+  size_t at = 0;
+  bool same = true;
+  scene_walk(spheres, n_spheres, meshes, n_meshes, [&](const void *p, size_t n) {
+    if (!same)
+      return;
+    if (n > kept.size() - at || memcmp(kept.data() + at, p, n) != 0)
+      same = false;
+    else
+      at += n;
+  });
+  return same && at == kept.size();
+}
+
+void scene_serialise(std::vector<unsigned char> &bytes, const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes,
+                     size_t n_meshes)
+{
+  bytes.clear();
+  scene_walk(spheres, n_spheres, meshes, n_meshes, [&](const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    bytes.insert(bytes.end(), b, b + n);
+  });
 }
 
 #define CTX_TRY(expr)                                                                               \
@@ -1402,16 +1499,14 @@ uint64_t scene_fingerprint(const RtHipSphere *spheres, size_t n_spheres, const R
 int ctx_prepare(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes, int G, int W, int H,
                 int prev)
 {
-  std::vector<unsigned char> bytes;
-  const uint64_t fp = scene_fingerprint(spheres, n_spheres, meshes, n_meshes, bytes);
   /* RT_HIP_FORCE_COMM=1: build the RCCL communicator(s) and run the gather's grouped send / recv block even with ONE
    * device (the device sends its tile buffers to itself): how a one-GPU box exercises library load, bootstrap,
    * communicator creation / destruction and the send / recv kernels of the N > 1 path */
   const char *fc = getenv("RT_HIP_FORCE_COMM");
   const bool force_comm = fc && fc[0] == '1';
   ImageCtx &c = g_ctx;
-  if (c.G == G && c.W == W && c.H == H && c.force_comm == force_comm && c.scene_hash == fp && (int)c.dev.size() == G &&
-      c.scene_bytes == bytes)
+  if (c.G == G && c.W == W && c.H == H && c.force_comm == force_comm && (int)c.dev.size() == G &&
+      scene_matches(c.scene_bytes, spheres, n_spheres, meshes, n_meshes))
     return RT_HIP_OK;
   ctx_release(c);
   c.builds++;
@@ -1462,8 +1557,7 @@ int ctx_prepare(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *m
   c.W = W;
   c.H = H;
   c.force_comm = force_comm;
-  c.scene_hash = fp;
-  c.scene_bytes.swap(bytes);
+  scene_serialise(c.scene_bytes, spheres, n_spheres, meshes, n_meshes);
   return RT_HIP_OK;
 }
 

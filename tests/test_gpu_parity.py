@@ -754,8 +754,12 @@ def test_bench_host_path_and_config_array(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # RT_HIP_FORCE_COMM=1: the bench's own child builds an RCCL communicator and sends the tile buffers through the grouped
+    # send / recv block (one device, to itself) -- so that bench.py --host-path, not only tests/rccl_child.py, has met a
+    # communicator before the first 8-GPU run
     hp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--host-path", "--gpus", "1", "--config", "2",
-                         "--spp", "4", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, cwd=root)
+                         "--spp", "4", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, cwd=root,
+                        env=dict(os.environ, RT_HIP_FORCE_COMM="1"))
     assert hp.returncode == 0, hp.stderr[-2000:]
     d = json.loads([ln for ln in hp.stdout.splitlines() if ln.startswith("{")][0])["host_path"]
     assert d["n_devices"] == 1 and len(d["call_ms"]) == 2 and d["ray_bounces_per_s"] > 0
@@ -767,6 +771,40 @@ def test_bench_host_path_and_config_array(gpu):
     assert set(got) == {2, 3, 4, 5} or set(got) == {2, 3, 5}
     assert got[3]["kernel"] == "pt_render_tiles_tri" and got[5]["kernel"] == "pt_render_tiles_tri_queued_sph"
     assert all("error" not in c and c["kernel_ms"] > 0 and c["ray_bounces_per_s"] > 0 for c in got.values())
+    # every entry says whether its committed PMC / PT_DIAG figures still describe the kernels (never a stale number)
+    for c in got.values():
+        if c.get("pmc_stale"):
+            assert c["valu_busy"] is None and c["traffic"] is None and c["pmc_stale_reason"]
+        elif "pmc_stale" in c:
+            assert c["pmc_source"] is not None and c["valu_busy"] is not None
+        assert c["frac_executed"] is None or 0 < c["frac_executed"] < 1
+
+
+def test_bench_parity_block_against_the_compiled_reference(gpu):
+    """the same-run parity block of bench.py: the CPU leg's pixels -- the reference's compiled
+    trace_path() -- against the frame the timed steps produced, counters against a re-render of exactly those tiles"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "4", "--width", "480", "--height", "270",
+                          "--spp", "16", "--steps", "2", "--warmup", "1", "--cpu-tiles", "256", "--cpu-workers", "4", "--no-configs"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-1500:])
+    d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    p = d["parity"]
+    assert p["ok"] and p["counters_equal"] and p["timed_frame_equals_rerender"], p
+    assert p["pixels"] == 256 * 64 and p["spp"] == 16 and max(p["rms"]) <= 1e-4 and p["u8_max_diff"] <= 1
+    assert p["rays"]["gpu"] == p["rays"]["cpu"] > 0 and p["ray_bounces"]["gpu"] == p["ray_bounces"]["cpu"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and "error" not in d
+    # a mesh configuration goes through the reference's revived mesh scan (RefMeshOracle)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "3", "--width", "240", "--height", "136",
+                          "--spp", "8", "--steps", "1", "--warmup", "1", "--cpu-tiles", "64", "--cpu-workers", "4", "--no-configs"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-1500:])
+    d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["parity"]["ok"] and "mesh" in d["parity"]["oracle"], d["parity"]
 
 
 def test_mesh_hierarchy_partitions_and_chunks_are_bit_invariant(gpu):

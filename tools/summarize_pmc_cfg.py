@@ -5,6 +5,8 @@ usage: python tools/summarize_pmc_cfg.py r02a 5"""
 import collections, csv, glob, json, os, shutil, sys
 tag, cfg_n = sys.argv[1], int(sys.argv[2])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha256  # ties the record to the kernel sources it was measured on (bench.py: pmc_is_stale)
 D, P = os.path.join(ROOT, "gpurun_out", f"cfg{cfg_n}_{tag}"), os.path.join(ROOT, "profiles")
 bench = json.loads(open(f"{D}/bench.log").read().strip().splitlines()[-1])
 kernel = bench["roofline"]["kernel"]
@@ -48,7 +50,11 @@ lines += [f"{k:24s} " + "  ".join("%.5g (%.2f ms)" % x for x in vv) for k, vv in
 pre = f"{P}/{tag}_c{cfg_n}"
 open(f"{pre}_pmc.txt", "w").write("\n".join(lines) + "\n")
 json.dump({"kernel": kernel, "config": cfg_n, "width": cfg["width"], "height": cfg["height"], "spp": cfg["spp"],
-           "n_gpus": 1, "traffic_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+           "n_gpus": 1, "source_sha256": kernel_source_sha256(), "kernel_ms": bench["roofline"]["kernel_ms"],
+           "kernel_ms_note": "HIP-event kernel time of the un-profiled bench run of the same session (gpurun_out/cfg<C>_<tag>/bench.log); "
+                             "bench.py reports these counters only while the sources hash to source_sha256 and its own kernel "
+                             "time agrees within 3 %",
+           "pmc_pass_kernel_ms": ms, "traffic_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
            "valu_busy": busy, "valu_busy_raw": busy_raw,
            "valu_busy_note": "SQ_ACTIVE_INST_VALU*4/1024/(GRBM_GUI_ACTIVE/8), both from ONE pass; per-wave quad-cycles, so overlapping "
                              "waves on a SIMD can push the raw ratio past 1: valu_busy is capped at 1 = saturated",
