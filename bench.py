@@ -240,20 +240,46 @@ def host_cpus():
 
 # ---- CPU baseline: the compiled reference on a bounded sample -----------------------------
 
+GLASS_DEPTH = 5   # the reference's own compile-time MAX_DEPTH (raytracer.h:25)
+
+
+def make_scene(name, width=None, height=None, spp=None, depth=None):
+    """A benchmark scene by name -- the GPU side and the CPU workers build the same bytes from it.
+      <N>     BASELINE configs[N - 1] (rt_scene_build of the host library)
+      glass   config 4's room with every fifth of its 30 packed spheres turned into white M_REFRACTION 'glass' -- the
+              share the reference's own generator gives that material (main.c:107-115: r > 0.8) --, MAX_DEPTH 5: what
+              trace_path's two-child branch (raytracer.c:514-539) costs; the `integrators` entries of the N = 1 line"""
+    from rt_amd import abi, scene as S
+    if name != "glass":
+        return S.build_scene(int(name), width, height, spp, depth)
+    room = S.build_scene(4, width, height, spp)
+    objs = []
+    for i in range(room.n_objects):
+        o = room.objects[i]
+        d = dict(flags=int(o.flags), radius=float(o.radius), center=o.center.tuple(), color=o.color.tuple(), emission=o.emission.tuple())
+        if i >= 8 and (i - 8) % 5 == 0:
+            d.update(flags=abi.M_REFRACTION, color=(1.0, 1.0, 1.0), emission=(0.0, 0.0, 0.0))
+        objs.append(d)
+    info = S.scene_info(4)
+    sc = S.custom_scene(objs, room.width, room.height, room.samples, GLASS_DEPTH if depth is None else depth,
+                        tuple(info.cam_pos), tuple(info.cam_target))
+    room.free()
+    return sc
+
+
 def _cpu_worker(args):
-    config, width, height, spp, depth, pixels, kind, want_pixels = args
+    name, width, height, spp, depth, pixels, kind, want_pixels, integrator = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
-    from rt_amd import scene as S
-    sc = S.build_scene(config, width, height, spp)
+    sc = make_scene(name, width, height, spp, depth)
     if kind == "reference":
-        # the reference's own compiled trace_path() / intersect(); scenes with meshes through its revived mesh scan
-        # (oracle/ref_harness.c, ORACLE_MESH_HOOK)
+        # the reference's own compiled trace_path() / cast_ray() / intersect(); scenes with meshes through its revived mesh
+        # scan (oracle/ref_harness.c, ORACLE_MESH_HOOK)
         ora = oracle_py.RefMeshOracle(depth) if sc.n_meshes else oracle_py.RefOracle(depth)
-        mean, rgb8, st = ora.render_pixels(sc, SEED, pixels=pixels, want_rgb8=want_pixels)
+        mean, rgb8, st = ora.render_pixels(sc, SEED, pixels=pixels, want_rgb8=want_pixels, integrator=integrator)
         casts = st["tests"] // max(sc.n_primitives, 1)   # its counter is per primitive test: n_primitives per scan
     else:
-        mean, rgb8, st = oracle_py.PtOracle().render_pixels(sc, SEED, pixels=pixels, want_rgb8=want_pixels)
+        mean, rgb8, st = oracle_py.PtOracle().render_pixels(sc, SEED, pixels=pixels, want_rgb8=want_pixels, integrator=integrator)
         casts = st["casts"]
     return casts, st["rays"], (mean, rgb8) if want_pixels else None
 
@@ -287,7 +313,7 @@ def tile_pixel_indices(width, height, first, stride, count):
     return np.array(px, dtype=np.uint32), np.array(slot, dtype=np.int64), np.array(pit, dtype=np.int64)
 
 
-def cpu_reference(config, width, height, spp, depth, n_meshes, budget_tiles, workers, want_pixels=True):
+def cpu_reference(config, width, height, spp, depth, n_meshes, budget_tiles, workers, want_pixels=True, integrator="path"):
     """The CPU checker on `budget_tiles` 8x8 tiles spread evenly over the frame at full spp, one single-threaded
     process per usable core (processes, not threads: the reference's global counters make its threads slower,
     SURVEY T7).  -> (cpu_baseline dict, sample dict): the timing, and -- since round 4 -- the pixels it rendered
@@ -304,10 +330,10 @@ def cpu_reference(config, width, height, spp, depth, n_meshes, budget_tiles, wor
     nproc, usable, quota = host_cpus()
     cores = max(1, min(workers or usable, len(px)))
     chunks = [px[i::cores] for i in range(cores)]  # interleaved: even load
-    jobs = [(config, width, height, spp, depth, ch, kind, want_pixels) for ch in chunks]
+    jobs = [(str(config), width, height, spp, depth, ch, kind, want_pixels, integrator) for ch in chunks]
     ctx = mp.get_context("spawn")
     with ctx.Pool(len(jobs)) as pool:
-        pool.map(_cpu_worker, [(config, width, height, 1, depth, ch[:1], kind, False) for ch in chunks])  # warm
+        pool.map(_cpu_worker, [(str(config), width, height, 1, depth, ch[:1], kind, False, integrator) for ch in chunks])  # warm
         t0 = time.perf_counter()
         res = pool.map(_cpu_worker, jobs)
         dt = time.perf_counter() - t0
@@ -337,7 +363,7 @@ def cpu_reference(config, width, height, spp, depth, n_meshes, budget_tiles, wor
 RMS_BAR = 1e-4   # BASELINE.json north_star: per-channel RMS of the linear float framebuffer against the reference's
 
 
-def parity_numbers(gpu_rgb, gpu_rgb8, gpu_rays, gpu_casts, sample):
+def parity_numbers(gpu_rgb, gpu_rgb8, gpu_rays, gpu_casts, sample, hdr=False):
     """Pure comparison (numpy in, dict out; tests/test_host.py covers it on the CPU): the GPU's linear floats and
     tonemapped bytes of the sample's pixels against the CPU reference's, and the decision-exactness counters."""
     import numpy as np
@@ -357,11 +383,17 @@ def parity_numbers(gpu_rgb, gpu_rgb8, gpu_rays, gpu_casts, sample):
            "oracle": sample["oracle"], "cpu_seconds": float(sample["seconds"]),
            "bar": f"per-channel RMS <= {RMS_BAR:g} (linear float framebuffer), tonemapped bytes within 1 LSB, rays and "
                   "ray-bounces of the pixel subset equal"}
-    out["ok"] = bool(finite and (rms <= RMS_BAR).all() and out["u8_max_diff"] <= 1 and counters_equal)
+    # hdr (the glass scene only: the reference's "fresnel" weight reaches 7.3 per M_REFRACTION hit from inside a sphere, so
+    # pixel values are not bounded by the emitters'): the float32 framebuffer holds 6e-8 RELATIVE, the bar scales with the
+    # largest value compared -- the same rule as the tests' assert_parity(hdr=True)
+    bar = RMS_BAR * (max(1.0, float(np.abs(m).max())) if (hdr and len(m)) else 1.0)
+    if hdr:
+        out["bar"] += f"; HDR scene: RMS bar scaled by the largest value compared -> {bar:.3g}"
+    out["ok"] = bool(finite and (rms <= bar).all() and out["u8_max_diff"] <= 1 and counters_equal)
     return out
 
 
-def gpu_parity(gs, sc, dev, sample, frame, frame8, chunks=1, workspace=None):
+def gpu_parity(gs, sc, dev, sample, frame, frame8, integrator="path", hdr=False):
     """The same-run parity block: `frame` / `frame8` are the row-major images the TIMED steps produced (device tensors);
     their pixels of the sample's tiles are compared with the CPU reference's, and the subset is rendered once more on
     the GPU (render_tiles with tile_first / tile_stride: outside the timed region) for its own ray / ray-bounce
@@ -373,7 +405,7 @@ def gpu_parity(gs, sc, dev, sample, frame, frame8, chunks=1, workspace=None):
     px, slot, pit = tile_pixel_indices(sc.width, sc.height, first, stride, count)
     assert (px == sample["px"]).all()
     st = torch.zeros(abi.NSTATS, dtype=torch.int64, device=dev)
-    t, t8, _ = gs.render_tiles(SEED, first, stride, count, stats=st)
+    t, t8, _ = gs.render_tiles(SEED, first, stride, count, stats=st, integrator=integrator)
     torch.cuda.synchronize(dev)
     st = st.cpu().tolist()
     sub = t.cpu().numpy()[slot, pit]
@@ -381,7 +413,7 @@ def gpu_parity(gs, sc, dev, sample, frame, frame8, chunks=1, workspace=None):
     idx = torch.from_numpy(px.astype(np.int64)).to(dev)
     fr = frame.reshape(-1, 3)[idx].cpu().numpy()
     fr8 = frame8.reshape(-1, 3)[idx].cpu().numpy()
-    out = parity_numbers(fr, fr8, st[abi.STAT_RAYS], st[abi.STAT_CASTS], sample)
+    out = parity_numbers(fr, fr8, st[abi.STAT_RAYS], st[abi.STAT_CASTS], sample, hdr=hdr)
     out["timed_frame_equals_rerender"] = bool((fr.view(np.uint32) == sub.view(np.uint32)).all() and (fr8 == sub8).all())
     out["ok"] = bool(out["ok"] and out["timed_frame_equals_rerender"])
     out["compared"] = ("the frame the timed steps produced, at the sample's pixels, against the CPU reference's means; "
@@ -431,6 +463,67 @@ def cpu_as_shipped():
 
 # ---- the other configurations, one GPU -----------------------------------------------------
 
+def isa_keys(kernel, source_sha=None):
+    """VGPRs / SGPRs / scratch bytes / LDS of a kernel from the committed ISA statistics (profiles/isa_stats.json, written by
+    tools/isa_stats.sh on the cross-compiler: no GPU needed) -- only while they describe today's sources"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "isa_stats.json")))
+    except Exception:
+        return None
+    want = source_sha if source_sha is not None else kernel_source_sha256()
+    if rec.get("source_sha256") != want:
+        return {"isa_stale": True}
+    k = rec["kernels"].get(kernel)
+    return dict(k, source="profiles/isa_stats.json (tools/isa_stats.sh)") if k else None
+
+
+def integrator_line(kind, dev, parity_tiles=0, cpu_workers=0):
+    """The two other code paths of render() that the reference ships next to the headline's, on this GPU,
+    1920x1080:  'glass' -- trace_path with M_REFRACTION's two children per hit (raytracer.c:514-539), make_scene('glass'),
+    64 spp;  'cast_ray' -- the Whitted integrator on the other side of render()'s `#if 1` (raytracer.c:207-211, :556-641) on
+    config 4's room, 16 spp.  Kernel time by HIP events over 3 frames, the kernel's registers / scratch from the committed
+    ISA statistics, and the same-run parity block against the reference's compiled code."""
+    import torch
+    from rt_amd import abi, gpu as G
+    name, spp, integrator = ("glass", 64, "path") if kind == "glass" else ("4", 16, "whitted")
+    sc = make_scene(name, None, None, spp)
+    gs = G.GpuScene(sc, device=dev.index)
+    total = G.n_tiles(sc.width, sc.height)
+    tiles = torch.empty((total, abi.TILE_PIXELS, 3), dtype=torch.float32, device=dev)
+    tiles8 = torch.empty((total, abi.TILE_PIXELS, 3), dtype=torch.uint8, device=dev)
+    stats = torch.zeros(abi.NSTATS, dtype=torch.int64, device=dev)
+    gs.render_tiles(SEED, 0, 1, total, tiles, tiles8, stats, integrator=integrator)
+    torch.cuda.synchronize(dev)
+    stats.zero_()
+    steps = 3
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        gs.render_tiles(SEED, 0, 1, total, tiles, tiles8, stats, integrator=integrator)
+        b.record()
+    torch.cuda.synchronize(dev)
+    ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    rays, casts, tests, samples = [int(v) / steps for v in stats.cpu().tolist()]
+    kernel = gs.kernel_name(integrator)
+    line = {"integrator": "trace_path, M_REFRACTION scene (raytracer.c:514-539)" if kind == "glass" else "cast_ray (raytracer.c:556-641)",
+            "workload": f"{'config 4 room, every fifth packed sphere M_REFRACTION' if kind == 'glass' else 'BASELINE configs[3] scene'}: "
+                        f"{sc.width}x{sc.height}, {sc.samples} spp, {sc.n_objects} spheres, depth {sc.max_depth}",
+            "kernel": kernel, "kernel_ms": ms, "steps": steps,
+            "ray_bounces_per_s": casts / (ms * 1e-3), "scene_scans_note": "ray-bounces = scene scans (cast_ray: primary + shadow rays)",
+            "mpixel_samples_per_s": samples / (ms * 1e-3) * 1e-6, "rays_per_sample": rays / max(samples, 1),
+            "isa": isa_keys(kernel)}
+    if parity_tiles:
+        try:
+            image, image8 = gs.untile(tiles, tiles8, 0, 1, total)
+            _, sample = cpu_reference(name, sc.width, sc.height, sc.samples, sc.max_depth, sc.n_meshes, parity_tiles, cpu_workers,
+                                      integrator=integrator)
+            line["parity"] = gpu_parity(gs, sc, dev, sample, image, image8, integrator=integrator, hdr=(kind == "glass"))
+        except Exception as exc:
+            line["parity"] = {"ok": False, "error": repr(exc)}
+    gs.close()
+    return line
+
+
 # 8x8 tiles of the per-configuration parity samples, at the configuration's own size and spp: a budget (spread evenly over
 # the frame) or an explicit (tile_first, tile_stride, tile_count).  Config 5 is 4096 spp x 10,248 primitives per scan on the
 # CPU -- ~8 s of 16 cores per tile --, so two tiles: the centre of the frame (on the mesh) and one on the floor
@@ -466,7 +559,7 @@ def config_line(cfg, spp, steps, dev, parity_tiles=0, cpu_workers=0):  # parity_
                                        f"{sc.n_objects} spheres + {sc.n_triangles} triangles, depth {sc.max_depth}",
             "kernel": gs.kernel_name(), "kernel_ms": ms, "steps": steps, "ray_bounces_per_s": casts / (ms * 1e-3),
             "mpixel_samples_per_s": samples / (ms * 1e-3) * 1e-6, "rays_per_sample": rays / max(samples, 1),
-            "flops_per_ray_bounce": fr, "frac": casts * fr / (ms * 1e-3) * 1e-12 / PEAK_FP64_TFLOPS}
+            "flops_per_ray_bounce": fr, "frac": casts * fr / (ms * 1e-3) * 1e-12 / PEAK_FP64_TFLOPS, "isa": isa_keys(gs.kernel_name())}
     line.update(pmc_keys(committed_pmc(cfg, sc.width, sc.height, sc.samples, 1, any_spp=True), sc.samples, ms))
     line.update(executed_work(committed_diag(cfg), casts, ms * 1e-3, sc.n_objects, sc.n_triangles))
     if parity_tiles:
@@ -761,7 +854,7 @@ def main():
             "intersection_tests_per_s": tests / elapsed,
             "roofline": {"bound": "valu_fp64", "kernel": gs.kernel_name(), "achieved": achieved_tflops,
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_TFLOPS,
-                         "flops": FLOPS_NOTE, "flops_per_ray_bounce": fr, "kernel_ms": kern_s * 1e3,
+                         "flops": FLOPS_NOTE, "flops_per_ray_bounce": fr, "kernel_ms": kern_s * 1e3, "isa": isa_keys(gs.kernel_name()),
                          "traffic": pmc["traffic_bytes_per_launch"] if pmc else None, "traffic_source": pmc_source,
                          "valu_busy": min(pmc["valu_busy"], 1.0) if pmc and pmc.get("valu_busy") is not None else None,
                          "valu_busy_raw": pmc.get("valu_busy_raw", pmc.get("valu_busy")) if pmc else None,
@@ -806,6 +899,14 @@ def main():
                 except Exception as exc:
                     lines.append({"config": cfg, "error": repr(exc)})
             out["configs"] = lines
+            ints = []
+            for kind in ("glass", "cast_ray"):
+                try:
+                    ints.append(integrator_line(kind, dev, parity_tiles=0 if args.no_parity or args.cpu_tiles <= 0 else 1024,
+                                                cpu_workers=args.cpu_workers))
+                except Exception as exc:
+                    ints.append({"integrator": kind, "error": repr(exc)})
+            out["integrators"] = ints
         if world == 1 and args.cpu_tiles > 0:
             sample = None
             try:
@@ -828,6 +929,8 @@ def main():
         if world == 1:
             bad = [("headline", out["parity"])] if "parity" in out and not out["parity"].get("ok") else []
             bad += [(f"config {ln.get('config')}", ln["parity"]) for ln in out.get("configs", [])
+                    if isinstance(ln.get("parity"), dict) and not ln["parity"].get("ok")]
+            bad += [(ln.get("integrator"), ln["parity"]) for ln in out.get("integrators", [])
                     if isinstance(ln.get("parity"), dict) and not ln["parity"].get("ok")]
             if bad:
                 out["error"] = "parity check failed: " + "; ".join(f"{w}: {json.dumps(p_)[:300]}" for w, p_ in bad)

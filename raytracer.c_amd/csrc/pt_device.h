@@ -89,7 +89,10 @@
 #define PT_HULL_MAX_TRIS 65536u /* pt_build_hull_flags is quadratic: larger triangle sets go without the flags */
 #define PT_ACC_WS_WORDS (PT_TILE_PIXELS * 3 + 3) /* chunked renders: u64 per tile in the workspace: 192 sums + 3 NaN masks */
 
-#define PT_REFRACT_MAX_DEPTH 32 /* the pending-ray stack of the two-child kernels holds max_depth + 2 */
+#define PT_REFRACT_MAX_DEPTH 32 /* the pending-ray stacks of the two-child kernels hold max_depth + 2 entries (a pool in global memory
+                                 * sized by the launch: 20 KB per entry and resident workgroup) */
+#define PT_PEND_FIELDS_HOST 10u /* doubles per pending ray: o, d, T, depth (pt_kernel.hip: PT_PEND_FIELDS) */
+#define PT_PEND_SLOTS_PER_XCD 128u /* 32 CUs x at most 3-4 resident workgroups of the static-body kernels, with slack */
 
 #define PT_FLAG_DIFFUSE 2u
 #define PT_FLAG_MIRROR 4u
@@ -130,9 +133,33 @@ struct PtSceneView
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
+#ifndef PT_GEOM_LDS_BYTES
+#define PT_GEOM_LDS_BYTES (24u * 1024u) /* the LDS staging budget of sphere geometry + materials */
+#endif
 static inline bool pt_geom_in_lds(const PtSceneView &sc)
-{ /* sphere geometry + materials within the 24 KiB staging budget (6 workgroups per CU) */
-  return (PT_GEOM_STRIDE * (uint64_t)sc.n_spheres + PT_MAT_STRIDE * ((uint64_t)sc.n_spheres + sc.n_meshes)) * 8u <= 24u * 1024u;
+{ /* sphere geometry + materials within the staging budget */
+  return (PT_GEOM_STRIDE * (uint64_t)sc.n_spheres + PT_MAT_STRIDE * ((uint64_t)sc.n_spheres + sc.n_meshes)) * 8u <= PT_GEOM_LDS_BYTES;
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+/* Sphere-only scenes of more than ~85 spheres are better off NOT staged although they would fit: a workgroup's life is
+ * short (64 pixels x spp), staging copies 120 bytes per sphere into LDS for each of the frame's tens of thousands of
+ * workgroups, and the staged bytes cost resident workgroups (256 spheres: 3 per CU instead of 5).  The pooled body that reads
+ * geometry and materials from memory and the filter table through scalar loads (pt_render_tiles_pool_mem_s) measured, per
+ * sphere test at 1920x1080 x 64 spp in rooms packed as main.c:65-138 would (profiles/r04_staging_sweep.txt): 10 spheres
+ * 1.88 ps against 1.84 staged, 38: 0.660 / 0.634, 64: 0.455 / 0.463, 128: 0.327 / 0.375, 192: 0.284 / 0.327, 256: 0.267 / 0.389.
+ * (The pooled sphere kernels only: scenes with triangles, M_REFRACTION or cast_ray keep the staging budget.) */
+#ifndef PT_STREAM_ABOVE_BYTES
+#define PT_STREAM_ABOVE_BYTES (8u * 1024u)
+#endif
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline bool pt_prefer_streaming(const PtSceneView &sc)
+{
+  return sc.n_triangles == 0u && !sc.any_refract && !sc.wide_range &&
+         (PT_GEOM_STRIDE * (uint64_t)sc.n_spheres + PT_MAT_STRIDE * ((uint64_t)sc.n_spheres + sc.n_meshes)) * 8u > PT_STREAM_ABOVE_BYTES;
 }
 #if defined(__HIPCC__)
 __host__ __device__
@@ -224,6 +251,13 @@ struct PtLaunch
   char *park_ws;
   uint32_t *park_flags;
   uint32_t park_slots_per_xcd;
+  /* kernels with two-child materials (M_REFRACTION under trace_path; M_REFLECTION | M_REFRACTION under cast_ray): the pool of
+   * pending-ray stacks (pt_kernel.hip, PendStack): PT_PARK_XCDS x pend_slots_per_xcd slots of pend_slot_doubles doubles
+   * (= pend_entries x 10 fields x PT_BLOCK lanes) and one in-use flag per slot */
+  double *pend_ws;
+  uint32_t *pend_flags;
+  uint32_t pend_slots_per_xcd, pend_entries;
+  uint64_t pend_slot_doubles;
   unsigned long long *acc_ws;        /* sample_chunks > 1: tile_count x 192 fixed-point sums, then tile_count x 3 NaN masks */
   float *tiles_rgb;
   uint8_t *tiles_rgb8;
@@ -239,6 +273,7 @@ hipError_t pt_launch_build_hull_flags(const double *tri_geom, const double *tri_
                                       uint32_t *tri_object, hipStream_t stream);
 hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream);
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws = true);
+bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant); /* a kernel with a pending-ray stack */
 hipError_t pt_launch_selftest_xcc(unsigned int *counts, uint32_t n_workgroups, hipStream_t stream);
 hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream);
 hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,

@@ -124,6 +124,79 @@ __device__ __forceinline__ uint8_t tonemap(double x)
   return (uint8_t)(255.0 * cl);
 }
 
+/* ---- math of the material code without library calls inside the trip loops -------------------------------------
+ * The device library's atan2 / pow / fmod are long polynomial sequences whose dozen-odd fp64 constants the compiler
+ * hoists out of the sample loop into registers -- and, in kernels at their register limit, spills from there: the
+ * static-body kernels' scratch traffic at three waves per SIMD was exactly the thirteen coefficients of atan2, stored
+ * once and re-loaded at every checker hit (round 4, read off the ISA).  None of the three decides anything -- they
+ * shape VALUES (a texture coordinate, a fresnel weight, a specular term) -- and the device library does not round like
+ * glibc anyway ("where exactness ends"), so:
+ *   cube(x), pow10(x)   products instead of pow(x, 3.0) / pow(x, 10.0): within 1.5 / 4 ulp of the exact power;
+ *   frac1(x)            x - trunc(x), with x's sign = fmod(x, 1.0) EXACTLY (the difference of a double and its integer part
+ *                       is representable; inf -> NaN, NaN -> NaN, as fmod has it);
+ *   atan2_tab(y, x)     fdlibm's atan2 / atan (Sun Microsystems' freely distributable algorithm, e_atan2.c / s_atan.c:
+ *                       argument reduction at 7/16, 11/16, 19/16, 39/16, an odd polynomial of degree 23 in two
+ *                       interleaved Horner chains; error below one ulp of the result) with its twenty coefficients read
+ *                       from a table in LDS through an index the compiler cannot see through, so that they stay where
+ *                       they are used.  Against glibc's atan2 on 2.4e7 unit normals and random arguments (numpy, the same
+ *                       unfused operations): 84 % equal, 16 % one ulp off, 2.5e-7 two ulps at a binade boundary -- the
+ *                       same class as the device library's own; rt_hip_selftest_math op 6 compares it on the device. */
+__device__ __forceinline__ double cube(double x) { return x * x * x; }
+__device__ __forceinline__ double pow10(double x)
+{
+  const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+  return x8 * x2;
+}
+__device__ __forceinline__ double frac1(double x) { return __builtin_copysign(x - trunc(x), x); } /* (a zero result takes x's sign, as fmod's) */
+
+#define PT_ATAN_TAB 22 /* doubles: aT[0..10], atanhi[0..3], atanlo[0..3], pi, pi_lo, 1 / (2 PI) is NOT here: the reference divides */
+__constant__ double kAtanTab[PT_ATAN_TAB] = {
+    3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
+    9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
+    4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02,
+    4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00,
+    2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17,
+    3.1415926535897931160e+00, 1.2246467991473531772e-16, 0.0};
+/* once per workgroup, before a barrier */
+__device__ __forceinline__ void atan_table_to_lds(double *tab)
+{
+  if (threadIdx.x < PT_ATAN_TAB)
+    tab[threadIdx.x] = kAtanTab[threadIdx.x];
+}
+__device__ __forceinline__ double atan2_tab(double y, double x, const double *tab)
+{
+  uint32_t z0 = 0;
+  asm volatile("" : "+v"(z0)); /* (opaque_zero, defined further down) */
+  const double ay = fabs(y), ax = fabs(x);
+  /* atan(|y| / |x|); 0 / 0 counts as 0 (atan2(+-0, +-0) = +-0 or +-pi), |x| = 0 gives inf -> pi / 2 through the last interval */
+  double q = ay / ax;
+  if (ay == 0.0)
+    q = 0.0;
+  /* s_atan.c's argument reduction, one division for all five intervals; NaN falls through to the last and stays NaN */
+  int id = 3;
+  double num = -1.0, den = q;
+  if (q < 2.4375) { id = 2; num = q - 1.5; den = 1.0 + 1.5 * q; }
+  if (q < 1.1875) { id = 1; num = q - 1.0; den = q + 1.0; }
+  if (q < 0.6875) { id = 0; num = 2.0 * q - 1.0; den = 2.0 + q; }
+  if (q < 0.4375) { id = -1; num = q; den = 1.0; }
+  const double xr = num / den;
+  const double z = xr * xr, w = z * z;
+  const double s1 = z * (tab[z0 + 0] + w * (tab[z0 + 2] + w * (tab[z0 + 4] + w * (tab[z0 + 6] + w * (tab[z0 + 8] + w * tab[z0 + 10])))));
+  const double s2 = w * (tab[z0 + 1] + w * (tab[z0 + 3] + w * (tab[z0 + 5] + w * (tab[z0 + 7] + w * tab[z0 + 9]))));
+  const uint32_t k = (uint32_t)(id < 0 ? 0 : id);
+  const double hi = tab[z0 + 11 + k], lo = tab[z0 + 15 + k];
+  const double t = xr * (s1 + s2);
+  const double r = id < 0 ? xr - t : hi - ((t - lo) - xr);
+  /* e_atan2.c's quadrants: the sign bit of x counts -- also of -0 when y is a zero too (atan2(+-0, -0) = +-pi) --, but
+   * x = +-0 with y != 0 is +-pi / 2 whatever the zero's sign */
+  const bool x_neg = __double2hiint(x) < 0 && (ax != 0.0 || ay == 0.0);
+  const bool y_neg = __double2hiint(y) < 0;
+  const double pi = tab[z0 + 19], pi_lo = tab[z0 + 20];
+  const double left = y_neg ? (r - pi_lo) - pi : pi - (r - pi_lo);
+  const double right = y_neg ? -r : r;
+  return x_neg ? left : right;
+}
+
 /* PT_DIAG builds (make shim-diag, tools/diag.py) count wave-level events into stats[4..];
  * the shipped build compiles every DIAG(...) away. */
 #ifdef PT_DIAG
@@ -636,25 +709,49 @@ __device__ __forceinline__ f32x2 lo_half(float x)
   r.x = x; /* (the high half stays undefined on purpose: nothing initialises it, nothing keeps it alive) */
   return r;
 }
-/* a * b.lo + c.lo, a * b.lo + c, a + b.lo -- per half of a */
+/* a * b.lo + c.lo, a * b.lo + c, a + b.lo -- per half of a.  S0: `a` arrives in a scalar register pair (a table entry read from
+ * memory through scalar loads, ConstPair below) and is used from there: one constant-bus operand per instruction is allowed */
+template <bool S0 = false>
 __device__ __forceinline__ f32x2 pk_fma_lo_lo(f32x2 a, f32x2 b, f32x2 c)
 {
   f32x2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  if (S0)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "s"(a), "v"(b), "v"(c));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+template <bool S0 = false>
 __device__ __forceinline__ f32x2 pk_fma_lo(f32x2 a, f32x2 b, f32x2 c)
 {
   f32x2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  if (S0)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "s"(a), "v"(b), "v"(c));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+template <bool S0 = false>
 __device__ __forceinline__ f32x2 pk_add_lo(f32x2 a, f32x2 b)
 {
   f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  if (S0)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(a), "v"(b));
+  else
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+
+/* The filter table where it is read from MEMORY (every kernel whose table is not staged in LDS): through the constant address
+ * space, so that the wave-uniform reads become SCALAR loads (s_load: the scalar cache, values in SGPRs, no vector-memory
+ * instruction).  As plain global loads the compiler could not prove the table unwritten and issued a vector load of one and the
+ * same address for all 64 lanes, three per pair of spheres -- which made these kernels texture-unit bound: a CU's four SIMDs can
+ * filter a pair every ~11 cycles, its one address unit took ~32 for those loads (round 4, tools/many_spheres.py: the scalar-table
+ * kernels cost 2.0x the LDS-table kernel per sphere test).  The table is written by pt_build_filter in an earlier launch and is
+ * immutable while a render reads it (rt_hip_shim.hip, TableSet): constant for the kernel's lifetime, which is what the
+ * address space asserts. */
+typedef const f32x2 __attribute__((address_space(4))) *ConstPair;
+__device__ __forceinline__ ConstPair const_pairs(const f32x2 *p) { return reinterpret_cast<ConstPair>(reinterpret_cast<uintptr_t>(p)); }
 
 /* the ray as phase 1 of scan_filtered sees it: fp32 (round to nearest: relative error <= 2^-24,
  * part of the bound), origin pulled back by filt_shift along d in the sign-test form */
@@ -733,12 +830,15 @@ struct BigPrune
   uint32_t n_pairs; /* 0: off (wave-uniform) */
 };
 
-template <bool TRIS, bool FILT_LDS>
+/* TABLE_MEM: the FILT_LDS form of the filter with its table in memory (pt_render_tiles_pool_mem_s); the other form's table
+ * always is */
+template <bool TRIS, bool FILT_LDS, bool TABLE_MEM = false>
 __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uint32_t base, uint32_t chunk, const FiltRay &fr,
                                              uint32_t &cand_lo, uint32_t &cand_hi, BigPrune big = BigPrune{nullptr, 0u},
                                              uint32_t *pruned_out = nullptr)
 {
   constexpr bool SHIFT = FILT_LDS && !TRIS;
+  constexpr bool MEM = TABLE_MEM || !FILT_LDS;
   const float ox = fr.ox, oy = fr.oy, oz = fr.oz;
   const f32x2 dx = fr.dx, dy = fr.dy, dz = fr.dz;
   const bool far_origin = fr.far_origin;
@@ -753,7 +853,15 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
     f32x2 cx, cy, cz, r2_hi, neg_tol; /* sign-test form: r2_hi holds kq = |c|^2 - r2_hi instead, neg_tol is not read */
   };
   auto load_pair = [&](uint32_t pair) -> PairRec {
-    const f32x2 *g = filt + PT_FILT_STRIDE * (size_t)((base >> 1) + pair);
+    const size_t at = PT_FILT_STRIDE * (size_t)((base >> 1) + pair);
+    if (MEM)
+    {
+      const ConstPair g = const_pairs(filt) + at;
+      if (SHIFT)
+        return {g[0], g[1], g[2], g[5], g[5]};
+      return {g[0], g[1], g[2], g[3], g[4]};
+    }
+    const f32x2 *g = filt + at;
     if (SHIFT)
       return {g[0], g[1], g[2], g[5], g[5]};
     return {g[0], g[1], g[2], g[3], g[4]};
@@ -764,8 +872,8 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
       /* the products expanded: tca' = c.d - o'.d and |c - o'|^2 - r2_hi = (|c|^2 - r2_hi) + |o'|^2 - 2 c.o', so the
        * per-sphere work is two 3-term chains on c alone (8 packed ops per pair instead of 10; |c|^2 - r2_hi comes
        * exact-then-rounded from the table, which also spares the walls' |L|^2 ~ 1e8 its fp32 rounding) */
-      const f32x2 tca = pk_fma_lo(g.cz, dzl, pk_fma_lo(g.cy, dyl, pk_fma_lo_lo(g.cx, dxl, neg_odl)));
-      const f32x2 ll = pk_fma_lo(g.cz, m2ozl, pk_fma_lo(g.cy, m2oyl, pk_fma_lo(g.cx, m2oxl, pk_add_lo(g.r2_hi, ool))));
+      const f32x2 tca = pk_fma_lo<MEM>(g.cz, dzl, pk_fma_lo<MEM>(g.cy, dyl, pk_fma_lo_lo<MEM>(g.cx, dxl, neg_odl)));
+      const f32x2 ll = pk_fma_lo<MEM>(g.cz, m2ozl, pk_fma_lo<MEM>(g.cy, m2oyl, pk_fma_lo<MEM>(g.cx, m2oxl, pk_add_lo<MEM>(g.r2_hi, ool))));
       /* ONE sign decides: q'' = tca |tca| - ll.  Where tca32 >= 0 it is q = tca^2 - ll, the reject "d2 > r2_hi" as
        * before.  Where tca32 < 0 the reference rejects the sphere whatever q says (the pulled-back origin makes
        * tca32' > 0 for every tca >= 0, scan_filtered), so any sign is right there: -tca^2 - ll is negative for an
@@ -837,8 +945,8 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
         if ((uint32_t)p < nb) /* wave-uniform */
         {
           const PairRec g = load_pair((uint32_t)p);
-          const f32x2 tca = pk_fma_lo(g.cz, dzl, pk_fma_lo(g.cy, dyl, pk_fma_lo_lo(g.cx, dxl, neg_odl)));
-          const f32x2 ll = pk_fma_lo(g.cz, m2ozl, pk_fma_lo(g.cy, m2oyl, pk_fma_lo(g.cx, m2oxl, pk_add_lo(g.r2_hi, ool))));
+          const f32x2 tca = pk_fma_lo<MEM>(g.cz, dzl, pk_fma_lo<MEM>(g.cy, dyl, pk_fma_lo_lo<MEM>(g.cx, dxl, neg_odl)));
+          const f32x2 ll = pk_fma_lo<MEM>(g.cz, m2ozl, pk_fma_lo<MEM>(g.cy, m2oyl, pk_fma_lo<MEM>(g.cx, m2oxl, pk_add_lo<MEM>(g.r2_hi, ool))));
           const float qx = __builtin_fmaf(tca.x, __builtin_fabsf(tca.x), -ll.x), qy = __builtin_fmaf(tca.y, __builtin_fabsf(tca.y), -ll.y);
           cand_lo = __builtin_amdgcn_alignbit(cand_lo, __float_as_uint(qy), 31);
           cand_lo = __builtin_amdgcn_alignbit(cand_lo, __float_as_uint(qx), 31);
@@ -902,7 +1010,7 @@ __device__ __forceinline__ void filter_chunk(const f32x2 *__restrict__ filt, uin
  * camera ray of the tile can reach at all, tile_cull below) go through the packed-fp32 test; every other primitive
  * of the chunk is dropped for all lanes.  Same arithmetic and thresholds as filter_chunk, so a listed primitive gets
  * the keep bit it would get there; keep bits are placed by position instead of shifted in, because pairs are skipped. */
-template <bool SHIFT>
+template <bool SHIFT, bool MEM = false>
 __device__ __forceinline__ void filter_chunk_listed(const f32x2 *__restrict__ filt, uint32_t base, uint32_t chunk, uint32_t pair_mask,
                                                     const FiltRay &fr, uint32_t &cand_lo, uint32_t &cand_hi)
 {
@@ -915,13 +1023,23 @@ __device__ __forceinline__ void filter_chunk_listed(const f32x2 *__restrict__ fi
   {
     const uint32_t p = (uint32_t)__builtin_ctz(pm);
     pm &= pm - 1u;
-    const f32x2 *g = filt + PT_FILT_STRIDE * (size_t)((base >> 1) + p);
+    const size_t at = PT_FILT_STRIDE * (size_t)((base >> 1) + p);
+    const f32x2 *g = filt + at;
     uint32_t two;
     if (SHIFT)
     {
-      const f32x2 cx = g[0], cy = g[1], cz = g[2], kq = g[5];
-      const f32x2 tca = pk_fma_lo(cz, dzl, pk_fma_lo(cy, dyl, pk_fma_lo_lo(cx, dxl, neg_odl)));
-      const f32x2 ll = pk_fma_lo(cz, m2ozl, pk_fma_lo(cy, m2oyl, pk_fma_lo(cx, m2oxl, pk_add_lo(kq, ool))));
+      f32x2 cx, cy, cz, kq;
+      if (MEM)
+      { /* (p comes from the wave-uniform mask: a scalar, so these are scalar loads) */
+        const ConstPair gc = const_pairs(filt) + at;
+        cx = gc[0]; cy = gc[1]; cz = gc[2]; kq = gc[5];
+      }
+      else
+      {
+        cx = g[0]; cy = g[1]; cz = g[2]; kq = g[5];
+      }
+      const f32x2 tca = pk_fma_lo<MEM>(cz, dzl, pk_fma_lo<MEM>(cy, dyl, pk_fma_lo_lo<MEM>(cx, dxl, neg_odl)));
+      const f32x2 ll = pk_fma_lo<MEM>(cz, m2ozl, pk_fma_lo<MEM>(cy, m2oyl, pk_fma_lo<MEM>(cx, m2oxl, pk_add_lo<MEM>(kq, ool))));
       /* a set sign bit of q'' = tca |tca| - ll means DROP (filter_chunk) */
       const float qx = __builtin_fmaf(tca.x, __builtin_fabsf(tca.x), -ll.x), qy = __builtin_fmaf(tca.y, __builtin_fabsf(tca.y), -ll.y);
       const uint32_t d0 = __float_as_uint(qx) >> 31, d1 = __float_as_uint(qy) >> 31;
@@ -999,24 +1117,29 @@ __device__ __forceinline__ void tile_cull(const double *cam_lds, const double *e
                                           uint32_t tx0, uint32_t ty0, uint32_t *pairs)
 {
   auto root = [](double x) { return x > 0.0 ? x * __builtin_amdgcn_rsq(x) : 0.0; };
-  const uint32_t i = threadIdx.x;
-  bool keep = false;
-  if (i < n_entries)
+  /* thread = entry, PT_BLOCK entries per pass (one pass for the small scenes whose table is in LDS; scenes of thousands of
+   * spheres -- pt_render_tiles_pool_mem_s -- take several): wave w of pass p writes the word of chunk 4 p + w */
+  for (uint32_t base = 0; base < n_entries; base += PT_BLOCK)
   {
-    const double *e = entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz R2 |c| Rb */
-    const double R = (i < n_sph ? root(e[3]) : e[5]) * (1.0 + 1e-5) + 1e-300;
-    keep = tile_cone_reaches_ball(cam_lds, tx0, ty0, ld3(e), R);
+    const uint32_t i = base + threadIdx.x;
+    bool keep = false;
+    if (i < n_entries)
+    {
+      const double *e = entry_src + PT_ENTRY_SRC_STRIDE * (size_t)i; /* cx cy cz R2 |c| Rb */
+      const double R = (i < n_sph ? root(e[3]) : e[5]) * (1.0 + 1e-5) + 1e-300;
+      keep = tile_cone_reaches_ball(cam_lds, tx0, ty0, ld3(e), R);
+    }
+    unsigned long long m = __ballot(keep);
+    /* entry mask -> pair mask: OR neighbouring bits, then gather the even positions */
+    m = (m | (m >> 1)) & 0x5555555555555555ull;
+    m = (m | (m >> 1)) & 0x3333333333333333ull;
+    m = (m | (m >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    m = (m | (m >> 4)) & 0x00FF00FF00FF00FFull;
+    m = (m | (m >> 8)) & 0x0000FFFF0000FFFFull;
+    m = (m | (m >> 16)) & 0x00000000FFFFFFFFull;
+    if ((threadIdx.x & 63u) == 0u && base + (threadIdx.x & ~63u) < n_entries)
+      pairs[(base >> 6) + (threadIdx.x >> 6)] = (uint32_t)m;
   }
-  unsigned long long m = __ballot(keep);
-  /* entry mask -> pair mask: OR neighbouring bits, then gather the even positions */
-  m = (m | (m >> 1)) & 0x5555555555555555ull;
-  m = (m | (m >> 1)) & 0x3333333333333333ull;
-  m = (m | (m >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-  m = (m | (m >> 4)) & 0x00FF00FF00FF00FFull;
-  m = (m | (m >> 8)) & 0x0000FFFF0000FFFFull;
-  m = (m | (m >> 16)) & 0x00000000FFFFFFFFull;
-  if ((threadIdx.x & 63u) == 0u)
-    pairs[threadIdx.x >> 6] = (uint32_t)m;
 }
 
 /* Per-lane fp32 pre-test of one triangle candidate (small scenes: the flat filter passes a
@@ -1107,7 +1230,7 @@ __device__ __forceinline__ void tri_may_hit32_x2(const float4 *__restrict__ ra, 
 
 /* SPH_LDS (hierarchy kernels with parked walks): the flat filter covers the spheres only, and their part of the pair
  * table is staged in LDS and used in the sign-test form, as in the sphere-only kernels. */
-template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true, bool LAST = false, bool SPH_LDS = false>
+template <bool TRIS, bool BVH, bool FILT_LDS, bool WALK = true, bool LAST = false, bool SPH_LDS = false, bool FILT_MEM = false>
 __device__ __forceinline__ void scan_filtered(const double *geom, const double *tri_geom,
                                               const f32x2 *__restrict__ filt, double near_R2, uint32_t n_sph,
                                               uint32_t n_entries, const V3 &o, const V3 &d, double &min_t,
@@ -1155,9 +1278,9 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     if (SPH_LDS)
       filter_chunk<false, true>(filt, base, chunk, fr, cand_lo, cand_hi, big, &pruned);
     else if (FILT_LDS && prim_pairs != nullptr)
-      filter_chunk_listed<SHIFT>(filt, base, chunk, prim_pairs[base >> 6], fr, cand_lo, cand_hi);
+      filter_chunk_listed<SHIFT, FILT_MEM>(filt, base, chunk, prim_pairs[base >> 6], fr, cand_lo, cand_hi);
     else
-      filter_chunk<TRIS, FILT_LDS>(filt, base, chunk, fr, cand_lo, cand_hi, big, &pruned);
+      filter_chunk<TRIS, FILT_LDS, FILT_MEM>(filt, base, chunk, fr, cand_lo, cand_hi, big, &pruned);
     /* triangle candidates of this chunk: bits from entry n_sph on */
     uint32_t tri_lo = 0, tri_hi = 0;
     if (TRIS && !BVH)
@@ -1345,6 +1468,7 @@ struct SceneCtx
   uint32_t n_sph, n_tri;
   int max_depth;
   bool stale_uv;          /* M_CHECKERED materials AND triangles: hit.u / hit.v follow the TriLast rule */
+  const double *atan_tab; /* LDS: atan2_tab's coefficients (kernels with M_CHECKERED code), else nullptr */
   BigPrune big;           /* pruning of the leading wall-sized spheres among themselves (sign-test kernels), or off */
 };
 
@@ -1354,7 +1478,10 @@ struct SceneCtx
 template <bool GEOM_LDS, bool FILT_LDS, bool SPH_FILT = false>
 __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
 {
-  static_assert(GEOM_LDS || !FILT_LDS, "a filter table in LDS implies staged geometry");
+  /* FILT_LDS without GEOM_LDS (pt_render_tiles_pool_mem_s: sphere scenes beyond the staging budget): the small scenes' FORM of
+   * the filter -- sign tests, descending pairs, per-tile culling, wall pruning -- with the pair table read from memory
+   * (wave-uniform addresses: scalar loads) instead of from an LDS copy */
+  constexpr bool FILT_FROM_MEMORY = FILT_LDS && !GEOM_LDS;
   static_assert(!SPH_FILT || (GEOM_LDS && !FILT_LDS), "SPH_FILT: the sphere pairs only, for the hierarchy kernels");
   const PtSceneView &sc = L.scene;
   const uint32_t n_sph = sc.n_spheres, n_mat = sc.n_spheres + sc.n_meshes;
@@ -1388,7 +1515,9 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
     for (uint32_t k = threadIdx.x; k < n_slots; k += PT_BLOCK)
       filt_lds[k] = src[k];
   }
-  if (FILT_LDS)
+  if (FILT_FROM_MEMORY)
+    filt_lds = reinterpret_cast<f32x2 *>(sc.filt);
+  if (FILT_LDS && !FILT_FROM_MEMORY)
   {
     filt_lds = reinterpret_cast<f32x2 *>(mat + PT_MAT_STRIDE * (size_t)n_mat);
     /* the pair table (+ the look-ahead pair) and, behind it, the fp32 triangle table */
@@ -1438,6 +1567,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
   ctx.max_depth = L.max_depth;
   ctx.stale_uv = sc.any_checker != 0 && sc.n_triangles != 0;
   ctx.big = BigPrune{nullptr, 0u};
+  ctx.atan_tab = nullptr;
   return ctx;
 }
 
@@ -1454,13 +1584,36 @@ struct Path
 
 /* Deferred second child of an M_REFRACTION hit (raytracer.c:523-529 traces two children per
  * hit, the "refracted" one completely first): depth-first order = a LIFO of pending rays.
- * At most one entry is pushed per depth level, so max_depth + 1 slots suffice. */
-struct PendingRay
+ * At most one entry is pushed per depth level, so max_depth + 2 slots suffice.
+ * Round 4: the LIFO is no longer a private array (34 x 80 B = 2.7 KB of scratch memory per lane, indexed dynamically:
+ * the one thing that kept the static-body kernels from ever being free of scratch) but lives in a workspace slot in
+ * global memory that the workgroup takes from a per-device pool at entry (pt_pool_acquire, as the parked-walk kernels
+ * take their rings) -- entry-major, field-major, lane-minor: [entry][o xyz, d xyz, T xyz, depth][PT_BLOCK lanes], so a
+ * wave's push or pop of one field is one coalesced 512-byte access.  A lane only ever reads what it wrote itself.  The
+ * slot is sized by the launch's max_depth (PtLaunch.pend_entries = max_depth + 2). */
+#define PT_PEND_FIELDS 10u
+static_assert(PT_PEND_FIELDS == PT_PEND_FIELDS_HOST, "pending-ray record");
+struct PendStack
 {
-  V3 o, d, T;
-  int depth;
+  double *base;    /* this lane's column of the workgroup's slot (nullptr in kernels without a stack) */
+  int capacity;    /* entries */
+  __device__ __forceinline__ void push(int e, const V3 &o, const V3 &d, const V3 &T, int depth) const
+  {
+    double *q = base + (size_t)e * (PT_PEND_FIELDS * PT_BLOCK);
+    q[0 * PT_BLOCK] = o.x; q[1 * PT_BLOCK] = o.y; q[2 * PT_BLOCK] = o.z;
+    q[3 * PT_BLOCK] = d.x; q[4 * PT_BLOCK] = d.y; q[5 * PT_BLOCK] = d.z;
+    q[6 * PT_BLOCK] = T.x; q[7 * PT_BLOCK] = T.y; q[8 * PT_BLOCK] = T.z;
+    q[9 * PT_BLOCK] = __longlong_as_double((long long)depth);
+  }
+  __device__ __forceinline__ void pop(int e, V3 &o, V3 &d, V3 &T, int &depth) const
+  {
+    const double *q = base + (size_t)e * (PT_PEND_FIELDS * PT_BLOCK);
+    o = {q[0 * PT_BLOCK], q[1 * PT_BLOCK], q[2 * PT_BLOCK]};
+    d = {q[3 * PT_BLOCK], q[4 * PT_BLOCK], q[5 * PT_BLOCK]};
+    T = {q[6 * PT_BLOCK], q[7 * PT_BLOCK], q[8 * PT_BLOCK]};
+    depth = (int)__double_as_longlong(q[9 * PT_BLOCK]);
+  }
 };
-#define PT_REFRACT_STACK 34 /* supports max_depth <= 32 for scenes with M_REFRACTION */
 
 struct CameraRegs
 {
@@ -1649,9 +1802,9 @@ struct HitRec
  * half only, from *rec (which the caller may have completed with bvh_traverse).
  * DEFER_DIR: a diffuse hit does not sample its direction here; the caller does (HitRec). */
 template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int MODE = 0, bool DEFER_DIR = false,
-          bool SPH_LDS = false>
+          bool SPH_LDS = false, bool FILT_MEM = false>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
-                                           unsigned long long *diag_ptr, PendingRay *stack, int &stack_n,
+                                           unsigned long long *diag_ptr, const PendStack &stack, int &stack_n,
                                            HitRec *rec = nullptr, const uint32_t *prim_pairs = nullptr)
 {
   V3 add = {S.bg, S.bg, S.bg}; /* what this call contributes if the path ends here */
@@ -1690,7 +1843,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
                                                  &H.last);
       }
       else
-        scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0, CHECKER && TRIS, SPH_LDS>(
+        scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, MODE == 0, CHECKER && TRIS, SPH_LDS, FILT_MEM>(
             S.geom, S.tri, (FILT_LDS || SPH_LDS) ? S.filt_lds : S.filt, S.near_R2, S.n_sph, S.n_sph + S.n_tri, o, d, H.min_t, H.best,
             H.bary_u, H.bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, &H.last, S.stale_uv, S.tri32, prim_pairs, S.big);
     }
@@ -1769,7 +1922,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
            * sphere's (:410-411) */
           if (!(TRIS && H.last.idx >= 0))
           {
-            tex_u = atan2(n.x, n.z) / (2 * kPi) + 0.5; /* :410-411 */
+            tex_u = atan2_tab(n.x, n.z, S.atan_tab) / (2 * kPi) + 0.5; /* :410-411 */
             tex_v = n.y * 0.5 + 0.5;
           }
           else
@@ -1782,7 +1935,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
             tex_v = (tx[1] * w0 + tx[3] * lu) + tx[5] * lv;
           }
           /* checkered_texture :386-391, M = 100000 (:508) */
-          double on = (double)((fmod(tex_u * 100000.0, 1.0) > 0.5) ^ (fmod(tex_v * 100000.0, 1.0) < 0.5));
+          double on = (double)((frac1(tex_u * 100000.0) > 0.5) ^ (frac1(tex_v * 100000.0) < 0.5)); /* fmod(., 1): frac1 */
           double c = 0.3 * (1 - on) + 0.7 * on;
           albedo = v_scale(albedo, c);
           checker_scale = c;
@@ -1799,7 +1952,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
            * i.e. child A goes back along the incoming ray; child B is the mirror direction.
            * Both are normalised (:523, :526).  B waits on the stack with its share kr. */
           const double facing = -v_dot(d, n);
-          const double fresnel = 1 * 0.1 + pow(1 - facing, 3.0) * (1 - 0.1);
+          const double fresnel = 1 * 0.1 + cube(1 - facing) * (1 - 0.1); /* pow(x, 3): a weight, see cube() */
           const double kr = fresnel, kt = (1 - fresnel) * 1.0;
           const V3 in = v_scale(d, -1);
           const V3 nn = v_scale(n, -1);
@@ -1808,14 +1961,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           nd = v_normalize(refr);
           const V3 refl = v_normalize(v_sub(v_scale(d, 1), v_scale(n, 2 * v_dot(v_scale(d, 1), n))));
           const V3 base = v_mul(P.T, albedo);
-          if (stack_n < PT_REFRACT_STACK)
-          {
-            PendingRay &slot = stack[stack_n++];
-            slot.o = p;
-            slot.d = refl;
-            slot.T = v_scale(base, kr);
-            slot.depth = P.depth + 1;
-          }
+          if (stack_n < stack.capacity)
+            stack.push(stack_n++, p, refl, v_scale(base, kr), P.depth + 1);
           P.Ls = v_add(P.Ls, v_mul(P.T, emission));
           P.T = v_scale(base, kt);
           split = true;
@@ -1880,11 +2027,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
     {
       /* this branch of the tree is done: resume the most recent pending child; the RNG
        * stream simply continues, as it does across the reference's two recursive calls */
-      const PendingRay &slot = stack[--stack_n];
-      P.o = slot.o;
-      P.d = slot.d;
-      P.T = slot.T;
-      P.depth = slot.depth;
+      stack.pop(--stack_n, P.o, P.d, P.T, P.depth);
       path_ends = false;
     }
   }
@@ -1902,7 +2045,7 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
  * parks the other on the pending-ray stack.  No random draws after the camera jitter. */
 template <bool TRIS, bool FILT_LDS, bool STACK>
 __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
-                                             unsigned long long *diag_ptr, PendingRay *stack, int &stack_n)
+                                             unsigned long long *diag_ptr, const PendStack &stack, int &stack_n)
 {
   V3 add = {S.bg, S.bg, S.bg}; /* depth limit or no hit: BACKGROUND (:561-564) */
   bool path_ends = true;
@@ -1957,7 +2100,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
         double tex_u, tex_v;
         if (!(TRIS && last.idx >= 0))
         {
-          tex_u = atan2(n.x, n.z) / (2 * kPi) + 0.5; /* :410-411 */
+          tex_u = atan2_tab(n.x, n.z, S.atan_tab) / (2 * kPi) + 0.5; /* :410-411 */
           tex_v = n.y * 0.5 + 0.5;
         }
         else
@@ -1968,7 +2111,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
           tex_v = (tx[1] * w0 + tx[3] * last.u) + tx[5] * last.v;
         }
         /* checkered_texture :386-391 with M = 10 (:583) */
-        const double on = (double)((fmod(tex_u * 10.0, 1.0) > 0.5) ^ (fmod(tex_v * 10.0, 1.0) < 0.5));
+        const double on = (double)((frac1(tex_u * 10.0) > 0.5) ^ (frac1(tex_v * 10.0) < 0.5)); /* fmod(., 1): frac1 */
         color = v_scale(color, 0.3 * (1 - on) + 0.7 * on);
       }
 
@@ -1979,7 +2122,8 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
       const V3 reflected = v_sub(ldir, v_scale(n, 2 * v_dot(ldir, n)));
       const V3 view = v_normalize(v_sub(p, o));
       const double v_dot_r = v_dot(view, reflected);
-      const double specular = 1.0 * (ks * pow(v_dot_r > 0.0 ? v_dot_r : 0.0, alpha)); /* MAX(x, 0.0) */
+      (void)alpha;
+      const double specular = 1.0 * (ks * pow10(v_dot_r > 0.0 ? v_dot_r : 0.0)); /* pow(MAX(x, 0.0), alpha = 10): pow10() */
       const double shade = 1.0 * ka + (specular + diffuse) * lit;
       const V3 surface = v_scale(color, shade);
       add = surface;
@@ -1992,7 +2136,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
         if (glass)
         {
           const double facing = -v_dot(d, n);
-          const double fresnel = 1 * 0.1 + pow(1 - facing, 3.0) * (1 - 0.1); /* mix() :255 */
+          const double fresnel = 1 * 0.1 + cube(1 - facing) * (1 - 0.1); /* mix() :255; pow(x, 3): cube() */
           kr = fresnel; /* :622 -- also the weight of an M_REFLECTION child of the same hit */
           kt = (1 - fresnel) * 0.5;
           /* refract(I, N, 1.0) :354-373 with cosi == 1: I*1 + (-N)*(1*1 - sqrtf(1)) */
@@ -2005,14 +2149,8 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
         {
           const V3 refl = v_normalize(v_sub(d, v_scale(n, 2 * v_dot(d, n))));
           /* STACK = false: the launcher has checked that no material carries both flags */
-          if (STACK && glass && stack_n < PT_REFRACT_STACK)
-          {
-            PendingRay &pend = stack[stack_n++];
-            pend.o = p;
-            pend.d = through;
-            pend.T = v_scale(weight, kt);
-            pend.depth = P.depth + 1;
-          }
+          if (STACK && glass && stack_n < stack.capacity)
+            stack.push(stack_n++, p, through, v_scale(weight, kt), P.depth + 1);
           P.d = refl;
           P.T = v_scale(weight, kr);
         }
@@ -2032,11 +2170,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
     P.Ls = v_add(P.Ls, v_mul(P.T, add));
     if (STACK && stack_n > 0)
     {
-      const PendingRay &pend = stack[--stack_n];
-      P.o = pend.o;
-      P.d = pend.d;
-      P.T = pend.T;
-      P.depth = pend.depth;
+      stack.pop(--stack_n, P.o, P.d, P.T, P.depth);
       path_ends = false;
     }
   }
@@ -2151,7 +2285,10 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   constexpr uint32_t WAIT_F = CHECKER ? 11u : 10u;
   __shared__ double w_f[SWAP ? PT_BLOCK / 64 : 1][SWAP ? WAIT_F : 1][SWAP ? 64 : 1];
   __shared__ uint32_t w_u[SWAP ? PT_BLOCK / 64 : 1][SWAP ? 2 : 1][SWAP ? 64 : 1];
-  __shared__ uint32_t tile_pairs[PT_FILT_LDS_MAX / 64]; /* tile_cull: pairs a camera ray of this tile can reach, per chunk of 64 entries */
+  /* tile_cull: pairs a camera ray of this tile can reach, per chunk of 64 entries (scenes of more entries than the array
+   * covers go without the culling: cull_ok) */
+  constexpr uint32_t CULL_WORDS = GEOM_LDS ? PT_FILT_LDS_MAX / 64 : 256u;
+  __shared__ uint32_t tile_pairs[CULL_WORDS];
   __shared__ uint32_t wg_next_job;                      /* SWAP: jobs of the tile's pool handed out so far */
 
 #ifdef PT_PHASE
@@ -2163,6 +2300,12 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   }
 #endif
   SceneCtx S_init = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
+  __shared__ double atan_tab[CHECKER ? PT_ATAN_TAB : 1];
+  if (CHECKER)
+  {
+    atan_table_to_lds(atan_tab);
+    S_init.atan_tab = atan_tab;
+  }
   PHASE(8); /* prologue: staging (scene -> LDS) */
   __shared__ __attribute__((aligned(16))) float big_tab[12]; /* BigPrune: delta, tmin, qmin of the leading wall-sized spheres */
   if (SWAP && FILT_LDS && !TRIS && L.big_pairs != 0u)
@@ -2197,7 +2340,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
    * tiles, so the chunks of an expensive tile are spread over the launch */
   const uint32_t slot = blockIdx.x % L.tile_count, chunk = blockIdx.x / L.tile_count;
   const uint32_t tile = L.tile_first + slot * L.tile_stride;
-  if (SWAP && FILT_LDS)
+  const bool cull_ok = S.n_sph + S.n_tri <= 64u * CULL_WORDS;
+  if (SWAP && FILT_LDS && cull_ok)
   { /* the primitives a camera ray of this tile can reach at all: what the filter of a PRIMARY trip looks at */
     tile_cull(cam_lds, L.scene.entry_src, S.n_sph, S.n_sph + S.n_tri, (tile % L.tiles_x) * PT_TILE, (tile / L.tiles_x) * PT_TILE, tile_pairs);
     __syncthreads();
@@ -2247,6 +2391,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   uint32_t pix_slot = 0;     /* 0..63 inside the tile */
   bool busy = false;
   int stack_n = 0; /* no pending-ray stack in this body */
+  const PendStack no_stack = {nullptr, 0};
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
   const uint32_t lane = threadIdx.x & 63u;
@@ -2424,7 +2569,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     }
     if (__ballot(busy) == 0)
       break; /* pool dry and every lane drained (an idle lane would have taken a waiting path): the one exit, reached by all lanes together */
-    const uint32_t *const prim_pairs = (SWAP && FILT_LDS && primary_trip) ? tile_pairs : nullptr;
+    const uint32_t *const prim_pairs = (SWAP && FILT_LDS && primary_trip && cull_ok) ? tile_pairs : nullptr;
     PHASE(0); /* the rest of the trip's head: the camera samples of a swap (start_sample) */
 
     bool step_done = false;
@@ -2445,7 +2590,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         DIAG(0, 1);
         DIAG_LANES(1);
         n_rays++;
-        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
         const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
         /* stale_uv: every triangle the ray passes matters, not only those closer than min_t (TriLast) */
         mesh_wait = hit.depth_ok && bvh_probe(S.bvh_nodes, S.n_bvh_nodes, far_origin, P.o, P.d,
@@ -2469,7 +2614,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       }
       trip++;
       if (stepping && !mesh_wait)
-        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
     }
     else if (PARK_T)
     {
@@ -2486,10 +2631,10 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         t_park[1][threadIdx.x] = P.T.y;
         t_park[2][threadIdx.x] = P.T.z;
         asm volatile("" ::: "memory"); /* no store-to-load forwarding: the values must leave the registers */
-        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit, prim_pairs);
+        (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit, prim_pairs);
         asm volatile("" ::: "memory");
         P.T = {t_park[0][threadIdx.x], t_park[1][threadIdx.x], t_park[2][threadIdx.x]};
-        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
       }
     }
     else if (stepping)
@@ -2497,7 +2642,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 0, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit, prim_pairs);
+      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 0, true, false, FILT_LDS && !GEOM_LDS>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit, prim_pairs);
     }
     PHASE(3); /* hit record, roulette, material */
     /* ---- directions of diffuse hits: PT_DIR_ROUNDS rejection rounds per trip ----
@@ -2705,14 +2850,14 @@ __device__ __forceinline__ void ring_st3(const ParkRing &r, uint32_t field, uint
  * search.  The waves of such a workgroup render nothing and say so: every pixel of their tiles comes out NaN (bytes 255;
  * render_tiles_queued), rather than spin for ever or walk rays from registers the kernel does not have.  Thread 0 only. */
 __device__ __forceinline__ uint32_t lane_of_thread() { return threadIdx.x & 63u; }
-__device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
+/* a slot of a pool of `per` slots per XCD with one in-use flag each (zero between launches) */
+__device__ __forceinline__ uint32_t pt_pool_acquire(uint32_t *flags_base, uint32_t per)
 {
-  if (L.park_ws == nullptr || L.park_slots_per_xcd == 0u)
+  if (flags_base == nullptr || per == 0u)
     return 0xFFFFFFFFu;
   /* s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, width 4): the XCD this wave runs on */
   const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
-  const uint32_t per = L.park_slots_per_xcd;
-  uint32_t *flags = L.park_flags + xcc * per;
+  uint32_t *flags = flags_base + xcc * per;
   uint32_t i = ((blockIdx.x * 2654435761u) >> 7) % per;
   for (uint32_t probes = 0; probes < 64u * per; probes++)
   {
@@ -2723,6 +2868,10 @@ __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
       __builtin_amdgcn_s_sleep(8);
   }
   return 0xFFFFFFFFu;
+}
+__device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
+{
+  return pt_pool_acquire(L.park_ws == nullptr ? nullptr : L.park_flags, L.park_slots_per_xcd);
 }
 
 /* The per-lane traversal stacks of the parked-walk kernels: 24-bit entries (a 16-bit and an 8-bit array, entry-major,
@@ -2960,6 +3109,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   }
 #endif
   SceneCtx S_init = stage_scene<true, FILT_LDS, true>(L, lds);
+  __shared__ double atan_tab[CHECKER ? PT_ATAN_TAB : 1];
+  if (CHECKER)
+  {
+    atan_table_to_lds(atan_tab);
+    S_init.atan_tab = atan_tab;
+  }
   PHASE(8);
   __shared__ __attribute__((aligned(16))) float big_tab[12]; /* BigPrune: delta, tmin, qmin of the leading wall-sized spheres */
   if (L.big_pairs != 0u)
@@ -3072,6 +3227,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   bool busy = false;
   bool waiting = false; /* the lane's ray is scanned and wants a walk, but the ring was full: park it next trip */
   int stack_n = 0;
+  const PendStack no_stack = {nullptr, 0};
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
   const uint32_t lane = threadIdx.x & 63u;
@@ -3314,7 +3470,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       /* ... and a fresh camera ray of a tile whose cone cannot reach the triangles' bounding ball (tile_sees_mesh, once
        * per wave: a primary trip's 64 rays are all such rays) cannot either: most of the image's primary trips skip the probe */
       const bool no_mesh = (hit.leaving && !(CHECKER && S.stale_uv)) || (primary_trip && !tile_sees_mesh);
-      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
       const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
 #ifdef PT_DIAG
       /* RT_HIP_DIAG_WALK_REJECTED=1: rays the bounding sphere rejects are parked and walked all the same, and any
@@ -3388,7 +3544,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
      * walked rays resumed at the top of this trip ---- */
     bool step_done = false;
     if (busy && (stepping || resumed) && !waiting)
-      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true>(S, P, n_casts, diag_ptr, nullptr, stack_n, &hit);
+      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
     PHASE(3);
 
     /* ---- directions of diffuse hits (see render_tiles_pooled) ---- */
@@ -3526,11 +3682,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
  * (static body + per-lane stack of pending second children; also covers M_CHECKERED).
  * pt_render_tiles itself is the headline configuration: diffuse / mirror / emissive spheres,
  * small scene. */
-#define PT_KERNEL(name, bounds, CHECKER, TRIS, FILT_LDS)                                     \
+#define PT_KERNEL_G(name, bounds, CHECKER, TRIS, FILT_LDS, GEOM_LDS)                         \
   extern "C" __global__ bounds void name(const PtLaunch L)                                  \
   {                                                                                         \
-    render_tiles_pooled<CHECKER, TRIS, FILT_LDS, true>(L);                                  \
+    render_tiles_pooled<CHECKER, TRIS, FILT_LDS, GEOM_LDS>(L);                              \
   }
+#define PT_KERNEL(name, bounds, CHECKER, TRIS, FILT_LDS) PT_KERNEL_G(name, bounds, CHECKER, TRIS, FILT_LDS, true)
 PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, true)
 PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
 PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_TRI), false, true, true)
@@ -3556,7 +3713,23 @@ PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK), true, false, true)
 PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK), true, false, false)
 PT_KERNEL(pt_render_tiles_tri_chk, __launch_bounds__(PT_BLOCK), true, true, true)
 PT_KERNEL(pt_render_tiles_tri_big_chk, __launch_bounds__(PT_BLOCK), true, true, false)
+/* Scenes whose sphere geometry + materials exceed the LDS staging budget (pt_geom_in_lds: more than 256 spheres): the SAME
+ * pooled body -- job pool, swap, fixed-point sums, four rejection rounds per trip, sample chunks -- with geometry and
+ * materials gathered from memory (PtSceneView.geom4 / material: 32 + 64 bytes per sphere, L2-resident up to tens of
+ * thousands of spheres) and the filter table streamed through scalar loads as in the _big kernels.  Until round 4 the
+ * 257th sphere dropped a scene onto pt_render_tiles_mem, the static body with every material's code and a 2.7 KB
+ * private stack per lane (still the kernel of such scenes WITH M_REFRACTION, whose throughput is unbounded). */
+PT_KERNEL_G(pt_render_tiles_pool_mem, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false, false)
+PT_KERNEL_G(pt_render_tiles_pool_mem_chk, __launch_bounds__(PT_BLOCK), true, false, false, false)
+PT_KERNEL_G(pt_render_tiles_pool_mem_tri, __launch_bounds__(PT_BLOCK, 4), false, true, false, false)
+PT_KERNEL_G(pt_render_tiles_pool_mem_tri_chk, __launch_bounds__(PT_BLOCK), true, true, false, false)
+/* ... and, for sphere-only scenes within fp32's comfortable range (no centre or radius beyond 1e17), with the small scenes' FORM
+ * of the filter -- sign tests, per-tile culling of the primary trips, the walls pruned among themselves -- read from memory
+ * (stage_scene, FILT_FROM_MEMORY).  Measured on rooms packed as main.c:65-138 would (tools/many_spheres.py, profiles/r04_many_spheres.txt). */
+PT_KERNEL_G(pt_render_tiles_pool_mem_s, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, true, false)
+PT_KERNEL_G(pt_render_tiles_pool_mem_s_chk, __launch_bounds__(PT_BLOCK), true, false, true, false)
 #undef PT_KERNEL
+#undef PT_KERNEL_G
 
 /* ---- static body: lane = (pixel, sample slice), fp64 partial sums ------------------------
  * Lane l of wave w: pixel (l >> 2) of the wave's 16, sample slice (l & 3): samples s = slice,
@@ -3574,7 +3747,14 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
 
-  const SceneCtx S = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
+  SceneCtx S_init = stage_scene<GEOM_LDS, FILT_LDS>(L, lds);
+  __shared__ double atan_tab[(CHECKER || WHITTED) ? PT_ATAN_TAB : 1];
+  if (CHECKER || WHITTED)
+  {
+    atan_table_to_lds(atan_tab);
+    S_init.atan_tab = atan_tab;
+  }
+  const SceneCtx S = S_init;
   if (threadIdx.x < 2)
     wg_stats[threadIdx.x] = 0;
   __syncthreads();
@@ -3601,7 +3781,23 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   uint32_t n_rays = 0, n_casts = 0;
   uint32_t s = inside ? slice : spp;
   bool fresh = true;
-  PendingRay stack[(REFRACT || WHITTED == 2) ? PT_REFRACT_STACK : 1];
+  /* kernels with two-child materials: the workgroup's slot of the pending-ray pool (PendStack) */
+  constexpr bool STACKED = REFRACT || WHITTED == 2;
+  __shared__ uint32_t pend_slot_lds;
+  if (STACKED)
+  {
+    if (threadIdx.x == 0)
+      pend_slot_lds = pt_pool_acquire(L.pend_flags, L.pend_slots_per_xcd);
+    __syncthreads();
+  }
+  const uint32_t pend_slot = STACKED ? pend_slot_lds : 0u;
+  /* (no slot: a sizing bug of the pool, never seen -- the launcher refuses to launch without a pool.  The tile then comes
+   * out NaN, bytes 255, rather than wrong: see the epilogue) */
+  const bool pend_ok = !STACKED || pend_slot != 0xFFFFFFFFu;
+  const PendStack stack = {STACKED && pend_ok ? L.pend_ws + (size_t)pend_slot * L.pend_slot_doubles + threadIdx.x : nullptr,
+                           STACKED && pend_ok ? (int)L.pend_entries : 0};
+  if (!pend_ok)
+    s = spp;
   int stack_n = 0;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
@@ -3636,7 +3832,9 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   acc.x += __shfl_xor(acc.x, 2);
   acc.y += __shfl_xor(acc.y, 2);
   acc.z += __shfl_xor(acc.z, 2);
-  const V3 mean = v_scale(acc, 1.0 / (double)spp); /* :215 */
+  V3 mean = v_scale(acc, 1.0 / (double)spp); /* :215 */
+  if (!pend_ok)
+    mean.x = mean.y = mean.z = __longlong_as_double(0x7FF8000000000000ll);
   if (slice == 0)
   {
     out_f[3 * pix_in_tile + 0] = inside ? (float)mean.x : 0.f;
@@ -3653,18 +3851,29 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   }
   __syncthreads();
   store_tile(L, out_f, out_b, wg_stats, tile, blockIdx.x, S.n_sph + S.n_tri, true, true);
+  if (STACKED && pend_ok && threadIdx.x == 0)
+    atomicExch(&L.pend_flags[pend_slot], 0u); /* every lane is past its last pop (the barrier above) */
 }
 
-#define PT_KERNEL_STATIC(name, VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS)                    \
-  extern "C" __global__ __launch_bounds__(PT_BLOCK) void name(const PtLaunch L)             \
+/* launch bounds of the M_REFRACTION kernels (waves per SIMD).  Until round 4 they had none: 203-232 VGPRs and a 2.7 KB private
+ * stack, two waves per SIMD.  With the pending rays in the pool (PendStack) and the material code's library calls gone
+ * (atan2_tab, cube, frac1) the sphere kernels need 127 VGPRs and the mesh kernels ~150, without scratch */
+#ifndef PT_MIN_WAVES_REFR
+#define PT_MIN_WAVES_REFR 4
+#endif
+#ifndef PT_MIN_WAVES_REFR_TRI
+#define PT_MIN_WAVES_REFR_TRI 3
+#endif
+#define PT_KERNEL_STATIC(name, WAVES, VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS)             \
+  extern "C" __global__ __launch_bounds__(PT_BLOCK, WAVES) void name(const PtLaunch L)      \
   {                                                                                         \
     render_tiles_static<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS, 0, true>(L);             \
   }
-PT_KERNEL_STATIC(pt_render_tiles_v0, 0, false, true, true, false)
-PT_KERNEL_STATIC(pt_render_tiles_refr, 1, true, true, false, true)
-PT_KERNEL_STATIC(pt_render_tiles_big_refr, 1, true, true, false, false)
-PT_KERNEL_STATIC(pt_render_tiles_tri_refr, 1, true, true, true, true)
-PT_KERNEL_STATIC(pt_render_tiles_tri_big_refr, 1, true, true, true, false)
+PT_KERNEL_STATIC(pt_render_tiles_v0, 1, 0, false, true, true, false)
+PT_KERNEL_STATIC(pt_render_tiles_refr, PT_MIN_WAVES_REFR, 1, true, true, false, true)
+PT_KERNEL_STATIC(pt_render_tiles_big_refr, PT_MIN_WAVES_REFR, 1, true, true, false, false)
+PT_KERNEL_STATIC(pt_render_tiles_tri_refr, PT_MIN_WAVES_REFR_TRI, 1, true, true, true, true)
+PT_KERNEL_STATIC(pt_render_tiles_tri_big_refr, PT_MIN_WAVES_REFR_TRI, 1, true, true, true, false)
 #undef PT_KERNEL_STATIC
 
 /* cast_ray kernels: the static body with whitted_step, without a pending-ray stack (scenes with
@@ -3722,10 +3931,14 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const Pt
 /* Self-test hook (rt_hip_selftest_math): evaluates the kernel's exact-arithmetic shortcuts
  * on caller data so a test can compare them bit for bit with the host's IEEE results.
  * op 0: sqrt_unscaled(a[i]);  op 1: div_small_int(a[i], b[i], 1/b[i]);  op 2: the library
- * sqrt(a[i]);  op 3: a[i] / b[i];  op 4: rnd_pm1-style fused r * 2^-30 - 1 with r = a[i]. */
+ * sqrt(a[i]);  op 3: a[i] / b[i];  op 4: rnd_pm1-style fused r * 2^-30 - 1 with r = a[i];  op 5: rcp_unscaled(a[i]);
+ * op 6: atan2_tab(a[i], b[i]);  op 7: frac1(a[i]) (= fmod(a[i], 1.0)). */
 extern "C" __global__ __launch_bounds__(256) void pt_selftest_math(int op, const double *a, const double *b,
                                                                   double *out, size_t n)
 {
+  __shared__ double tab[PT_ATAN_TAB];
+  atan_table_to_lds(tab);
+  __syncthreads();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
   {
     double r = 0;
@@ -3741,6 +3954,10 @@ extern "C" __global__ __launch_bounds__(256) void pt_selftest_math(int op, const
       r = __builtin_fma(a[i], 1.0 / 1073741824.0, -1.0);
     else if (op == 5)
       r = rcp_unscaled(a[i]);
+    else if (op == 6)
+      r = atan2_tab(a[i], b[i], tab);
+    else if (op == 7)
+      r = frac1(a[i]);
     out[i] = r;
   }
 }
@@ -4066,13 +4283,15 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
 /* have_park_ws = false: the parked-walk kernels' workspace is missing (its allocation failed): the lane-waiting kernels */
 static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name, bool have_park_ws = true)
 {
-  static const char *const names[22] = {
+  static const char *const names[28] = {
       "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
       "pt_render_tiles_chk",  "pt_render_tiles_big_chk",  "pt_render_tiles_tri_chk",  "pt_render_tiles_tri_big_chk",
       "pt_render_tiles_refr", "pt_render_tiles_big_refr", "pt_render_tiles_tri_refr", "pt_render_tiles_tri_big_refr",
       "pt_render_tiles_v0",   "pt_whitted_tiles",         "pt_whitted_tiles_big",     "pt_whitted_tiles_tri",
       "pt_whitted_tiles_tri_big", "pt_render_tiles_mem",  "pt_whitted_tiles_mem",
-      "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk", "pt_render_tiles_tri_queued_sph"};
+      "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk", "pt_render_tiles_tri_queued_sph",
+      "pt_render_tiles_pool_mem", "pt_render_tiles_pool_mem_chk", "pt_render_tiles_pool_mem_tri", "pt_render_tiles_pool_mem_tri_chk",
+      "pt_render_tiles_pool_mem_s", "pt_render_tiles_pool_mem_s_chk"};
   const bool tris = scene.n_triangles != 0;
   const bool big = !pt_filter_in_lds(scene);
   const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
@@ -4081,18 +4300,31 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
   /* too large to stage, or cast_ray with two-child materials: the two general kernels */
   const bool in_memory = !pt_geom_in_lds(scene) || (cast_ray && scene.any_mirror_glass);
   if (in_memory)
+  {
     which = cast_ray ? 18 : 17;
+    /* trace_path without M_REFRACTION: the pooled body with geometry from memory (variant 3: the static kernel, for A/B) */
+    if (!cast_ray && !refr && variant != 3)
+      which = (!tris && !scene.wide_range && variant != 4) ? 26 + (chk ? 1 : 0) : 22 + (tris ? 2 : 0) + (chk ? 1 : 0); /* (variant 4: the compare-form kernel, for A/B) */
+  }
   else if (variant == 0 && !refr && !cast_ray)
     which = 12;
+  else if (!cast_ray && variant != 5 && pt_prefer_streaming(scene))
+    which = 26 + (chk ? 1 : 0); /* a sphere scene that would fit the staging budget but is faster streamed (pt_device.h; variant 5: staged, for A/B) */
   else if ((which == 3 || which == 7) && variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) && scene.n_triangles < (1u << (23 - PT_BVH_COUNT_BITS)))
     which = which == 3 ? (scene.mesh_round ? 21 : 19) : 20; /* hierarchy scenes: parked walks (variant 2, scenes beyond fp32's comfortable range,
                                    * whose filter needs the NaN-safe compares, and meshes whose references do not fit the walk's
                                    * 24-bit stack entries keep the lane-waiting pooled kernels) */
-  if (which >= 19 && !have_park_ws)
+  if (which >= 19 && which <= 21 && !have_park_ws)
     which = which == 20 ? 7 : 3; /* no ring workspace: the lane-waiting kernels need none */
   if (name)
     *name = names[which];
   return which;
+}
+
+bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant)
+{
+  const int which = pt_pick_kernel(scene, integrator, variant, nullptr);
+  return (which >= 8 && which <= 11) || which == 17 || which == 18; /* _refr, pt_render_tiles_mem, pt_whitted_tiles_mem */
 }
 
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws)
@@ -4146,16 +4378,22 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }();
   size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[22] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
+  static const Kernel family[28] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
                                     pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr,
                                     pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
                                     pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem,
-                                    pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph};
+                                    pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph,
+                                    pt_render_tiles_pool_mem, pt_render_tiles_pool_mem_chk, pt_render_tiles_pool_mem_tri,
+                                    pt_render_tiles_pool_mem_tri_chk, pt_render_tiles_pool_mem_s, pt_render_tiles_pool_mem_s_chk};
   const int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr,
                                    launch.park_ws != nullptr && launch.park_slots_per_xcd != 0u);
   const Kernel kernel = family[which];
-  if (which >= 19) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
+  if (which >= 22)
+    lds_bytes = extra_lds; /* the in-memory pooled kernels stage nothing, whatever the scene's size */
+  if (((which >= 8 && which <= 11) || which == 17 || which == 18) && (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
+    return hipErrorInvalidValue; /* a kernel with a pending-ray stack needs its pool (rt_hip_shim.hip: pend_pool_for) */
+  if (which >= 19 && which <= 21) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
                  (((size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u);
   if (lds_bytes > 64 * 1024)
@@ -4174,7 +4412,7 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }
   /* the parked-walk kernels render a tile per wave, four work units per workgroup */
   const uint32_t n_units = launch.tile_count * launch.sample_chunks;
-  hipLaunchKernelGGL(kernel, dim3(which >= 19 ? (n_units + PT_BLOCK / 64 - 1) / (PT_BLOCK / 64) : n_units), dim3(PT_BLOCK), lds_bytes,
+  hipLaunchKernelGGL(kernel, dim3((which >= 19 && which <= 21) ? (n_units + PT_BLOCK / 64 - 1) / (PT_BLOCK / 64) : n_units), dim3(PT_BLOCK), lds_bytes,
                      stream, launch);
   if (launch.sample_chunks > 1)
     hipLaunchKernelGGL(pt_resolve_tiles, dim3(launch.tile_count), dim3(PT_BLOCK), 0, stream, launch);

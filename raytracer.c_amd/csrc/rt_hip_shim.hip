@@ -314,7 +314,9 @@ int kernel_variant()
 {
   static const int v = [] {
     const char *e = getenv("RT_HIP_KERNEL_VARIANT");
-    return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); /* 2: hierarchy scenes on the lane-waiting pooled kernels */
+    /* 2: hierarchy scenes on the lane-waiting pooled kernels; 3: scenes beyond the LDS staging budget on the static in-memory kernel */
+    /* 4: such scenes on the compare-form pooled kernel; 5: mid-size sphere scenes staged in LDS although streaming is faster (pt_prefer_streaming) */
+    return (e && e[0] >= '0' && e[0] <= '5' && e[0] != '1') ? e[0] - '0' : 1;
   }();
   return v;
 }
@@ -504,6 +506,78 @@ void park_drop_ws(int device)
     (void)hipFree(p.ws);
     p.ws = nullptr;
   }
+}
+
+/* the per-device pool of pending-ray stacks of the two-child kernels (pt_kernel.hip, PendStack): flags, then
+ * PT_PARK_XCDS x PT_PEND_SLOTS_PER_XCD slots of `entries` x 10 fields x PT_BLOCK doubles.  Sized by the deepest launch
+ * seen so far (max_depth + 2 entries: 147 MB at the reference's MAX_DEPTH 5, 713 MB at the limit of 32); grown -- after
+ * the device has drained -- when a launch needs more, never shrunk; rt_hip_release_cache() frees it. */
+struct PendPool
+{
+  char *ws = nullptr;
+  uint32_t entries = 0;
+};
+std::mutex g_pend_mutex; /* held from the pool lookup until the launch that uses it is enqueued (so that a growing
+                          * launch's hipDeviceSynchronize covers every kernel that holds the old pointer) */
+PendPool g_pend[64];
+
+size_t pend_flag_bytes() { return ((size_t)PT_PARK_XCDS * PT_PEND_SLOTS_PER_XCD * sizeof(uint32_t) + 255) & ~(size_t)255; }
+
+/* caller holds g_pend_mutex; the current device is `device` */
+int pend_pool_for(int device, uint32_t entries, PtLaunch &L)
+{
+  if (device < 0 || device >= 64)
+    return fail(RT_HIP_ENODEV, "device %d: no pending-ray pool", device);
+  PendPool &p = g_pend[device];
+  if (p.entries < entries)
+  {
+    if (p.ws)
+    {
+      HIP_TRY(hipDeviceSynchronize());
+      (void)hipFree(p.ws);
+      p.ws = nullptr;
+      p.entries = 0;
+    }
+    const size_t slot_bytes = (size_t)entries * PT_PEND_FIELDS_HOST * PT_BLOCK * sizeof(double);
+    const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PEND_SLOTS_PER_XCD;
+    char *ws = nullptr;
+    hipError_t e = hipMalloc(&ws, pend_flag_bytes() + n_slots * slot_bytes);
+    if (e != hipSuccess)
+      return fail(RT_HIP_ENOMEM, "pending-ray pool for max_depth %u (%zu MB): %s", entries - 2u,
+                  (pend_flag_bytes() + n_slots * slot_bytes) >> 20, hipGetErrorString(e));
+    e = hipMemset(ws, 0, pend_flag_bytes());
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(nullptr); /* the flags are zero before a kernel on any stream looks at them */
+    if (e != hipSuccess)
+    {
+      (void)hipFree(ws);
+      return fail(RT_HIP_ERUNTIME, "pending-ray pool: %s", hipGetErrorString(e));
+    }
+    p.ws = ws;
+    p.entries = entries;
+  }
+  L.pend_flags = reinterpret_cast<uint32_t *>(p.ws);
+  L.pend_ws = reinterpret_cast<double *>(p.ws + pend_flag_bytes());
+  L.pend_slots_per_xcd = PT_PEND_SLOTS_PER_XCD;
+  L.pend_entries = p.entries; /* slots are laid out for the pool's depth; a shallower launch uses a prefix of each */
+  L.pend_slot_doubles = (uint64_t)p.entries * PT_PEND_FIELDS_HOST * PT_BLOCK;
+  return RT_HIP_OK;
+}
+
+void pend_pools_release()
+{
+  std::lock_guard<std::mutex> lock(g_pend_mutex);
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  for (int d = 0; d < 64; d++)
+    if (g_pend[d].ws)
+    {
+      (void)hipSetDevice(d);
+      (void)hipDeviceSynchronize();
+      (void)hipFree(g_pend[d].ws);
+      g_pend[d] = PendPool();
+    }
+  (void)hipSetDevice(prev);
 }
 
 uint32_t tiles_x_of(int width) { return ((uint32_t)width + PT_TILE - 1) / PT_TILE; }
@@ -877,6 +951,13 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.any_checker = any_checker ? 1u : 0u;
   sc->view.mesh_round = mesh_round ? 1u : 0u;
   sc->view.any_refract = any_refract ? 1u : 0u;
+  {
+    /* development knob (tools/many_spheres.py): RT_HIP_FORCE_BIG=1 sends a small scene to the scalar-table _big kernels,
+     * which it otherwise reaches only through a centre or radius beyond 1e17 */
+    const char *fb = getenv("RT_HIP_FORCE_BIG");
+    if (fb && fb[0] == '1')
+      wide_range = true;
+  }
   sc->view.wide_range = wide_range ? 1u : 0u;
   sc->max_center = max_center;
   {
@@ -1032,8 +1113,10 @@ static void big_prune_for(const RtHipScene *scene, double near_R, double filt_sh
   }();
   /* the kernels whose sphere filter is the sign-test form from LDS: sphere-only small scenes, and hierarchy scenes whose
    * spheres fit the staging (the parked-walk kernels filter the spheres alone) */
-  const bool sign_form = !scene->view.wide_range && pt_geom_in_lds(scene->view) &&
-                         (scene->view.n_triangles == 0 ? pt_filter_in_lds(scene->view) : !pt_filter_in_lds(scene->view));
+  const bool sign_form = !scene->view.wide_range &&
+                         (pt_geom_in_lds(scene->view) ? (scene->view.n_triangles == 0 ? pt_filter_in_lds(scene->view) : !pt_filter_in_lds(scene->view))
+                                                      : (scene->view.n_triangles == 0 && !scene->view.any_refract)); /* pt_render_tiles_pool_mem_s
+                                                                             * (scenes it takes by preference, pt_prefer_streaming, satisfy the first arm) */
   if (off || scene->n_big < 2 || !sign_form)
     return;
   const double e = 5.9604644775390625e-08, f = 1.0 / 16.0;
@@ -1181,7 +1264,8 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   L.tile_count = params->tile_count;
   L.tiles_x = tx;
   /* the static kernels (plain reference variant; M_REFRACTION; cast_ray; scenes too large to stage) do not split samples */
-  L.sample_chunks = (kernel_variant() == 0 || scene->view.any_refract || cast_ray || !pt_geom_in_lds(scene->view)) ? 1u : sample_chunks;
+  L.sample_chunks = (kernel_variant() == 0 || scene->view.any_refract || cast_ray ||
+                     (!pt_geom_in_lds(scene->view) && kernel_variant() == 3)) ? 1u : sample_chunks;
   L.integrator = cast_ray ? 1u : 0u;
   L.acc_ws = static_cast<unsigned long long *>(d_workspace);
   if ((uint64_t)L.tile_count * L.sample_chunks > 0x7FFFFFFFull)
@@ -1215,7 +1299,20 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   rc = acquire_tables(scene, L.near_R, static_cast<hipStream_t>(stream), &L.scene.filt, &L.scene.bvh_nodes, &slot);
   if (rc)
     return rc;
-  hipError_t e = pt_launch_render(L, static_cast<hipStream_t>(stream), kernel_variant());
+  hipError_t e;
+  if (pt_kernel_needs_pend_pool(L.scene, L.integrator, kernel_variant()))
+  {
+    std::lock_guard<std::mutex> pend_lock(g_pend_mutex);
+    rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, L);
+    if (rc)
+    {
+      release_tables(scene, slot, static_cast<hipStream_t>(stream));
+      return rc;
+    }
+    e = pt_launch_render(L, static_cast<hipStream_t>(stream), kernel_variant());
+  }
+  else
+    e = pt_launch_render(L, static_cast<hipStream_t>(stream), kernel_variant());
   release_tables(scene, slot, static_cast<hipStream_t>(stream));
   if (e != hipSuccess)
     return fail(RT_HIP_ERUNTIME, "pt_render_tiles launch: %s", hipGetErrorString(e));
@@ -1224,7 +1321,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
 
 int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h_out, size_t n, int device)
 {
-  if (!h_a || !h_b || !h_out || op < 0 || op > 5)
+  if (!h_a || !h_b || !h_out || op < 0 || op > 7)
     return fail(RT_HIP_EINVAL, "bad self-test arguments");
   if (device < 0 || device >= usable_devices())
     return fail(RT_HIP_ENODEV, "no HIP device %d", device);
@@ -1748,8 +1845,11 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
 
 void release_cache_impl()
 {
-  std::lock_guard<std::mutex> lock(g_ctx_mutex);
-  ctx_release(g_ctx);
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    ctx_release(g_ctx);
+  }
+  pend_pools_release();
 }
 
 uint64_t cache_builds_impl()

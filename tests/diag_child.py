@@ -12,7 +12,7 @@ shim (RT_HIP_SHIM_PATH=.../librt_hip_diag.so, RT_HIP_DIAG_WALK_REJECTED=1) and p
   parked rays, parked rays the probe alone would have let through, rays that left a hull facet, leaf pre-tests.
 
 The PT_DIAG build is a checker's build of the product kernels, not the product: it never runs outside these tests.
-usage: diag_child.py SET   with SET in {configs, fullsize, fuzz, convex, wide}"""
+usage: diag_child.py SET   with SET in {configs, fullsize, fuzz, convex, rooms, wide}"""
 import json
 import os
 import sys
@@ -42,6 +42,9 @@ def scene_sets(which):
         return sets + [("whitted scene", whitted_scene())]
     if which == "convex":    # convex bodies at 64 spp: ~1e6 bounces off hull facets each, all walked
         return [("convex body %d" % k, convex_body_scene(k, 160, 100, 64)[0]) for k in range(4)]
+    if which == "rooms":     # rooms of more than 256 spheres (pt_render_tiles_pool_mem: geometry from memory, scalar-table filter)
+        from util import packed_room
+        return [("room %d" % n, packed_room(n, k, 160, 96, 4, 8)) for k, n in enumerate([249, 500, 1500])]
     if which == "wide":      # the wider sweep of tools/diag_fuzz.py
         kinds = ["all", "no_glass", "plain"]
         sets = [("fuzz %d" % k, _random_scene(k, False, 0, materials=kinds[k % 3])) for k in range(40)]

@@ -93,3 +93,14 @@ def test_diag_full_size_tile_cones_zero_violations():
     _no_violations(recs)
     path = [r for r in recs if r["integrator"] == "path" and "skipped" not in r]
     assert {r["kernel"] for r in path} == {"pt_render_tiles", "pt_render_tiles_tri"} and len(path) == 3
+
+
+def test_diag_rooms_beyond_the_staging_budget_zero_violations():
+    """rooms of 257 .. 1,508 spheres: the pooled body with geometry from memory and the filter table by scalar loads"""
+    recs = _run("rooms")
+    _no_violations(recs)
+    path = [r for r in recs if r["integrator"] == "path" and "skipped" not in r]
+    assert len(path) == 3 and {r["kernel"] for r in path} == {"pt_render_tiles_pool_mem_s"}
+    assert all(r["walls_pruned"] > 0 for r in path)   # the six walls lead these rooms too: pruned among themselves here as well
+    for r in path:
+        assert 0 < r["candidates"] < r["casts"] * r["n_primitives"] // 4, r

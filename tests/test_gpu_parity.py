@@ -416,6 +416,25 @@ def test_device_math_shortcuts_are_bit_exact(gpu):
     # ... and of either sign: intersect_triangle's 1.0 / a (exact_triangle<.., UNSCALED>), |a| >= 1e-8
     z = np.concatenate([-y, 10.0 ** rng.uniform(-8, 36, 200000) * rng.choice([-1.0, 1.0], 200000), np.array([1e-8, -1e-8, -3.0])])
     assert np.array_equal(run(5, z, z), 1.0 / z), "unscaled reciprocal of a negative value differs from IEEE division"
+    # atan2_tab (M_CHECKERED's texture coordinate, raytracer.c:410): bit for bit the numpy statement of the same fdlibm
+    # algorithm, and within two ulps of the host's atan2 (glibc through numpy) -- on unit normals, which is what the kernels
+    # pass, on wide-ranging arguments, and on the axis / zero / sign-of-zero cases
+    from util import fdlibm_atan2
+    nrm = rng.normal(size=(400000, 3))
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    ya = np.concatenate([nrm[:, 0], rng.normal(size=200000) * 10.0 ** rng.uniform(-12, 12, 200000),
+                         np.array([0.0, -0.0, 1.0, -1.0, 0.0, -0.0, 0.0, -0.0, 1e-300, 1.0, 1.0, 0.4375, 0.6875, 1.1875, 2.4375, -2.4375])])
+    xa = np.concatenate([nrm[:, 2], rng.normal(size=200000) * 10.0 ** rng.uniform(-12, 12, 200000),
+                         np.array([1.0, 1.0, 0.0, -0.0, -1.0, -1.0, -0.0, 0.0, 1.0, 1e300, -1e300, 1.0, 1.0, 1.0, 1.0, -1.0])])
+    got = run(6, ya, xa)
+    assert np.array_equal(got.view(np.uint64), fdlibm_atan2(ya, xa).view(np.uint64)), "atan2_tab is not the fdlibm algorithm it states"
+    want = np.arctan2(ya, xa)
+    assert (np.abs(got - want) <= 2.0 * np.spacing(np.abs(want))).all() and np.array_equal(np.signbit(got), np.signbit(want))
+    assert (got == want).mean() > 0.8
+    # frac1(x) = fmod(x, 1.0), exactly: texture coordinates times the checker's 1e5 (or 10), either sign, and the edges
+    fa = np.concatenate([rng.uniform(-1, 2, 300000) * 100000.0, rng.uniform(-1, 2, 100000) * 10.0, 10.0 ** rng.uniform(-300, 300, 100000),
+                         np.array([0.0, -0.0, 0.5, 1.0, -1.0, 1.5, -1.5, 2.0 ** 52, 2.0 ** 52 + 1.0, 4503599627370495.5])])
+    assert np.array_equal(run(7, fa, fa).view(np.uint64), np.fmod(fa, 1.0).view(np.uint64)), "frac1 differs from fmod(x, 1)"
 
 
 def _random_scene(seed, with_mesh, n_tris, extra_flags=(), materials="all"):
@@ -856,6 +875,43 @@ def test_many_spheres_beyond_the_lds_staging_budget(gpu, pt):
     meshes = [dict(flags=abi.M_REFLECTION, color=(0.9, 0.9, 0.9), triangles=tri)]
     _full(gpu, pt, S.custom_scene(objs, 40, 24, 2, 4, (0, 6, 45), (0, 2, 0), meshes=meshes))
     _full(gpu, pt, S.custom_scene(objs, 40, 24, 2, 3, (0, 6, 45), (0, 2, 0), meshes=meshes), integrator="whitted")
+
+
+def test_rooms_of_more_than_256_spheres_take_the_pooled_body(gpu, pt):
+    """The 257th sphere used to drop a scene onto the static in-memory kernel; now the pooled body runs with geometry
+    and materials read from memory (pt_render_tiles_pool_mem*).  Rooms packed as the reference's
+    generate_random_spheres() (main.c:65-138) would: on both sides of the staging budget, with sample chunks and a
+    tile partition (bit-identical), and -- with its M_REFRACTION spheres kept -- the static kernel that such scenes
+    still need"""
+    import torch
+    from util import packed_room
+    sc = packed_room(60, 1, 72, 40, 6, 8)            # 68 spheres (6.5 KB of geometry + materials): staged in LDS
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name() == "pt_render_tiles"
+    gs.close()
+    _full(gpu, pt, sc)
+    # beyond ~85 spheres a sphere-only scene is streamed although it would fit the staging budget (pt_prefer_streaming)
+    for n, seed in ((100, 5), (248, 1), (249, 2), (700, 3)):
+        sc = packed_room(n, seed, 72, 40, 6, 8)
+        gs = gpu.GpuScene(sc)
+        assert gs.kernel_name() == "pt_render_tiles_pool_mem_s", gs.kernel_name()
+        total = gpu.n_tiles(sc.width, sc.height)
+        ref_t, ref_t8, ref_s = gs.render_tiles(SEED, 0, 1, total)
+        t, t8, st = gs.render_tiles(SEED, 0, 1, total, chunks=3)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref_t) and torch.equal(t8, ref_t8) and torch.equal(st, ref_s)
+        first, stride, count = gpu.rank_tiles(sc.width, sc.height, 1, 3)
+        p, p8, _ = gs.render_tiles(SEED, first, stride, count)
+        torch.cuda.synchronize()
+        assert torch.equal(p, ref_t[first::stride][:count]) and torch.equal(p8, ref_t8[first::stride][:count])
+        gs.close()
+        st = _full(gpu, pt, sc)
+        assert st["tests"] == st["casts"] * (n + 8)
+    sc = packed_room(300, 4, 56, 32, 4, 6, glass=True)
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name() == "pt_render_tiles_mem"
+    gs.close()
+    _full(gpu, pt, sc, hdr=True)
 
 
 def test_many_samples_per_pixel(gpu, pt):

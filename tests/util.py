@@ -253,3 +253,85 @@ def walls_scene(seed, width=72, height=44, samples=6, with_mesh=False):
             tris.append([tuple(b), tuple(b + rng.normal(size=3) * 0.7), tuple(b + rng.normal(size=3) * 0.7)])
         meshes = [dict(flags=abi.M_DEFAULT, color=(0.7, 0.8, 0.5), triangles=tris)]
     return S.custom_scene(objs, width, height, samples, 6, tuple(cam), tuple(rng.uniform(-1, 1, 3)), meshes=meshes)
+
+
+def packed_room(n_packed, seed=1, width=1920, height=1080, samples=64, max_depth=16, glass=False):
+    """config 4's room -- six wall-sized spheres, the ceiling light and the small magenta light, camera (0, 0, 50) --
+    with `n_packed` spheres packed into it the way the reference's generate_random_spheres() (main.c:65-138) packs its 30:
+    rejection sampling of non-overlapping spheres in the room's box with its material lottery (half emitters with a random
+    colour, a fifth mirrors, a fifth glass, the rest white diffuse).  Radii are scaled by (30 / n)^(1/3) from its 2..8 so
+    that any count fits; glass=False turns its M_REFRACTION spheres into diffuse ones (scenes with M_REFRACTION take
+    the static kernels).  -> scene with 8 + n_packed spheres"""
+    from rt_amd import abi, scene as S
+    room = S.build_scene(4, width, height, samples)
+    objs = []
+    for i in range(8):   # walls and lights lead config 4's object array (host/scenes.c: build_room_walls, build_room_lights)
+        o = room.objects[i]
+        objs.append(dict(flags=int(o.flags), radius=float(o.radius), center=o.center.tuple(), color=o.color.tuple(),
+                         emission=o.emission.tuple()))
+    assert all(o["radius"] >= 1000 for o in objs[:6])
+    rng = np.random.default_rng(4000 + seed)
+    scale = min(1.0, (30.0 / max(n_packed, 1)) ** (1.0 / 3.0))
+    aspect = width / height
+    lo = np.array([-20.0 * aspect, -20.0, -30.0]) * 0.95
+    hi = np.array([20.0 * aspect, 20.0, 30.0]) * 0.95
+    cen = np.zeros((n_packed, 3))
+    rad = np.zeros(n_packed)
+    k = 0
+    while k < n_packed:
+        r = rng.uniform(2.0, 8.0) * scale
+        c = rng.uniform(lo + r, hi - r)
+        if k and (np.linalg.norm(cen[:k] - c, axis=1) < rad[:k] + r).any():
+            continue
+        cen[k], rad[k] = c, r
+        k += 1
+    for k in range(n_packed):
+        u = rng.random()
+        flags, color, emission = abi.M_DEFAULT, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)
+        if u < 0.5:
+            emission = tuple(rng.random(3))
+        elif u > 0.8:
+            flags = abi.M_REFRACTION if glass else abi.M_DEFAULT
+        elif u > 0.6:
+            flags = abi.M_REFLECTION
+        objs.append(dict(flags=int(flags), radius=float(rad[k]), center=tuple(cen[k]), color=color, emission=emission))
+    room.free()
+    return S.custom_scene(objs, width, height, samples, max_depth, (0, 0, 50), (0, 0, 0))
+
+
+def fdlibm_atan2(y, x):
+    """numpy statement of the kernels' atan2_tab (pt_kernel.hip): fdlibm's e_atan2.c / s_atan.c with one division for all
+    five reduction intervals, every operation unfused and in the same order -- so the device must agree BIT FOR BIT"""
+    aT = [3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
+          9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
+          4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02]
+    hi = np.array([4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00])
+    lo = np.array([2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17])
+    pi, pi_lo = 3.1415926535897931160e+00, 1.2246467991473531772e-16
+    y = np.asarray(y, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    ay, ax = np.abs(y), np.abs(x)
+    with np.errstate(all="ignore"):
+        q = np.where(ay == 0.0, 0.0, ay / ax)
+        idv = np.full(q.shape, 3)
+        num = np.full(q.shape, -1.0)
+        den = q.copy()
+        for lim, k, n_, d_ in ((2.4375, 2, q - 1.5, 1.0 + 1.5 * q), (1.1875, 1, q - 1.0, q + 1.0), (0.6875, 0, 2.0 * q - 1.0, 2.0 + q),
+                               (0.4375, -1, q, np.ones_like(q))):
+            m = q < lim
+            idv = np.where(m, k, idv)
+            num = np.where(m, n_, num)
+            den = np.where(m, d_, den)
+        xr = num / den
+        z = xr * xr
+        w = z * z
+        s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))))
+        s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))))
+        k = np.maximum(idv, 0)
+        t = xr * (s1 + s2)
+        r = np.where(idv < 0, xr - t, hi[k] - ((t - lo[k]) - xr))
+        x_neg = np.signbit(x) & ((ax != 0.0) | (ay == 0.0))
+        y_neg = np.signbit(y)
+        left = np.where(y_neg, (r - pi_lo) - pi, pi - (r - pi_lo))
+        right = np.where(y_neg, -r, r)
+        return np.where(x_neg, left, right)
