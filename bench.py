@@ -708,6 +708,8 @@ def main():
                     help="skip the same-run parity blocks (the CPU baseline is still timed; its pixels are thrown away)")
     ap.add_argument("--c5-spp", type=int, default=0,
                     help="spp of config 5 in the per-configuration array (0 = its own 4096: ~4 s a frame on one GPU)")
+    ap.add_argument("--integrators-only", action="store_true",
+                    help="dev: only the `integrators` entries (glass scene, cast_ray), one JSON line, no CPU legs")
     ap.add_argument("--host-path", action="store_true",
                     help="single process: time rt_hip_render_image() over --gpus devices (the C host's path) and exit")
     args = ap.parse_args()
@@ -715,6 +717,11 @@ def main():
         return host_path_main(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args.gpus)   # plain `python bench.py --gpus N`: start the ranks ourselves
+    if args.integrators_only:
+        import torch
+        dev = torch.device("cuda", 0)
+        print(json.dumps({"integrators": [integrator_line(k, dev) for k in ("glass", "cast_ray")]}), flush=True)
+        return 0
 
     import torch
     import torch.distributed as dist
