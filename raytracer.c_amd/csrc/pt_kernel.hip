@@ -2903,6 +2903,12 @@ struct WalkStack
 {
   uint16_t *lo; /* [levels][PT_BLOCK] */
   uint8_t *hi;  /* [levels][PT_BLOCK] */
+#ifdef PT_BVH_WIDE
+  /* the four-wide walk can hold three entries per level: those beyond the LDS array's `cap` levels (rare) go to an
+   * overflow area behind the wave's ring in the workspace, [entry][lane], read and written by the owning lane only */
+  uint32_t cap;
+  uint32_t *ovf;
+#endif
 };
 #define PT_WALK_LEAF_FLAG24 0x800000u
 __device__ __forceinline__ uint32_t walk_ref24(uint32_t ref) /* PT_BVH_LEAF_FLAG (bit 31) moves to bit 23 */
@@ -2912,14 +2918,81 @@ __device__ __forceinline__ uint32_t walk_ref24(uint32_t ref) /* PT_BVH_LEAF_FLAG
 __device__ __forceinline__ uint32_t walk_ref32(uint32_t r24) { return (r24 & 0x7FFFFFu) | ((r24 & PT_WALK_LEAF_FLAG24) << 8); }
 __device__ __forceinline__ void walk_push(const WalkStack &st, uint32_t sp, uint32_t ref)
 {
+#ifdef PT_BVH_WIDE
+  if (sp >= st.cap)
+  { /* (L1-bypassing both ways, like every access to the workspace) */
+    __hip_atomic_store(st.ovf + (size_t)min(sp - st.cap, 31u) * 64u + (threadIdx.x & 63u), ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+#endif
   const uint32_t r = walk_ref24(ref);
   st.lo[sp * PT_BLOCK + threadIdx.x] = (uint16_t)r;
   st.hi[sp * PT_BLOCK + threadIdx.x] = (uint8_t)(r >> 16);
 }
 __device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp)
 {
+#ifdef PT_BVH_WIDE
+  if (sp >= st.cap)
+    return __hip_atomic_load(st.ovf + (size_t)min(sp - st.cap, 31u) * 64u + (threadIdx.x & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   return walk_ref32((uint32_t)st.lo[sp * PT_BLOCK + threadIdx.x] | ((uint32_t)st.hi[sp * PT_BLOCK + threadIdx.x] << 16));
 }
+
+#ifdef PT_BVH_WIDE
+/* One visit of the four-wide walk: the boxes of node `ref`'s (up to) four children against the ray -- the binary visit's
+ * slab test, bounds and NaN rules (bvh_test_children), two children per packed instruction.  Leaves the nearest hit child in
+ * `ref` and pushes the others; -> false when no child is hit (the caller pops or finishes). */
+__device__ __forceinline__ bool bvhw_visit(const float *__restrict__ wnodes, uint32_t &ref, const BvhRay &R, bool far_origin, float tmax,
+                                           const WalkStack &stack, uint32_t &sp)
+{
+  const float widen = 6.0f * 5.9604644775390625e-08f;
+  const float4 *node = reinterpret_cast<const float4 *>(wnodes + PT_BVHW_NODE_WORDS * (size_t)ref);
+  const float4 xl = node[0], xh = node[1], yl = node[2], yh = node[3], zl = node[4], zh = node[5], rr = node[6];
+  /* (lo, hi) planes of children (0, 1) and (2, 3) */
+  const f32x2 ax1 = (f32x2{xl.x, xl.y} - R.ox) * R.ix, ax2 = (f32x2{xh.x, xh.y} - R.ox) * R.ix;
+  const f32x2 bx1 = (f32x2{xl.z, xl.w} - R.ox) * R.ix, bx2 = (f32x2{xh.z, xh.w} - R.ox) * R.ix;
+  const f32x2 ay1 = (f32x2{yl.x, yl.y} - R.oy) * R.iy, ay2 = (f32x2{yh.x, yh.y} - R.oy) * R.iy;
+  const f32x2 by1 = (f32x2{yl.z, yl.w} - R.oy) * R.iy, by2 = (f32x2{yh.z, yh.w} - R.oy) * R.iy;
+  const f32x2 az1 = (f32x2{zl.x, zl.y} - R.oz) * R.iz, az2 = (f32x2{zh.x, zh.y} - R.oz) * R.iz;
+  const f32x2 bz1 = (f32x2{zl.z, zl.w} - R.oz) * R.iz, bz2 = (f32x2{zh.z, zh.w} - R.oz) * R.iz;
+  float tn[4], tf[4];
+  tn[0] = hw_max3(hw_min(ax1.x, ax2.x), hw_min(ay1.x, ay2.x), hw_min(az1.x, az2.x));
+  tf[0] = hw_min3(hw_max(ax1.x, ax2.x), hw_max(ay1.x, ay2.x), hw_max(az1.x, az2.x));
+  tn[1] = hw_max3(hw_min(ax1.y, ax2.y), hw_min(ay1.y, ay2.y), hw_min(az1.y, az2.y));
+  tf[1] = hw_min3(hw_max(ax1.y, ax2.y), hw_max(ay1.y, ay2.y), hw_max(az1.y, az2.y));
+  tn[2] = hw_max3(hw_min(bx1.x, bx2.x), hw_min(by1.x, by2.x), hw_min(bz1.x, bz2.x));
+  tf[2] = hw_min3(hw_max(bx1.x, bx2.x), hw_max(by1.x, by2.x), hw_max(bz1.x, bz2.x));
+  tn[3] = hw_max3(hw_min(bx1.y, bx2.y), hw_min(by1.y, by2.y), hw_min(bz1.y, bz2.y));
+  tf[3] = hw_min3(hw_max(bx1.y, bx2.y), hw_max(by1.y, by2.y), hw_max(bz1.y, bz2.y));
+  const uint32_t r[4] = {__float_as_uint(rr.x), __float_as_uint(rr.y), __float_as_uint(rr.z), __float_as_uint(rr.w)};
+  bool hit[4];
+  float near_d = __builtin_inff();
+  int near_c = -1;
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+  {
+    const float n_ = tn[c] - fabsf(tn[c]) * widen, f_ = tf[c] + fabsf(tf[c]) * widen;
+    /* (a missing child has an inverted box; far origins keep every REAL child) */
+    hit[c] = r[c] != PT_BVHW_EMPTY && (far_origin || (f_ >= n_ && f_ >= 0.0f && n_ <= tmax));
+    if (hit[c] && (near_c < 0 || n_ < near_d))
+    {
+      near_d = n_;
+      near_c = c;
+    }
+  }
+  if (near_c < 0)
+    return false;
+#pragma unroll
+  for (int c = 3; c >= 0; c--) /* (the others wait, in reverse child order) */
+    if (hit[c] && c != near_c)
+    {
+      walk_push(stack, sp, r[c]);
+      sp++;
+    }
+  ref = r[near_c];
+  return true;
+}
+#endif
 
 /* The wave walks the n_new parked rays at ring positions first, first + 1, ... (see the header
  * comment): refill, then either one node visit for the lanes that hold an inner node or the exact
@@ -3003,6 +3076,18 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
 #ifdef PT_DIAG
         visits++;
 #endif
+#ifdef PT_BVH_WIDE
+        if (!bvhw_visit(S.bvh_nodes + pt_bvhw_offset_words(S.n_bvh_nodes), ref, R, far_origin, wtmax, stack, sp))
+        {
+          if (sp == 0)
+            finished = true;
+          else
+          {
+            sp--;
+            ref = walk_pop(stack, sp);
+          }
+        }
+#else
         bool hit0, hit1;
         float tn0, tn1;
         uint32_t r0, r1;
@@ -3023,6 +3108,7 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
           sp--;
           ref = walk_pop(stack, sp);
         }
+#endif
       }
     }
     else if (at_leaf)
@@ -3153,6 +3239,10 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     stack.lo = reinterpret_cast<uint16_t *>(lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
                                                    pt_filt_pair_slots(S.n_sph)));
     stack.hi = reinterpret_cast<uint8_t *>(stack.lo + (size_t)levels * PT_BLOCK);
+#ifdef PT_BVH_WIDE
+    stack.cap = levels; /* the LDS array keeps the binary walk's size; deeper entries overflow (WalkStack) */
+    stack.ovf = nullptr; /* set below, once the wave's ring is known */
+#endif
   }
   {
     unsigned long long *z = &pix_sum_all[0][0];
@@ -3204,6 +3294,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     ring.f = reinterpret_cast<double *>(base);
     ring.u = reinterpret_cast<uint32_t *>(base);
   }
+#ifdef PT_BVH_WIDE
+  stack.ovf = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ring.f) + PT_PARK_Q * 128u + 512u);
+#endif
   /* can a camera ray of this wave's tile reach the triangles' bounding ball at all?  (tile_cull's cone test, for the probe's
    * own ball: its r2_hi is the radius squared plus the filter's widening, far more than the centre's rounding to fp32) */
   const bool tile_sees_mesh =
@@ -4115,6 +4208,30 @@ extern "C" __global__ __launch_bounds__(256) void pt_build_bvh(const double *bvh
   }
 }
 
+/* PT_BVH_WIDE builds: the four-wide device nodes for one near_R -- the same widening and outward rounding as pt_build_bvh,
+ * planes grouped per axis: x lo of children 0..3, x hi, y lo, y hi, z lo, z hi, then the four references. */
+extern "C" __global__ __launch_bounds__(256) void pt_build_bvh_wide(const double *src_nodes, uint32_t n_nodes, double near_R, float *nodes)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x)
+  {
+    const double *src = src_nodes + PT_BVHW_SRC_DOUBLES * (size_t)i;
+    float *dst = nodes + PT_BVHW_NODE_WORDS * (size_t)i;
+    const double e = 5.9604644775390625e-08;
+    for (int c = 0; c < 4; c++)
+      for (int k = 0; k < 3; k++)
+      {
+        const double lo = src[6 * c + k], hi = src[6 * c + 3 + k];
+        const bool none = lo > hi; /* no child: the box stays inverted */
+        dst[8 * k + c] = none ? 3.0e38f : __double2float_rd(lo - 4.0 * e * (near_R + fabs(lo)));
+        dst[8 * k + 4 + c] = none ? -3.0e38f : __double2float_ru(hi + 4.0 * e * (near_R + fabs(hi)));
+      }
+    const uint32_t *refs = reinterpret_cast<const uint32_t *>(src + 24);
+    for (int c = 0; c < 4; c++)
+      dst[24 + c] = __uint_as_float(refs[c]);
+    dst[28] = dst[29] = dst[30] = dst[31] = 0.f;
+  }
+}
+
 /* HULL FACETS (scene creation, once): triangle F is one if every corner p of every triangle of the scene has
  * m . (p - v0_F) <= tau for m = +n_F (PT_HULL_PLUS: the stored normal points outward) or m = -n_F (PT_HULL_MINUS).
  * What it buys (render_tiles_queued): a ray that starts at a hit point on F -- within delta of F's plane -- with
@@ -4380,6 +4497,9 @@ hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float
   if (n_nodes)
     hipLaunchKernelGGL(pt_build_bvh, dim3(min(1024u, (n_nodes + 255u) / 256u)), dim3(256), 0, stream, scene.bvh_src,
                        n_nodes, near_R, bvh_nodes);
+  if (scene.n_bvhw_nodes) /* PT_BVH_WIDE builds */
+    hipLaunchKernelGGL(pt_build_bvh_wide, dim3(min(1024u, (scene.n_bvhw_nodes + 255u) / 256u)), dim3(256), 0, stream, scene.bvhw_src,
+                       scene.n_bvhw_nodes, near_R, bvh_nodes + pt_bvhw_offset_words(n_nodes));
   /* the pre-test table behind the pair table: in scan order for small scenes (staged in LDS with the pairs), in the
    * hierarchy's leaf order for large meshes (read from HBM at the leaves) */
   if (scene.n_triangles != 0 && (pt_filter_in_lds(scene) || n_nodes != 0))
