@@ -25,10 +25,22 @@ The JSON line also carries
                 committed PMC pass of this configuration (profiles/pmc_c<N>.json);
   roofline_hbm  the same launch against the HBM roof (reported because the north star asks
                 for it; ~1e-5 by construction);
+                `frac_executed` prices the arithmetic the kernels' own algorithm executes (lane-level
+                event counts of a committed PT_DIAG pass x flops per event, fp64 and fp32 each at its pipe's
+                rate: EXEC_FLOPS), `frac_valu_lanes` = VALU busy x lanes active (the hardware-true share);
+                PMC / PT_DIAG / ISA figures come from committed files under profiles/ and are reported only
+                while the sha256 of the kernel sources they were measured on is today's and (PMC) the kernel
+                time agrees within 3 % -- otherwise null with pmc_stale / diag_stale / isa_stale;
   cpu_baseline  the reference's own compiled trace_path()/intersect() (oracle/_ref) timed on
                 this host's cores over a bounded sample of the same frame (rank 0, N = 1 only);
-  configs       (N = 1) the other BASELINE configurations on the same GPU: 1, 2, 3 at full size,
-                5 at a stated reduced spp -- ms per frame, ray-bounces/s, kernel, model fraction;
+  parity        (N = 1) the pixels that CPU leg rendered -- 2,048 tiles at the full 1024 spp -- against the
+                frame the timed steps produced: per-channel RMS, max |diff|, tonemapped-byte difference, and
+                rays / ray-bounces of that subset equal to a GPU re-render of exactly those tiles; the run
+                exits non-zero when it fails (north star: "within 1e-4 per-channel RMS ... in the same run");
+  configs       (N = 1) the other BASELINE configurations on the same GPU, all at their own sizes --
+                ms per frame, ray-bounces/s, kernel, fractions, and a parity block each;
+  integrators   (N = 1) trace_path's M_REFRACTION branch (a glass scene) and cast_ray, 1920x1080, with
+                kernel, registers / scratch, and a parity block each;
   phase_ms, ranks_seen, rank_kernel_ms, host_path   (N > 1) where a frame's time goes, how many
                 ranks RCCL really connected, and the single-process C path
                 (rt_hip_render_image over N devices) timed in a child process.
@@ -185,7 +197,7 @@ def committed_pmc(config, width, height, spp, world, any_spp=False):
 def pmc_keys(pmc, spp, kernel_ms=None):
     """hardware-true figures of a configuration's dominant kernel from its committed PMC pass -- or nulls with
     `pmc_stale` when that pass no longer describes the kernel timed now (pmc_is_stale)"""
-    empty = {"valu_busy": None, "lane_utilisation": None, "valu_instr_per_64_bounces": None, "traffic": None,
+    empty = {"valu_busy": None, "lane_utilisation": None, "frac_valu_lanes": None, "valu_instr_per_64_bounces": None, "traffic": None,
              "pmc_source": None}
     if not pmc:
         return empty
@@ -196,6 +208,8 @@ def pmc_keys(pmc, spp, kernel_ms=None):
     same = pmc["spp"] == spp
     src = pmc.get("source", pmc["file"])
     return {"valu_busy": pmc.get("valu_busy"), "lane_utilisation": pmc.get("lane_utilisation"),
+            "frac_valu_lanes": (min(pmc["valu_busy"], 1.0) * pmc["lane_utilisation"]) if pmc.get("valu_busy") is not None and
+                               pmc.get("lane_utilisation") is not None else None,   # issue busy x lanes active: the hardware-true fraction
             "valu_instr_per_64_bounces": pmc.get("valu_instr_per_64_bounces"),
             # HBM bytes per launch; a pass at another spp is scaled by the sample count (ring / table traffic is per ray)
             "traffic": pmc["traffic_bytes_per_launch"] * (1.0 if same else spp / pmc["spp"]),
@@ -868,6 +882,10 @@ def main():
                          "valu_busy_note": "per-wave quad-cycles over the cycles of the same PMC pass; overlapping waves on a SIMD "
                                            "can push the raw ratio past 1, so valu_busy is capped at 1 (= VALU issue saturated)",
                          "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
+                         # the hardware-true fraction: the share of the VALU's lane-slots that did work (issue busy x lanes
+                         # active), whatever the instructions were -- fp64, packed fp32, the RNG's integer ops, selects
+                         "frac_valu_lanes": (min(pmc["valu_busy"], 1.0) * pmc["lane_utilisation"]) if pmc and pmc.get("valu_busy") is not None
+                                            and pmc.get("lane_utilisation") is not None else None,
                          "valu_instr_per_64_bounces": pmc.get("valu_instr_per_64_bounces") if pmc else None,
                          "source": pmc_source, "pmc_stale": bool(pmc_stale), "pmc_stale_reason": pmc_stale_reason,
                          "note": "branchy fp64 scalar-per-lane math: neither HBM nor MFMA binds it "
