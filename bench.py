@@ -83,8 +83,8 @@ def kernel_source_sha256():
 def pmc_is_stale(pmc, kernel_ms, spp, source_sha=None):
     """-> None if the committed PMC record still describes the kernel that was just timed, else the reason.
     Two checks: the record's source hash must be today's (a kernel edit without a re-profile), and the kernel time
-    of the PMC pass must agree with the time measured now -- within 3 % at the same spp, within 8 % per sample when
-    the pass ran at another spp (frame time is not exactly linear in spp)."""
+    of the PMC pass must agree with the time measured now -- within 3 % (+ 20 us) at the same spp, within 8 % per sample
+    when the pass ran at another spp (frame time is not exactly linear in spp)."""
     if not pmc:
         return None
     have = pmc.get("source_sha256")
@@ -98,8 +98,10 @@ def pmc_is_stale(pmc, kernel_ms, spp, source_sha=None):
         tol, ref = 0.03, ms
     else:
         tol, ref = 0.08, ms * spp / pmc["spp"]
-    if abs(kernel_ms - ref) > tol * ref:
-        return f"kernel time now {kernel_ms:.3f} ms vs {ref:.3f} ms in the PMC pass (more than {tol:.0%} apart)"
+    # (+ 20 microseconds: a sub-millisecond kernel's time moves by that much with the clock's ramp from one process to the
+    # next -- config 2's 0.88 ms measured 0.872 ... 0.895 within one session)
+    if abs(kernel_ms - ref) > tol * ref + 0.02:
+        return f"kernel time now {kernel_ms:.3f} ms vs {ref:.3f} ms in the PMC pass (more than {tol:.0%} + 0.02 ms apart)"
     return None
 
 

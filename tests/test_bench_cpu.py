@@ -73,7 +73,11 @@ def test_committed_pmc_records_are_tied_to_the_kernel_sources():
     keys = bench.pmc_keys(rec, 1024, 204.0)
     assert keys["pmc_stale"] is False and keys["valu_busy"] == 1.0 and keys["traffic"] == 3.5e7
     # stale by time: the kernel got faster (or slower) by more than 3 % since the pass
+    assert bench.pmc_is_stale(rec, 206.1, 1024) is not None and bench.pmc_is_stale(rec, 193.9, 1024) is not None
     assert "kernel time" in bench.pmc_is_stale(rec, 190.0, 1024)
+    # sub-millisecond kernels get 20 microseconds of clock-ramp noise on top of the 3 %
+    short = dict(rec, kernel_ms=0.872, spp=64)
+    assert bench.pmc_is_stale(short, 0.895, 64) is None and bench.pmc_is_stale(short, 0.93, 64) is not None
     keys = bench.pmc_keys(rec, 1024, 190.0)
     assert keys["pmc_stale"] is True and keys["valu_busy"] is None and keys["traffic"] is None and "kernel time" in keys["pmc_stale_reason"]
     # stale by source: any edit of the kernel sources
