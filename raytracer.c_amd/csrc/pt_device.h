@@ -103,6 +103,14 @@
 #define PT_REFRACT_MAX_DEPTH 32 /* the pending-ray stacks of the two-child kernels hold max_depth + 2 entries (a pool in global memory
                                  * sized by the launch: 20 KB per entry and resident workgroup) */
 #define PT_PEND_FIELDS_HOST 10u /* doubles per pending ray: o, d, T, depth (pt_kernel.hip: PT_PEND_FIELDS) */
+#define PT_PEND_COLUMNS 512u /* stacks per pool slot: the static body uses one per lane (256), the pooled refraction kernel 128 per wave */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline bool pt_refr_pool_fits(int32_t samples, int32_t max_depth)
+{ /* pt_kernel.hip, win_add: samples x 2^(max_depth + 2) <= 2^30 */
+  return max_depth + 2 <= 30 && ((int64_t)samples << (max_depth + 2)) <= ((int64_t)1 << 30);
+}
 #define PT_PEND_SLOTS_PER_XCD 128u /* 32 CUs x at most 3-4 resident workgroups of the static-body kernels, with slack */
 
 #define PT_FLAG_DIFFUSE 2u
@@ -278,7 +286,7 @@ struct PtLaunch
   double *pend_ws;
   uint32_t *pend_flags;
   uint32_t pend_slots_per_xcd, pend_entries;
-  uint64_t pend_slot_doubles;
+  uint64_t pend_slot_doubles; /* = pend_entries x 10 fields x PT_PEND_COLUMNS */
   unsigned long long *acc_ws;        /* sample_chunks > 1: tile_count x 192 fixed-point sums, then tile_count x 3 NaN masks */
   float *tiles_rgb;
   uint8_t *tiles_rgb8;

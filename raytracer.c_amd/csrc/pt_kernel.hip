@@ -320,6 +320,15 @@ __device__ __forceinline__ double rcp_unscaled(double x)
   return __builtin_fma(rem, r, q);
 }
 
+/* the same double for |a|^2 in [1e-200, 1e200] through the expansions without their range scaling (sqrt_unscaled, rcp_unscaled:
+ * the same instructions on the same values; start_sample normalises the camera ray this way), the library forms otherwise:
+ * ~25 instructions fewer where the vector is known to be of ordinary length -- the two children of an M_REFRACTION hit */
+__device__ __forceinline__ V3 v_normalize_fast(V3 a)
+{
+  const double aa = v_dot(a, a);
+  return (aa >= 1e-200 && aa <= 1e200) ? v_scale(a, rcp_unscaled(sqrt_unscaled(aa))) : v_scale(a, 1.0 / sqrt(aa));
+}
+
 /* intersect_sphere :82-117, exact.  Updates (min_t, best) with strict <. */
 __device__ __forceinline__ void exact_sphere(const double *g, uint32_t index, const V3 &o, const V3 &d,
                                              double &min_t, int &best)
@@ -1614,25 +1623,154 @@ struct Path
 static_assert(PT_PEND_FIELDS == PT_PEND_FIELDS_HOST, "pending-ray record");
 struct PendStack
 {
-  double *base;    /* this lane's column of the workgroup's slot (nullptr in kernels without a stack) */
+  double *base;    /* this lane's (static body) or this path's (pooled body) first double (nullptr in kernels without a stack) */
   int capacity;    /* entries */
+  /* doubles from one field / one entry to the next.  Static body: [entry][field][PT_BLOCK lanes] (a wave's push of a field is
+   * one coalesced access).  Pooled body (pt_render_tiles_refr_pool): a path's stack moves with the path between lanes, so it
+   * is addressed by the path's id, [id][entry][field]: 80 contiguous bytes per pending ray */
+  uint32_t field_stride, entry_stride;
   __device__ __forceinline__ void push(int e, const V3 &o, const V3 &d, const V3 &T, int depth) const
   {
-    double *q = base + (size_t)e * (PT_PEND_FIELDS * PT_BLOCK);
-    q[0 * PT_BLOCK] = o.x; q[1 * PT_BLOCK] = o.y; q[2 * PT_BLOCK] = o.z;
-    q[3 * PT_BLOCK] = d.x; q[4 * PT_BLOCK] = d.y; q[5 * PT_BLOCK] = d.z;
-    q[6 * PT_BLOCK] = T.x; q[7 * PT_BLOCK] = T.y; q[8 * PT_BLOCK] = T.z;
-    q[9 * PT_BLOCK] = __longlong_as_double((long long)depth);
+    double *q = base + (size_t)e * entry_stride;
+    const uint32_t f = field_stride;
+    q[0 * f] = o.x; q[1 * f] = o.y; q[2 * f] = o.z;
+    q[3 * f] = d.x; q[4 * f] = d.y; q[5 * f] = d.z;
+    q[6 * f] = T.x; q[7 * f] = T.y; q[8 * f] = T.z;
+    q[9 * f] = __longlong_as_double((long long)depth);
   }
   __device__ __forceinline__ void pop(int e, V3 &o, V3 &d, V3 &T, int &depth) const
   {
-    const double *q = base + (size_t)e * (PT_PEND_FIELDS * PT_BLOCK);
-    o = {q[0 * PT_BLOCK], q[1 * PT_BLOCK], q[2 * PT_BLOCK]};
-    d = {q[3 * PT_BLOCK], q[4 * PT_BLOCK], q[5 * PT_BLOCK]};
-    T = {q[6 * PT_BLOCK], q[7 * PT_BLOCK], q[8 * PT_BLOCK]};
-    depth = (int)__double_as_longlong(q[9 * PT_BLOCK]);
+    const double *q = base + (size_t)e * entry_stride;
+    const uint32_t f = field_stride;
+    o = {q[0 * f], q[1 * f], q[2 * f]};
+    d = {q[3 * f], q[4 * f], q[5 * f]};
+    T = {q[6 * f], q[7 * f], q[8 * f]};
+    depth = (int)__double_as_longlong(q[9 * f]);
   }
 };
+
+/* ---- order-free pixel sums WITHOUT a bound on the terms (pt_render_tiles_refr_pool) -----------------------------------
+ * The pooled kernels add radiance terms to 64-bit fixed-point sums, which needs a bound on a term (throughput <= 1).  Scenes
+ * with M_REFRACTION have none: the reference's fresnel weight reaches 7.3 per hit from inside a sphere, 1 - fresnel -6.3
+ * (raytracer.c:517-529).  Here a pixel channel is PT_WIN_N signed 64-bit words, word k collecting the bits
+ * [PT_WIN_E0 + 32 k, PT_WIN_E0 + 32 k + 32) of every term: a double's 53-bit mantissa is cut -- exactly, by shifts -- into the
+ * (at most three) 32-bit pieces that fall into consecutive words, and each piece is added with an integer LDS atomic.
+ * Integer addition commutes and associates, so the sums do not depend on the order or grouping of terms (any lane / wave /
+ * tile / GPU assignment gives the same words), there is no rounding at all above 2^PT_WIN_E0, and a word overflows only
+ * after 2^31 pieces (the launcher keeps samples x 2^(max_depth + 2) below 2^30).  Range: 2^-64 (bits below are dropped: 5e-20
+ * absolute per term) to 2^128, all a float32 pixel can hold; a term at or above that flags the pixel like a NaN.  (Six words: a
+ * seventh would cost the kernel its fourth workgroup per CU.) */
+#define PT_WIN_N 6
+#define PT_WIN_E0 (-64)
+__device__ __forceinline__ bool win_add(unsigned long long *w, double x)
+{ /* -> false: x is not finite or too large (the caller flags the pixel) */
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+  const int ex = (int)((bits >> 52) & 0x7FFu);
+  if (ex == 0x7FF)
+    return false;
+  const unsigned long long mant = (bits & 0xFFFFFFFFFFFFFull) | (ex ? 0x10000000000000ull : 0ull);
+  /* x = +-mant * 2^(e2), e2 = max(ex, 1) - 1075; its bit 0 sits `sh` bits above the accumulator's origin */
+  const int sh = (ex ? ex : 1) - 1075 - PT_WIN_E0;
+  if (mant == 0ull || sh <= -53)
+    return true; /* zero, or entirely below 2^PT_WIN_E0 */
+  if (sh + 53 > 32 * PT_WIN_N)
+    return false;
+  /* v = mant shifted so that v's bit 0 is bit 0 of word k0 (k0 = floor(sh / 32); sh < 0: the low bits are dropped) */
+  const int k0 = sh >= 0 ? (sh >> 5) : 0;
+  const int r = sh >= 0 ? (sh & 31) : 0;
+  const unsigned long long m = sh >= 0 ? mant : (mant >> (-sh));
+  const unsigned long long lo = m << r;                                /* bits 0..63 of v (m < 2^53, r < 32: bits up to 84) */
+  const unsigned long long hi = r ? (m >> (64 - r)) : 0ull;            /* bits 64.. of v */
+  const long long sgn = (long long)bits < 0 ? -1ll : 1ll;
+  const unsigned long long p0 = lo & 0xFFFFFFFFull, p1 = lo >> 32, p2 = hi; /* p2 < 2^21 */
+  if (p0) atomicAdd(&w[k0], (unsigned long long)(sgn * (long long)p0));
+  if (p1) atomicAdd(&w[k0 + 1], (unsigned long long)(sgn * (long long)p1));
+  if (p2) atomicAdd(&w[k0 + 2], (unsigned long long)(sgn * (long long)p2));
+  return true;
+}
+/* the sum: words combined from the top (each conversion and product is exact up to 2^-53 relative of its own word: the result is
+ * within a few ulps of the exact sum, which is more than the reference's own left-to-right fp64 summation guarantees) */
+__device__ __forceinline__ double win_value(const unsigned long long *w)
+{
+  double v = 0.0;
+#pragma unroll
+  for (int k = PT_WIN_N - 1; k >= 0; k--)
+    v += ldexp((double)(long long)w[k], PT_WIN_E0 + 32 * k);
+  return v;
+}
+
+/* ids of the pending-ray stacks of the pooled refraction kernel: 128 per wave (a wave never holds more than 64 paths in its lanes
+ * and 64 on its waiting list), handed out lazily -- at a path's first M_REFRACTION hit -- from a 128-bit free mask in LDS, by
+ * compare-and-swap: lanes of one wave contend in lock step, one wins per round, and few ask in the same trip */
+__device__ __forceinline__ uint32_t pend_id_take(unsigned long long *free_mask)
+{
+  for (;;)
+  {
+    const unsigned long long m0 = free_mask[0];
+    unsigned long long *word = m0 ? &free_mask[0] : &free_mask[1];
+    const unsigned long long m = m0 ? m0 : free_mask[1];
+    if (m == 0ull)
+      return 0xFFu; /* (cannot happen: 128 ids for at most 128 paths) */
+    const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+    if (atomicCAS(word, m, m & ~(1ull << bit)) == m)
+      return bit + (m0 ? 0u : 64u);
+  }
+}
+__device__ __forceinline__ void pend_id_give(unsigned long long *free_mask, uint32_t id)
+{
+  atomicOr(&free_mask[id >> 6], 1ull << (id & 63u));
+}
+/* the pooled refraction kernel's view of a path's stack: the id is taken at the FIRST push (most paths never meet an
+ * M_REFRACTION surface and never ask), records are [id][entry][field], 80 contiguous bytes */
+struct PoolStack
+{
+  double *wave_base;             /* the wave's 128 stacks in the workgroup's pool slot */
+  unsigned long long *free_mask; /* LDS: the wave's free ids */
+  uint32_t *id;                  /* the path's id (a register of the calling lane), 0xFF: none yet */
+  int capacity;                  /* entries per stack */
+  __device__ __forceinline__ double *rec(int e) const { return wave_base + ((size_t)*id * (uint32_t)capacity + (uint32_t)e) * PT_PEND_FIELDS; }
+  __device__ __forceinline__ void push(int e, const V3 &o, const V3 &d, const V3 &T, int depth) const
+  {
+    if (*id == 0xFFu)
+      *id = pend_id_take(free_mask);
+    double *q = rec(e);
+    q[0] = o.x; q[1] = o.y; q[2] = o.z;
+    q[3] = d.x; q[4] = d.y; q[5] = d.z;
+    q[6] = T.x; q[7] = T.y; q[8] = T.z;
+    q[9] = __longlong_as_double((long long)depth);
+    /* the path may be popped by ANOTHER lane of this wave after a trip through the waiting list: the record is complete in
+     * memory before this lane goes on (s_waitcnt vmcnt(0); pushes are rare) */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
+  __device__ __forceinline__ void pop(int e, V3 &o, V3 &d, V3 &T, int &depth) const
+  {
+    const double *q = rec(e);
+    o = {q[0], q[1], q[2]};
+    d = {q[3], q[4], q[5]};
+    T = {q[6], q[7], q[8]};
+    depth = (int)__double_as_longlong(q[9]);
+  }
+};
+
+/* a slot of a pool of `per` slots per XCD with one in-use flag each (zero between launches) */
+__device__ __forceinline__ uint32_t pt_pool_acquire(uint32_t *flags_base, uint32_t per)
+{
+  if (flags_base == nullptr || per == 0u)
+    return 0xFFFFFFFFu;
+  /* s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, width 4): the XCD this wave runs on */
+  const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+  uint32_t *flags = flags_base + xcc * per;
+  uint32_t i = ((blockIdx.x * 2654435761u) >> 7) % per;
+  for (uint32_t probes = 0; probes < 64u * per; probes++)
+  {
+    if (atomicCAS(&flags[i], 0u, 1u) == 0u)
+      return xcc * per + i;
+    i = (i + 1u == per) ? 0u : i + 1u;
+    if ((probes & 15u) == 15u)
+      __builtin_amdgcn_s_sleep(8);
+  }
+  return 0xFFFFFFFFu;
+}
 
 struct CameraRegs
 {
@@ -1821,9 +1959,9 @@ struct HitRec
  * half only, from *rec (which the caller may have completed with bvh_traverse).
  * DEFER_DIR: a diffuse hit does not sample its direction here; the caller does (HitRec). */
 template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int MODE = 0, bool DEFER_DIR = false,
-          bool SPH_LDS = false, bool FILT_MEM = false>
+          bool SPH_LDS = false, bool FILT_MEM = false, class STK = PendStack>
 __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t &n_casts,
-                                           unsigned long long *diag_ptr, const PendStack &stack, int &stack_n,
+                                           unsigned long long *diag_ptr, const STK &stack, int &stack_n,
                                            HitRec *rec = nullptr, const uint32_t *prim_pairs = nullptr)
 {
   V3 add = {S.bg, S.bg, S.bg}; /* what this call contributes if the path ends here */
@@ -1979,8 +2117,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           const V3 nn = v_scale(n, -1);
           const double coef = 1.0 * 1.0 - (double)sqrtf(1.0f);
           const V3 refr = v_add(v_scale(in, 1.0), v_scale(nn, coef));
-          nd = v_normalize(refr);
-          const V3 refl = v_normalize(v_sub(v_scale(d, 1), v_scale(n, 2 * v_dot(v_scale(d, 1), n))));
+          nd = v_normalize_fast(refr);
+          const V3 refl = v_normalize_fast(v_sub(v_scale(d, 1), v_scale(n, 2 * v_dot(v_scale(d, 1), n))));
           const V3 base = v_mul(P.T, albedo);
           if (stack_n < stack.capacity)
             stack.push(stack_n++, p, refl, v_scale(base, kr), P.depth + 1);
@@ -2268,6 +2406,9 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 #ifndef PT_MIN_WAVES_TRI
 #define PT_MIN_WAVES_TRI 5
 #endif
+#ifndef PT_MIN_WAVES_CHK
+#define PT_MIN_WAVES_CHK 5 /* the M_CHECKERED sphere kernels: 96 VGPRs without scratch since atan2_tab (round 4; 128 before, no bound) */
+#endif
 /* postponed hierarchy walks of the pooled kernels: lanes that make a batch; trips the oldest waits */
 #ifndef PT_MESH_BATCH
 #define PT_MESH_BATCH 32
@@ -2282,15 +2423,23 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 /* Pooled kernel body.  Not for scenes with M_REFRACTION: there the throughput is not bounded
  * by 1 (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes
  * negative), so no fixed-point scale can be fixed in advance; those scenes use the static body. */
-template <bool CHECKER, bool TRIS, bool FILT_LDS, bool GEOM_LDS>
+/* REFR (pt_render_tiles_refr_pool, round 4): scenes with M_REFRACTION on the pooled body.  Two things kept them on the static
+ * body: pixel sums need a bound on a term (here: win_add, order-free without one), and the second child of a refractive hit
+ * waits on a per-lane stack while paths of this body move between lanes (here: the stack is addressed by a path ID that
+ * travels with the path -- PendStack, pend_id_take). */
+template <bool CHECKER, bool TRIS, bool FILT_LDS, bool GEOM_LDS, bool REFR = false>
 __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 {
+  static_assert(!REFR || (CHECKER && !TRIS && FILT_LDS && GEOM_LDS), "the pooled refraction kernel: small staged sphere scenes, every material");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ float out_f[PT_TILE_PIXELS * 3];
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   __shared__ unsigned long long wg_stats[2];
   __shared__ double cam_lds[PT_CAM_LDS_DOUBLES];             /* the camera (camera_to_lds) */
-  __shared__ unsigned long long pix_sum[PT_TILE_PIXELS * 3]; /* fixed-point radiance sums */
+  __shared__ unsigned long long pix_sum[REFR ? 1 : PT_TILE_PIXELS * 3]; /* fixed-point radiance sums */
+  __shared__ unsigned long long pix_win[REFR ? PT_TILE_PIXELS * 3 * PT_WIN_N : 1]; /* REFR: windowed sums without a bound on the terms (win_add) */
+  __shared__ unsigned long long pend_free[REFR ? PT_BLOCK / 64 : 1][2];            /* REFR: per wave, the free ids of its 128 pending-ray stacks */
+  __shared__ uint32_t pend_slot_lds;
   __shared__ unsigned long long pix_nan[3];                  /* per channel: pixels that received a NaN sample */
   __shared__ unsigned long long pix_key[PT_TILE_PIXELS];     /* per-pixel half of the RNG key */
   /* kernels with a triangle hierarchy postpone its walks in the lanes (see the loop): they keep round 2's job
@@ -2342,8 +2491,17 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     wg_next_job = 0;
   if (threadIdx.x < 3)
     pix_nan[threadIdx.x] = 0;
-  if (threadIdx.x < PT_TILE_PIXELS * 3)
+  if (!REFR && threadIdx.x < PT_TILE_PIXELS * 3)
     pix_sum[threadIdx.x] = 0;
+  if (REFR)
+  {
+    for (uint32_t k = threadIdx.x; k < PT_TILE_PIXELS * 3 * PT_WIN_N; k += PT_BLOCK)
+      pix_win[k] = 0;
+    if (threadIdx.x < 2 * (PT_BLOCK / 64))
+      pend_free[threadIdx.x >> 1][threadIdx.x & 1u] = ~0ull;
+    if (threadIdx.x == 0)
+      pend_slot_lds = pt_pool_acquire(L.pend_flags, L.pend_slots_per_xcd);
+  }
   if (threadIdx.x < PT_TILE_PIXELS)
   {
     const uint32_t t0 = L.tile_first + (blockIdx.x % L.tile_count) * L.tile_stride;
@@ -2380,7 +2538,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   /* this workgroup's share of the samples: [s_begin, s_end) of every pixel */
   const uint32_t s_begin = (uint32_t)(((uint64_t)chunk * spp) / L.sample_chunks);
   const uint32_t s_end = (uint32_t)(((uint64_t)(chunk + 1u) * spp) / L.sample_chunks);
-  const uint32_t pool = n_valid * (s_end - s_begin); /* jobs: j -> pixel j % n_valid, sample s_begin + j / n_valid */
+  const uint32_t pool_jobs = n_valid * (s_end - s_begin); /* jobs: j -> pixel j % n_valid, sample s_begin + j / n_valid */
 
   Path P;
   P.o = {0, 0, 0};
@@ -2411,8 +2569,17 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   uint32_t made_jobs = 0;    /* jobs whose camera ray sits in the wave's queue (wave-uniform) */
   uint32_t pix_slot = 0;     /* 0..63 inside the tile */
   bool busy = false;
-  int stack_n = 0; /* no pending-ray stack in this body */
-  const PendStack no_stack = {nullptr, 0};
+  int stack_n = 0; /* REFR: pending second children of this lane's path (else no pending-ray stack in this body) */
+  uint32_t pend_id = 0xFFu; /* REFR: the path's stack id, 0xFF = none yet */
+  const PendStack no_stack = {nullptr, 0, 0u, 0u};
+  /* REFR: this wave's 128 stacks in the workgroup's pool slot, [id][entry][field] (PendStack); no slot (a sizing bug of the
+   * pool, never seen): the tile comes out NaN, as in the static body */
+  const uint32_t pend_slot = REFR ? pend_slot_lds : 0u;
+  const bool pend_ok = !REFR || pend_slot != 0xFFFFFFFFu;
+  const uint32_t pool = pend_ok ? pool_jobs : 0u;
+  double *const pend_wave = REFR && pend_ok ? L.pend_ws + (size_t)pend_slot * L.pend_slot_doubles +
+                                                  (size_t)(threadIdx.x >> 6) * 128u * L.pend_entries * PT_PEND_FIELDS
+                                            : nullptr;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
   const uint32_t lane = threadIdx.x & 63u;
@@ -2458,7 +2625,14 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
           hit.dir_slot = wu[64 + e];
           pix_slot = meta & 63u;
           hit.need_dir = (meta & 64u) != 0u;
-          P.depth = (int)(meta >> 7);
+          P.depth = (int)((meta >> 7) & 63u); /* (max_depth <= 32 in scenes with M_REFRACTION, rt_hip_render_tiles_chunked; others carry no more bits) */
+          if (REFR)
+          {
+            stack_n = (int)((meta >> 13) & 63u);
+            pend_id = (meta >> 19) & 0xFFu;
+          }
+          else
+            P.depth = (int)(meta >> 7);
           busy = true;
         }
         n_wait -= min((uint32_t)__popcll(idle), n_wait);
@@ -2488,7 +2662,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
           wf[9 * 64 + e] = __longlong_as_double((long long)P.rng);
           if (CHECKER)
             wf[(CHECKER ? 10 : 0) * 64 + e] = hit.dir_scale;
-          wu[e] = ((uint32_t)P.depth << 7) | (hit.need_dir ? 64u : 0u) | pix_slot;
+          wu[e] = ((uint32_t)P.depth << 7) | (hit.need_dir ? 64u : 0u) | pix_slot |
+                  (REFR ? (((uint32_t)stack_n << 13) | (pend_id << 19)) : 0u);
           wu[64 + e] = hit.dir_slot;
         }
         n_wait = (uint32_t)__popcll(bm);
@@ -2520,6 +2695,11 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
           pix_slot = row * PT_TILE + col;
           start_sample(P, load_camera_lds(cam_lds), pix_key[pix_slot], tx0 + col, ty0 + row, term);
           hit.need_dir = false;
+          if (REFR)
+          { /* (the lane's previous path gave its id back when it ended, or took it along to the list) */
+            stack_n = 0;
+            pend_id = 0xFFu;
+          }
         }
         primary_trip = FILT_LDS;
       }
@@ -2663,7 +2843,13 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       DIAG(0, 1);      /* wave-level loop iterations */
       DIAG_LANES(1);   /* lanes alive in them */
       n_rays++;
-      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 0, true, false, FILT_LDS && !GEOM_LDS>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit, prim_pairs);
+      if (REFR)
+      {
+        const PoolStack mine = {pend_wave, pend_free[wave], &pend_id, (int)L.pend_entries};
+        step_done = trace_step<1, true, CHECKER, TRIS, FILT_LDS, 0, true, false, false, PoolStack>(S, P, n_casts, diag_ptr, mine, stack_n, &hit, prim_pairs);
+      }
+      else
+        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 0, true, false, FILT_LDS && !GEOM_LDS>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit, prim_pairs);
     }
     PHASE(3); /* hit record, roulette, material */
     /* ---- directions of diffuse hits: PT_DIR_ROUNDS rejection rounds per trip ----
@@ -2707,6 +2893,15 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
        * radiance lives in registers from one trip to the next. */
       if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
+        if (REFR)
+        { /* no bound on a term here: the windowed sums (win_add); a non-finite or oversized term flags the pixel */
+          unsigned long long *const pw = &pix_win[__umul24(pix_slot, 3u * PT_WIN_N)];
+          if (P.Ls.x != 0.0 && !win_add(pw, P.Ls.x)) atomicOr(&pix_nan[0], 1ull << pix_slot);
+          if (P.Ls.y != 0.0 && !win_add(pw + PT_WIN_N, P.Ls.y)) atomicOr(&pix_nan[1], 1ull << pix_slot);
+          if (P.Ls.z != 0.0 && !win_add(pw + 2 * PT_WIN_N, P.Ls.z)) atomicOr(&pix_nan[2], 1ull << pix_slot);
+        }
+        else
+        {
         /* (3 * pix_slot through v_mul_u32_u24: the compiler's v_mul_lo_u32 issues at a quarter of the rate) */
         unsigned long long *const px = &pix_sum[__umul24(pix_slot, 3u)];
         atomicAdd(&px[0], fixed_term(P.Ls.x, L.acc_scale));
@@ -2719,9 +2914,17 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
           if (P.Ls.y != P.Ls.y) atomicOr(&pix_nan[1], 1ull << pix_slot);
           if (P.Ls.z != P.Ls.z) atomicOr(&pix_nan[2], 1ull << pix_slot);
         }
+        }
       }
       if (step_done)
+      {
         busy = false;
+        if (REFR && pend_id != 0xFFu)
+        { /* the sample is complete (its stack is empty): the id goes back */
+          pend_id_give(pend_free[wave], pend_id);
+          pend_id = 0xFFu;
+        }
+      }
     }
     P.Ls = {0, 0, 0};
     PHASE(5); /* radiance to the pixel sums */
@@ -2735,7 +2938,27 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   __syncthreads();
   PHASE(12); /* epilogue: waiting for the workgroup's other waves */
 
-  if (L.sample_chunks == 1)
+  if (REFR)
+  {
+    if (!pend_ok && threadIdx.x < 3)
+      pix_nan[threadIdx.x] = ~0ull;
+    __syncthreads();
+    /* thread = (pixel, channel), as finish_pixels: the windowed sum -> mean -> float + tonemapped byte */
+    if (threadIdx.x < PT_TILE_PIXELS * 3)
+    {
+      const uint32_t t = threadIdx.x / 3u, c = threadIdx.x - 3u * t;
+      const bool inside = (tile % L.tiles_x) * PT_TILE + (t & 7u) < (uint32_t)L.width && (tile / L.tiles_x) * PT_TILE + (t >> 3) < (uint32_t)L.height;
+      double mean = win_value(&pix_win[threadIdx.x * PT_WIN_N]) * (1.0 / (double)L.samples);
+      mean = ((pix_nan[c] >> t) & 1ull) ? __longlong_as_double(0x7FF8000000000000ll) : mean;
+      out_f[threadIdx.x] = inside ? (float)mean : 0.f;
+      out_b[threadIdx.x] = inside ? tonemap(mean) : 0;
+    }
+    __syncthreads();
+    store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, true, true);
+    if (pend_ok && threadIdx.x == 0)
+      atomicExch(&L.pend_flags[pend_slot], 0u); /* every lane is past its last pop (the barriers above) */
+  }
+  else if (L.sample_chunks == 1)
   {
     finish_pixels(L, pix_sum, pix_nan, tile, out_f, out_b);
     __syncthreads();
@@ -2871,25 +3094,6 @@ __device__ __forceinline__ void ring_st3(const ParkRing &r, uint32_t field, uint
  * search.  The waves of such a workgroup render nothing and say so: every pixel of their tiles comes out NaN (bytes 255;
  * render_tiles_queued), rather than spin for ever or walk rays from registers the kernel does not have.  Thread 0 only. */
 __device__ __forceinline__ uint32_t lane_of_thread() { return threadIdx.x & 63u; }
-/* a slot of a pool of `per` slots per XCD with one in-use flag each (zero between launches) */
-__device__ __forceinline__ uint32_t pt_pool_acquire(uint32_t *flags_base, uint32_t per)
-{
-  if (flags_base == nullptr || per == 0u)
-    return 0xFFFFFFFFu;
-  /* s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, width 4): the XCD this wave runs on */
-  const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
-  uint32_t *flags = flags_base + xcc * per;
-  uint32_t i = ((blockIdx.x * 2654435761u) >> 7) % per;
-  for (uint32_t probes = 0; probes < 64u * per; probes++)
-  {
-    if (atomicCAS(&flags[i], 0u, 1u) == 0u)
-      return xcc * per + i;
-    i = (i + 1u == per) ? 0u : i + 1u;
-    if ((probes & 15u) == 15u)
-      __builtin_amdgcn_s_sleep(8);
-  }
-  return 0xFFFFFFFFu;
-}
 __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
 {
   return pt_pool_acquire(L.park_ws == nullptr ? nullptr : L.park_flags, L.park_slots_per_xcd);
@@ -3341,7 +3545,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   bool busy = false;
   bool waiting = false; /* the lane's ray is scanned and wants a walk, but the ring was full: park it next trip */
   int stack_n = 0;
-  const PendStack no_stack = {nullptr, 0};
+  const PendStack no_stack = {nullptr, 0, 0u, 0u};
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
   const uint32_t lane = threadIdx.x & 63u;
@@ -3823,8 +4027,16 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED) void pt_r
 {
   render_tiles_queued<false, true>(L);
 }
-PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK), true, false, true)
-PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK), true, false, false)
+/* small sphere scenes with M_REFRACTION on the pooled body (render_tiles_pooled, REFR) */
+#ifndef PT_MIN_WAVES_REFR_POOL
+#define PT_MIN_WAVES_REFR_POOL 4
+#endif
+extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_REFR_POOL) void pt_render_tiles_refr_pool(const PtLaunch L)
+{
+  render_tiles_pooled<true, false, true, true, true>(L);
+}
+PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_CHK), true, false, true)
+PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_CHK), true, false, false)
 PT_KERNEL(pt_render_tiles_tri_chk, __launch_bounds__(PT_BLOCK), true, true, true)
 PT_KERNEL(pt_render_tiles_tri_big_chk, __launch_bounds__(PT_BLOCK), true, true, false)
 /* Scenes whose sphere geometry + materials exceed the LDS staging budget (pt_geom_in_lds: more than 256 spheres): the SAME
@@ -3909,7 +4121,7 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
    * out NaN, bytes 255, rather than wrong: see the epilogue) */
   const bool pend_ok = !STACKED || pend_slot != 0xFFFFFFFFu;
   const PendStack stack = {STACKED && pend_ok ? L.pend_ws + (size_t)pend_slot * L.pend_slot_doubles + threadIdx.x : nullptr,
-                           STACKED && pend_ok ? (int)L.pend_entries : 0};
+                           STACKED && pend_ok ? (int)L.pend_entries : 0, PT_BLOCK, PT_PEND_FIELDS * PT_BLOCK};
   if (!pend_ok)
     s = spp;
   int stack_n = 0;
@@ -4421,7 +4633,7 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
 /* have_park_ws = false: the parked-walk kernels' workspace is missing (its allocation failed): the lane-waiting kernels */
 static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name, bool have_park_ws = true)
 {
-  static const char *const names[28] = {
+  static const char *const names[29] = {
       "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
       "pt_render_tiles_chk",  "pt_render_tiles_big_chk",  "pt_render_tiles_tri_chk",  "pt_render_tiles_tri_big_chk",
       "pt_render_tiles_refr", "pt_render_tiles_big_refr", "pt_render_tiles_tri_refr", "pt_render_tiles_tri_big_refr",
@@ -4429,7 +4641,7 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
       "pt_whitted_tiles_tri_big", "pt_render_tiles_mem",  "pt_whitted_tiles_mem",
       "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk", "pt_render_tiles_tri_queued_sph",
       "pt_render_tiles_pool_mem", "pt_render_tiles_pool_mem_chk", "pt_render_tiles_pool_mem_tri", "pt_render_tiles_pool_mem_tri_chk",
-      "pt_render_tiles_pool_mem_s", "pt_render_tiles_pool_mem_s_chk"};
+      "pt_render_tiles_pool_mem_s", "pt_render_tiles_pool_mem_s_chk", "pt_render_tiles_refr_pool"};
   const bool tris = scene.n_triangles != 0;
   const bool big = !pt_filter_in_lds(scene);
   const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
@@ -4452,6 +4664,9 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
     which = which == 3 ? (scene.mesh_round ? 21 : 19) : 20; /* hierarchy scenes: parked walks (variant 2, scenes beyond fp32's comfortable range,
                                    * whose filter needs the NaN-safe compares, and meshes whose references do not fit the walk's
                                    * 24-bit stack entries keep the lane-waiting pooled kernels) */
+  if (which == 8 && variant != 7)
+    which = 28; /* small staged sphere scenes with M_REFRACTION: the pooled body (variant 7: the static one, for A/B; the launcher also
+                 * falls back to it for launches whose sample x depth product could overflow the windowed sums) */
   if (which >= 19 && which <= 21 && !have_park_ws)
     which = which == 20 ? 7 : 3; /* no ring workspace: the lane-waiting kernels need none */
   if (name)
@@ -4462,7 +4677,7 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
 bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant)
 {
   const int which = pt_pick_kernel(scene, integrator, variant, nullptr);
-  return (which >= 8 && which <= 11) || which == 17 || which == 18; /* _refr, pt_render_tiles_mem, pt_whitted_tiles_mem */
+  return (which >= 8 && which <= 11) || which == 17 || which == 18 || which == 28; /* _refr, pt_render_tiles_mem, pt_whitted_tiles_mem, _refr_pool */
 }
 
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws)
@@ -4519,20 +4734,27 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }();
   size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[28] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
+  static const Kernel family[29] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
                                     pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr,
                                     pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
                                     pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem,
                                     pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph,
                                     pt_render_tiles_pool_mem, pt_render_tiles_pool_mem_chk, pt_render_tiles_pool_mem_tri,
-                                    pt_render_tiles_pool_mem_tri_chk, pt_render_tiles_pool_mem_s, pt_render_tiles_pool_mem_s_chk};
-  const int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr,
-                                   launch.park_ws != nullptr && launch.park_slots_per_xcd != 0u);
+                                    pt_render_tiles_pool_mem_tri_chk, pt_render_tiles_pool_mem_s, pt_render_tiles_pool_mem_s_chk,
+                                    pt_render_tiles_refr_pool};
+  int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr,
+                             launch.park_ws != nullptr && launch.park_slots_per_xcd != 0u);
+  /* the pooled refraction kernel's windowed sums hold 2^31 pieces per word: a sample of a refractive scene has at most
+   * 2^(max_depth + 2) terms (a full binary tree of children), so keep samples x 2^(max_depth + 2) <= 2^30 -- any other launch
+   * (4,097 spp at depth 16, say) takes the static kernel, whose fp64 sums have no such limit */
+  if (which == 28 && !pt_refr_pool_fits(launch.samples, launch.max_depth))
+    which = 8;
   const Kernel kernel = family[which];
-  if (which >= 22)
+  if (which >= 22 && which <= 27)
     lds_bytes = extra_lds; /* the in-memory pooled kernels stage nothing, whatever the scene's size */
-  if (((which >= 8 && which <= 11) || which == 17 || which == 18) && (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
+  if (((which >= 8 && which <= 11) || which == 17 || which == 18 || which == 28) &&
+      (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
     return hipErrorInvalidValue; /* a kernel with a pending-ray stack needs its pool (rt_hip_shim.hip: pend_pool_for) */
   if (which >= 19 && which <= 21) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +

@@ -367,7 +367,8 @@ int kernel_variant()
     const char *e = getenv("RT_HIP_KERNEL_VARIANT");
     /* 2: hierarchy scenes on the lane-waiting pooled kernels; 3: scenes beyond the LDS staging budget on the static in-memory kernel */
     /* 4: such scenes on the compare-form pooled kernel; 5: mid-size sphere scenes staged in LDS although streaming is faster (pt_prefer_streaming) */
-    return (e && e[0] >= '0' && e[0] <= '5' && e[0] != '1') ? e[0] - '0' : 1;
+    /* 7: small refractive sphere scenes on the static kernel instead of the pooled one */
+    return (e && e[0] >= '0' && e[0] <= '7' && e[0] != '1' && e[0] != '6') ? e[0] - '0' : 1;
   }();
   return v;
 }
@@ -560,8 +561,8 @@ void park_drop_ws(int device)
 }
 
 /* the per-device pool of pending-ray stacks of the two-child kernels (pt_kernel.hip, PendStack): flags, then
- * PT_PARK_XCDS x PT_PEND_SLOTS_PER_XCD slots of `entries` x 10 fields x PT_BLOCK doubles.  Sized by the deepest launch
- * seen so far (max_depth + 2 entries: 147 MB at the reference's MAX_DEPTH 5, 713 MB at the limit of 32); grown -- after
+ * PT_PARK_XCDS x PT_PEND_SLOTS_PER_XCD slots of `entries` x 10 fields x PT_PEND_COLUMNS doubles.  Sized by the deepest launch
+ * seen so far (max_depth + 2 entries: 294 MB at the reference's MAX_DEPTH 5, 1.4 GB at the limit of 32); grown -- after
  * the device has drained -- when a launch needs more, never shrunk; rt_hip_release_cache() frees it. */
 struct PendPool
 {
@@ -589,7 +590,7 @@ int pend_pool_for(int device, uint32_t entries, PtLaunch &L)
       p.ws = nullptr;
       p.entries = 0;
     }
-    const size_t slot_bytes = (size_t)entries * PT_PEND_FIELDS_HOST * PT_BLOCK * sizeof(double);
+    const size_t slot_bytes = (size_t)entries * PT_PEND_FIELDS_HOST * PT_PEND_COLUMNS * sizeof(double);
     const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PEND_SLOTS_PER_XCD;
     char *ws = nullptr;
     hipError_t e = hipMalloc(&ws, pend_flag_bytes() + n_slots * slot_bytes);
@@ -611,7 +612,7 @@ int pend_pool_for(int device, uint32_t entries, PtLaunch &L)
   L.pend_ws = reinterpret_cast<double *>(p.ws + pend_flag_bytes());
   L.pend_slots_per_xcd = PT_PEND_SLOTS_PER_XCD;
   L.pend_entries = p.entries; /* slots are laid out for the pool's depth; a shallower launch uses a prefix of each */
-  L.pend_slot_doubles = (uint64_t)p.entries * PT_PEND_FIELDS_HOST * PT_BLOCK;
+  L.pend_slot_doubles = (uint64_t)p.entries * PT_PEND_FIELDS_HOST * PT_PEND_COLUMNS;
   return RT_HIP_OK;
 }
 

@@ -74,7 +74,8 @@ def test_diag_fuzz_scenes_zero_violations():
     # the static (_refr), pooled (plain / _chk), small-mesh, parked-walk and cast_ray families were all exercised
     assert any(k.startswith("pt_render_tiles_tri_queued") for k in kernels), kernels
     assert any(k.startswith("pt_whitted_tiles") for k in kernels), kernels
-    assert any(k.endswith("_refr") for k in kernels) and any(k in ("pt_render_tiles", "pt_render_tiles_chk") for k in kernels), kernels
+    assert any("_refr" in k for k in kernels) and any(k in ("pt_render_tiles", "pt_render_tiles_chk") for k in kernels), kernels
+    assert "pt_render_tiles_refr_pool" in kernels, kernels   # small glass scenes: the pooled body (round 4)
     assert any(k in ("pt_render_tiles_tri", "pt_render_tiles_tri_chk") for k in kernels), kernels
 
 

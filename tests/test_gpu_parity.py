@@ -7,7 +7,7 @@ be EQUAL (every branch decision identical) and tonemapped bytes within 1 LSB.
 import numpy as np
 import pytest
 
-from conftest import SEED
+from conftest import ROOT, SEED
 from util import assert_parity, tile_pixels
 
 pytestmark = pytest.mark.gpu
@@ -1132,6 +1132,67 @@ def test_two_cameras_of_one_scene_on_two_streams(gpu):
                 assert torch.equal(t, a) and torch.equal(t8, a8) and torch.equal(st, ast)
         gs.close()
         sc.free()
+
+
+def test_refraction_on_the_pooled_body(gpu, pt):
+    """Small sphere scenes with M_REFRACTION render on the pooled body since round 4 (pt_render_tiles_refr_pool): pixel sums
+    without a bound on the terms (windowed integer sums: order-free, so partitions and repeated runs are bit-identical),
+    pending second children in stacks that travel with a path.  Against the oracle on scenes where the weights run away
+    (camera inside a glass sphere: 'fresnel' 7.3 per hit, negative 'kt'), against the static kernel it replaces, and the
+    launches it hands back to the static kernel (a sample x depth product the windowed sums could not hold)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from rt_amd import abi, scene as S
+    from util import glass_scene
+    sc = glass_scene(96, 64, 12, 7)
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name() == "pt_render_tiles_refr_pool"
+    total = gpu.n_tiles(sc.width, sc.height)
+    ref_t, ref_t8, ref_s = gs.render_tiles(SEED, 0, 1, total)
+    again_t, again_t8, again_s = gs.render_tiles(SEED, 0, 1, total)
+    torch.cuda.synchronize()
+    assert torch.equal(again_t, ref_t) and torch.equal(again_t8, ref_t8) and torch.equal(again_s, ref_s)
+    for r in range(3):   # any partition of the tiles: the same bits
+        first, stride, count = gpu.rank_tiles(sc.width, sc.height, r, 3)
+        t, t8, _ = gs.render_tiles(SEED, first, stride, count)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref_t[first::stride][:count]) and torch.equal(t8, ref_t8[first::stride][:count])
+    gs.close()
+    _full(gpu, pt, sc, hdr=True)
+    # the camera inside a white glass sphere inside a lit room: every path starts with refractions from inside
+    objs = [dict(flags=abi.M_REFRACTION, radius=3.0, center=(0, 0, 0), color=(1, 1, 1)),
+            dict(flags=abi.M_REFRACTION | abi.M_CHECKERED, radius=1.0, center=(0.5, 0.2, -1.2), color=(0.9, 0.95, 1.0)),
+            dict(flags=abi.M_DEFAULT, radius=1e4, center=(0, -10006.0, 0), color=(0.7, 0.7, 0.7)),
+            dict(flags=abi.M_REFLECTION, radius=2.0, center=(5, -1, -4), color=(1, 1, 1)),
+            dict(flags=abi.M_DEFAULT, radius=4.0, center=(-3, 9, 2), color=(1, 1, 1), emission=(6, 5, 4))]
+    for depth in (5, 10):
+        inside = S.custom_scene(objs, 64, 40, 6, depth, (0.3, 0.1, 0.8), (0.4, 0.3, -2.0))
+        st = _full(gpu, pt, inside, hdr=True)
+        assert st["rays"] > 64 * 40 * 6 * 4      # the trees really branch
+    # the static kernel (RT_HIP_KERNEL_VARIANT=7, read once per process: a child) gives the same image to float rounding and the same counters
+    code = ("import sys, json, torch; sys.path[:0] = [%r, %r]; from rt_amd import gpu as G; from util import glass_scene; "
+            "sc = glass_scene(96, 64, 12, 7); gs = G.GpuScene(sc); img, img8, st = gs.render_image(%d); "
+            "print(json.dumps({'k': gs.kernel_name(), 'st': st, 'sum': float(img.double().sum()), 'img8': int(img8.long().sum())}))"
+            % (os.path.join(ROOT, "raytracer.c_amd"), os.path.join(ROOT, "tests"), SEED))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RT_HIP_KERNEL_VARIANT="7"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1500:]
+    import json
+    other = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    gs = gpu.GpuScene(sc)
+    img, img8, st = gs.render_image(SEED)
+    assert other["k"] == "pt_render_tiles_refr" and other["st"] == st
+    assert abs(other["sum"] - float(img.double().sum())) <= 1e-6 * abs(other["sum"]) and abs(other["img8"] - int(img8.long().sum())) <= 64
+    # a launch whose samples x 2^(max_depth + 2) exceeds 2^30 goes to the static kernel inside the same library: still the oracle's image
+    # (the glass of this scene is out of reach, so that depth 29 does not mean 2^29 rays a sample on the CPU side)
+    far_glass = [dict(flags=abi.M_REFRACTION, radius=1.0, center=(-3.0e6, 5.0e6, 0), color=(0.9, 0.9, 0.9))] + objs[2:]
+    deep = S.custom_scene(far_glass, 32, 24, 2, 29, (0.3, 4.0, 12.0), (0.4, 0.3, -2.0))   # 2 x 2^31 > 2^30
+    gsd = gpu.GpuScene(deep)
+    assert gsd.kernel_name() == "pt_render_tiles_refr_pool"   # by scene; the launcher hands this launch to the static kernel
+    gsd.close()
+    _full(gpu, pt, deep, hdr=True)
+    gs.close()
 
 
 def test_nan_samples_poison_the_pixel_in_every_kernel_family(gpu):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off wide fuzz: many random scenes (tests/test_gpu_parity._random_scene), both integrators,
-GPU vs the CPU oracle with the tests' parity bar.  usage: [FUZZ_SPP_MULT=24] [FUZZ_WALLS=1] python tools/gpu_fuzz_parity.py [first] [count]"""
+GPU vs the CPU oracle with the tests' parity bar.  usage: [FUZZ_SPP_MULT=24] [FUZZ_WALLS=1 | FUZZ_ROOMS=1] python tools/gpu_fuzz_parity.py [first] [count]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("raytracer.c_amd", "oracle", "tests"):
@@ -20,7 +20,11 @@ bad = 0
 for k in range(first, first + count):
     n_tris = [0, 0, 0, 7, 60, 300, 900][k % 7]
     kind = ("all", "no_glass", "plain")[k % 3]  # the static (_refr), the pooled _chk / parked-walk _chk and the plain kernel families
-    if os.environ.get("FUZZ_WALLS") == "1":     # rooms of leading wall-sized spheres (pruned among themselves), with / without a mesh
+    if os.environ.get("FUZZ_ROOMS") == "1":     # rooms of 90 .. 900 packed spheres (the streamed pooled kernels; every third keeps the generator's glass: static in-memory kernels)
+        from util import packed_room
+        rng_n = np.random.default_rng(k)
+        sc = packed_room(int(rng_n.integers(80, 900)), k, 40 + k % 17, 24 + k % 11, 2 + k % 4, 3 + k % 6, glass=(k % 3 == 0))
+    elif os.environ.get("FUZZ_WALLS") == "1":     # rooms of leading wall-sized spheres (pruned among themselves), with / without a mesh
         from util import walls_scene
         sc = walls_scene(k, width=40 + k % 17, height=24 + k % 11, samples=2 + k % 5, with_mesh=(k % 3 == 2))
     else:

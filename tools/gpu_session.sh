@@ -12,7 +12,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 if [ "$TESTS" != "0" ]; then
   sel="tests"; [ "$TESTS" != "1" ] && sel="$TESTS"
-  timeout -k 10 1000 python -m pytest $sel -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; rc=$?
+  timeout -k 10 1000 python -m pytest $sel -m gpu -x -q --durations=8 > gpurun_out/pytest_gpu.log 2>&1; rc=$?
   echo "pytest exit $rc"; tail -3 gpurun_out/pytest_gpu.log
   if [ $rc -ne 0 ]; then grep -E "^(E|FAILED)" gpurun_out/pytest_gpu.log | head -30; exit 1; fi
 fi
