@@ -1738,17 +1738,23 @@ struct PoolStack
     q[3] = d.x; q[4] = d.y; q[5] = d.z;
     q[6] = T.x; q[7] = T.y; q[8] = T.z;
     q[9] = __longlong_as_double((long long)depth);
-    /* the path may be popped by ANOTHER lane of this wave after a trip through the waiting list: the record is complete in
-     * memory before this lane goes on (s_waitcnt vmcnt(0); pushes are rare) */
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   }
+  /* The path may be popped by ANOTHER lane of this wave, after a trip through the waiting list.  A wave's vector-memory
+   * operations complete in issue order, so the record is in L2 before any later load of this wave is served; what a later
+   * load must not do is hit a stale line in the CU's L1 (left by an earlier pop of the same slot): the pops bypass it
+   * (agent-scope relaxed loads = `sc1`, like the parked-walk kernels' ring).  No wait at the push: a fence there
+   * (s_waitcnt vmcnt(0) in a trip in which any lane hits glass, i.e. most trips) cost 2 % of the frame. */
   __device__ __forceinline__ void pop(int e, V3 &o, V3 &d, V3 &T, int &depth) const
   {
-    const double *q = rec(e);
-    o = {q[0], q[1], q[2]};
-    d = {q[3], q[4], q[5]};
-    T = {q[6], q[7], q[8]};
-    depth = (int)__double_as_longlong(q[9]);
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(rec(e));
+    double v[PT_PEND_FIELDS];
+#pragma unroll
+    for (uint32_t f = 0; f < PT_PEND_FIELDS; f++)
+      v[f] = __longlong_as_double((long long)__hip_atomic_load(q + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    o = {v[0], v[1], v[2]};
+    d = {v[3], v[4], v[5]};
+    T = {v[6], v[7], v[8]};
+    depth = (int)__double_as_longlong(v[9]);
   }
 };
 
@@ -2894,7 +2900,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
       if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
         if (REFR)
-        { /* no bound on a term here: the windowed sums (win_add); a non-finite or oversized term flags the pixel */
+        { /* no bound on a term here: the windowed sums (win_add); a non-finite or oversized term flags the pixel.  (What they cost:
+           * the same kernel adding plain fixed-point terms instead -- wrong for large terms, a timing experiment -- 19.9 against 20.3 ms) */
           unsigned long long *const pw = &pix_win[__umul24(pix_slot, 3u * PT_WIN_N)];
           if (P.Ls.x != 0.0 && !win_add(pw, P.Ls.x)) atomicOr(&pix_nan[0], 1ull << pix_slot);
           if (P.Ls.y != 0.0 && !win_add(pw + PT_WIN_N, P.Ls.y)) atomicOr(&pix_nan[1], 1ull << pix_slot);
