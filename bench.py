@@ -41,6 +41,7 @@ The JSON line also carries
                 ms per frame, ray-bounces/s, kernel, fractions, and a parity block each;
   integrators   (N = 1) trace_path's M_REFRACTION branch (a glass scene) and cast_ray, 1920x1080, with
                 kernel, registers / scratch, and a parity block each;
+  assembly_check (N > 1) the frame gathered from the N ranks against rank 0's own render of 2,048 of its tiles, bit for bit;
   phase_ms, ranks_seen, rank_kernel_ms, host_path   (N > 1) where a frame's time goes, how many
                 ranks RCCL really connected, and the single-process C path
                 (rt_hip_render_image over N devices) timed in a child process.
@@ -900,6 +901,25 @@ def main():
         }
         out["roofline"].update(executed_work(committed_diag(args.config), launch_casts, kern_s, sc.n_objects, sc.n_triangles))
         if world > 1:
+            # the frame assembled from N ranks' tiles must hold the bits one GPU renders: rank 0 renders a strided sample of
+            # the frame's tiles alone (outside the timed region) and compares them with the gathered image, bit for bit
+            try:
+                import numpy as np
+                a_first, a_stride, a_count = sample_tiles(W, H, 2048)
+                a_px, a_slot, a_pit = tile_pixel_indices(W, H, a_first, a_stride, a_count)
+                a_t, a_t8, _ = gs.render_tiles(SEED, a_first, a_stride, a_count)
+                torch.cuda.synchronize(dev)
+                idx = torch.from_numpy(a_px.astype(np.int64)).to(dev)
+                same = bool((image.reshape(-1, 3)[idx].cpu().numpy().view(np.uint32) == a_t.cpu().numpy()[a_slot, a_pit].view(np.uint32)).all() and
+                            (image8.reshape(-1, 3)[idx].cpu().numpy() == a_t8.cpu().numpy()[a_slot, a_pit]).all())
+                out["assembly_check"] = {"tiles": int(a_count), "pixels": int(len(a_px)), "bit_identical_to_one_gpu": same,
+                                         "what": f"the frame gathered from {world} ranks against rank 0's own render of tiles "
+                                                 f"{a_first} + {a_stride} k"}
+                if not same:
+                    out["error"] = "the frame assembled from the ranks' tiles differs from a one-GPU render of the same tiles"
+                    rc = 6
+            except Exception as exc:
+                out["assembly_check"] = {"error": repr(exc)}
             out["ranks_seen"] = ranks_seen
             out["phase_ms"] = {"render": max(p[0] for p in rank_phase), "gather": max(p[1] for p in rank_phase),
                                "untile": rank_phase[0][2],
@@ -909,7 +929,7 @@ def main():
             out["rank_kernel_ms"] = {"min": min(p[0] for p in rank_phase), "max": max(p[0] for p in rank_phase),
                                      "per_rank": [p[0] for p in rank_phase]}
             if ranks_seen != args.gpus:
-                out["error"] = f"the backend connected {ranks_seen} ranks, --gpus asked for {args.gpus}"
+                out["error"] = f"the backend connected {ranks_seen} ranks, --gpus asked for {args.gpus}" + ("; " + out["error"] if "error" in out else "")
                 rc = 3
         if world == 1 and not args.no_configs and not args.shard:
             lines = []

@@ -234,7 +234,9 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
 
 /* rt_hip_render_image() keeps what it built -- per-device scenes, streams, tile buffers, the RCCL
  * communicators -- and reuses it while the device count, the image size and the scene's bytes
- * stay the same (a caller rendering frame after frame re-creates nothing).  This releases it;
+ * stay the same (a caller rendering frame after frame re-creates nothing).  This releases it, and
+ * with it the per-device pool of pending-ray stacks that scenes with two-child materials
+ * (M_REFRACTION under trace_path, M_REFLECTION | M_REFRACTION under cast_ray) render with;
  * rt_hip_cache_builds() counts how often a context had to be (re)built (for tests). */
 void rt_hip_release_cache(void);
 uint64_t rt_hip_cache_builds(void);

@@ -8,12 +8,14 @@
  *       triangle: centre / squared radius / radius of a bounding sphere (filter only)
  *       The first four doubles of the sphere records are what the exact test and the
  *       normal use; they are staged in LDS per workgroup (scenes beyond the 24 KiB staging
- *       budget read the compact copy geom4 from memory instead).
- *   filt       [ceil(entries/2)] x 5 f32x2 (+ [n_triangles] x 16 f32, see pt_filt_bytes) : cx cy cz r2_hi neg_tol, two primitives per
- *       f32x2 -- the packed-fp32 phase-1 filter table (pt_build_filter).  Its thresholds depend
+ *       budget -- and sphere-only scenes beyond ~85 spheres by preference, pt_prefer_streaming --
+ *       read the compact copy geom4 from memory instead).
+ *   filt       [ceil(entries/2)] x 6 f32x2 (+ [n_triangles] x 16 f32, see pt_filt_bytes) : cx cy cz r2_hi neg_tol kq, two primitives
+ *       per f32x2 -- the packed-fp32 phase-1 filter table (pt_build_filter).  Its thresholds depend
  *       on the camera distance (near_R), so the shim keeps one table set per (scene, near_R),
- *       built once and immutable afterwards; read with wave-uniform indices, i.e. through
- *       scalar loads.
+ *       built once and immutable afterwards; staged in LDS by small scenes, otherwise read with
+ *       wave-uniform indices through the constant address space, i.e. by scalar loads
+ *       (pt_kernel.hip, ConstPair: as plain global loads they had been compiled to vector loads).
  *   material   [n_spheres + n_meshes] x 8 f64    : prob, albedo_rr xyz, emission xyz, flags
  *       prob      = MAX(color) (raytracer.c:497)
  *       albedo_rr = color * (1/prob), the albedo after a survived Russian roulette (:500);

@@ -30,9 +30,12 @@
  * until a batch of them walks it together.  None of this can change a value: a sample
  * depends only on its (seed, pixel, sample) stream.
  *
- * Kernel family: pt_render_tiles[_tri][_big][_chk] (pooled body, by scene content),
- * pt_render_tiles[..]_refr and pt_whitted_tiles[..] (static body: refraction's two-child
- * tree, and cast_ray, raytracer.c:556-641), see the PT_KERNEL lists below.
+ * Kernel family: pt_render_tiles[_tri][_big][_chk] (pooled body, by scene content), pt_render_tiles_pool_mem* (the same body
+ * with geometry read from memory: scenes beyond the LDS staging budget, and sphere scenes beyond ~85 spheres by preference),
+ * pt_render_tiles_refr_pool (the same body for small sphere scenes with M_REFRACTION: windowed pixel sums, pending rays that
+ * travel with a path), pt_render_tiles_tri_queued* (hierarchy scenes: parked walks), pt_render_tiles[..]_refr and
+ * pt_whitted_tiles[..] (static body: refraction's two-child tree where the pooled kernel does not apply, and cast_ray,
+ * raytracer.c:556-641), see pt_pick_kernel.
  *
  * pt_render_tiles_v0 (kept for A/B and as the plainest statement of the algorithm): static
  * assignment lane = (pixel, sample slice), literal scan, fp64 partial sums combined by
@@ -1728,7 +1731,8 @@ struct PoolStack
   unsigned long long *free_mask; /* LDS: the wave's free ids */
   uint32_t *id;                  /* the path's id (a register of the calling lane), 0xFF: none yet */
   int capacity;                  /* entries per stack */
-  __device__ __forceinline__ double *rec(int e) const { return wave_base + ((size_t)*id * (uint32_t)capacity + (uint32_t)e) * PT_PEND_FIELDS; }
+  /* (min: an id of 0xFF -- "none free", which 128 ids for at most 128 paths rule out -- must not address another wave's stacks) */
+  __device__ __forceinline__ double *rec(int e) const { return wave_base + ((size_t)min(*id, 127u) * (uint32_t)capacity + (uint32_t)e) * PT_PEND_FIELDS; }
   __device__ __forceinline__ void push(int e, const V3 &o, const V3 &d, const V3 &T, int depth) const
   {
     if (*id == 0xFFu)
@@ -1977,8 +1981,9 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
    * zero on entry, and this call's one term -- the hit's emission whether the path goes on or dies in the roulette,
    * BACKGROUND if it found nothing or ran out of depth -- is the throughput AT ENTRY times `add`.  Formed once (below,
    * before the throughput changes) instead of accumulated into P.Ls in two places (three products, three "+ 0" the compiler may not fold, three more
-   * additions and six selects per trip).  Scenes with M_REFRACTION (two children share a term) keep the general form. */
-  constexpr bool ONE_TERM = DEFER_DIR && !REFRACT;
+   * additions and six selects per trip).  The static body (DEFER_DIR = false: M_REFRACTION beyond the pooled kernel, cast_ray) keeps the general form. */
+  constexpr bool ONE_TERM = DEFER_DIR; /* (also with REFRACT -- the pooled refraction kernel: a refractive hit contributes its one emission term like any
+                                        * other hit, the two children only divide the throughput between them) */
   HitRec local;
   HitRec &H = (MODE == 0 && !DEFER_DIR) ? local : *rec;
 
@@ -2128,7 +2133,8 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           const V3 base = v_mul(P.T, albedo);
           if (stack_n < stack.capacity)
             stack.push(stack_n++, p, refl, v_scale(base, kr), P.depth + 1);
-          P.Ls = v_add(P.Ls, v_mul(P.T, emission));
+          if (!ONE_TERM)
+            P.Ls = v_add(P.Ls, v_mul(P.T, emission));
           P.T = v_scale(base, kt);
           split = true;
         }
@@ -2426,9 +2432,10 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 #ifndef PT_DIR_ROUNDS
 #define PT_DIR_ROUNDS 4
 #endif
-/* Pooled kernel body.  Not for scenes with M_REFRACTION: there the throughput is not bounded
- * by 1 (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes
- * negative), so no fixed-point scale can be fixed in advance; those scenes use the static body. */
+/* Pooled kernel body.  Its fixed-point pixel sums rest on a throughput bounded by 1; scenes with M_REFRACTION have none
+ * (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes negative), so no fixed-point scale
+ * can be fixed in advance: they take the REFR form of this body (below: windowed sums) or, where that does not apply, the
+ * static body. */
 /* REFR (pt_render_tiles_refr_pool, round 4): scenes with M_REFRACTION on the pooled body.  Two things kept them on the static
  * body: pixel sums need a bound on a term (here: win_add, order-free without one), and the second child of a refractive hit
  * waits on a per-lane stack while paths of this body move between lanes (here: the stack is addressed by a path ID that
@@ -4000,11 +4007,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 }
 
 /* Kernel family pt_render_tiles[_tri][_big][_chk|_refr], picked by scene content
- * (pt_launch_render): "_tri" = scene has triangles; "_big" = the filter table is not in LDS
+ * (pt_pick_kernel): "_tri" = scene has triangles; "_big" = the filter table is not in LDS
  * (more than PT_FILT_LDS_MAX primitives, or centres / radii beyond fp32's comfortable range):
  * table by scalar loads, NaN-safe compares, triangles through the hierarchy; "_chk" = scene
- * has M_CHECKERED materials (atan2 / fmod); "_refr" = scene has M_REFRACTION materials
- * (static body + per-lane stack of pending second children; also covers M_CHECKERED).
+ * has M_CHECKERED materials (atan2_tab / frac1); "_refr" = scene has M_REFRACTION materials
+ * (static body + pending second children in the pool; also covers M_CHECKERED) -- small staged sphere scenes take
+ * pt_render_tiles_refr_pool, the pooled body, instead.
  * pt_render_tiles itself is the headline configuration: diffuse / mirror / emissive spheres,
  * small scene. */
 #define PT_KERNEL_G(name, bounds, CHECKER, TRIS, FILT_LDS, GEOM_LDS)                         \

@@ -761,7 +761,9 @@ def test_bench_two_ranks_rehearsal(gpu):
     # the N > 1 diagnostics: ranks the backend connected, where a frame's time goes, per-rank kernel times
     assert d2["ranks_seen"] == 2 and set(d2["phase_ms"]) >= {"render", "gather", "untile"}
     assert len(d2["rank_kernel_ms"]["per_rank"]) == 2 and d2["rank_kernel_ms"]["min"] > 0
-    assert "ranks_seen" not in d1 and d1["roofline"]["kernel"] == "pt_render_tiles"
+    # the frame gathered from the two ranks holds the bits of a one-GPU render (2,048 of its tiles, compared on rank 0)
+    assert d2["assembly_check"]["bit_identical_to_one_gpu"] is True and d2["assembly_check"]["tiles"] == 2048, d2["assembly_check"]
+    assert "ranks_seen" not in d1 and "assembly_check" not in d1 and d1["roofline"]["kernel"] == "pt_render_tiles"
 
 
 def test_bench_host_path_and_config_array(gpu):
