@@ -4273,7 +4273,7 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const Pt
  * on caller data so a test can compare them bit for bit with the host's IEEE results.
  * op 0: sqrt_unscaled(a[i]);  op 1: div_small_int(a[i], b[i], 1/b[i]);  op 2: the library
  * sqrt(a[i]);  op 3: a[i] / b[i];  op 4: rnd_pm1-style fused r * 2^-30 - 1 with r = a[i];  op 5: rcp_unscaled(a[i]);
- * op 6: atan2_tab(a[i], b[i]);  op 7: frac1(a[i]) (= fmod(a[i], 1.0)). */
+ * op 6: atan2_tab(a[i], b[i]);  op 7: frac1(a[i]) (= fmod(a[i], 1.0));  op 8: win_add of every a[i] into one accumulator (out[0..6]). */
 extern "C" __global__ __launch_bounds__(256) void pt_selftest_math(int op, const double *a, const double *b,
                                                                   double *out, size_t n)
 {
@@ -4299,6 +4299,13 @@ extern "C" __global__ __launch_bounds__(256) void pt_selftest_math(int op, const
       r = atan2_tab(a[i], b[i], tab);
     else if (op == 7)
       r = frac1(a[i]);
+    else if (op == 8)
+    { /* the windowed pixel sums of pt_render_tiles_refr_pool: every a[i] into ONE accumulator, out[0 .. PT_WIN_N) (zeroed by the
+       * caller); out[PT_WIN_N] counts the values win_add refused (non-finite, or at least 2^128) */
+      if (!win_add(reinterpret_cast<unsigned long long *>(out), a[i]))
+        atomicAdd(reinterpret_cast<unsigned long long *>(out) + PT_WIN_N, 1ull);
+      continue;
+    }
     out[i] = r;
   }
 }

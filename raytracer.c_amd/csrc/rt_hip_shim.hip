@@ -1390,7 +1390,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
 
 int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h_out, size_t n, int device)
 {
-  if (!h_a || !h_b || !h_out || op < 0 || op > 7)
+  if (!h_a || !h_b || !h_out || op < 0 || op > 8 || (op == 8 && n < 8))
     return fail(RT_HIP_EINVAL, "bad self-test arguments");
   if (device < 0 || device >= usable_devices())
     return fail(RT_HIP_ENODEV, "no HIP device %d", device);
@@ -1402,6 +1402,7 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
   hipError_t e = hipMalloc(&d, 3 * n * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(d, h_a, n * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d + n, h_b, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(d + 2 * n, 0, n * sizeof(double)); /* (op 8 accumulates into out) */
   if (e == hipSuccess) e = pt_launch_selftest(op, d, d + n, d + 2 * n, n, nullptr);
   if (e == hipSuccess) e = hipMemcpy(h_out, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
   (void)hipFree(d);

@@ -435,6 +435,21 @@ def test_device_math_shortcuts_are_bit_exact(gpu):
     fa = np.concatenate([rng.uniform(-1, 2, 300000) * 100000.0, rng.uniform(-1, 2, 100000) * 10.0, 10.0 ** rng.uniform(-300, 300, 100000),
                          np.array([0.0, -0.0, 0.5, 1.0, -1.0, 1.5, -1.5, 2.0 ** 52, 2.0 ** 52 + 1.0, 4503599627370495.5])])
     assert np.array_equal(run(7, fa, fa).view(np.uint64), np.fmod(fa, 1.0).view(np.uint64)), "frac1 differs from fmod(x, 1)"
+    # win_add (the pooled refraction kernel's pixel sums): 300,000 values of either sign over 60 decades, added by 65,536 threads in
+    # whatever order into ONE windowed accumulator -- the six words, combined as integers, must be EXACTLY the sum of the values'
+    # truncations to multiples of 2^-64 (exact rational arithmetic on the host), and what win_add must refuse is counted
+    from fractions import Fraction
+    wv = np.concatenate([rng.normal(size=150000) * 10.0 ** rng.uniform(-30, 30, 150000), rng.uniform(-8, 8, 149990),
+                         np.array([0.0, -0.0, 2.0 ** -64, -(2.0 ** -64), 2.0 ** -65, 2.0 ** 127, -(2.0 ** 127), 1.0, -1.0, 5e-324])])
+    refuse = np.array([np.inf, -np.inf, np.nan, 2.0 ** 128, -(2.0 ** 130), 1e300])
+    words = run(8, np.concatenate([wv, refuse]), np.zeros(len(wv) + len(refuse)))[:7].view(np.int64)
+    assert words[6] == len(refuse)
+    got = sum(int(words[k]) << (32 * k) for k in range(6))
+    want = 0
+    for x in wv.tolist():
+        fr = Fraction(abs(x)) * (1 << 64)
+        want += (fr.numerator // fr.denominator) * (-1 if np.signbit(x) else 1)
+    assert got == want, "the windowed sum is not the exact sum of the truncated terms"
 
 
 def _random_scene(seed, with_mesh, n_tris, extra_flags=(), materials="all"):
