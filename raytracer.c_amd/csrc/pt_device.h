@@ -187,11 +187,15 @@ __host__ __device__
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-static inline bool pt_prefer_streaming(const PtSceneView &sc)
-{
-  return sc.n_triangles == 0u && !sc.any_refract && !sc.wide_range &&
+static inline bool pt_stream_sized(const PtSceneView &sc)
+{ /* a sphere scene large enough to be better off streamed */
+  return sc.n_triangles == 0u && !sc.wide_range &&
          (PT_GEOM_STRIDE * (uint64_t)sc.n_spheres + PT_MAT_STRIDE * ((uint64_t)sc.n_spheres + sc.n_meshes)) * 8u > PT_STREAM_ABOVE_BYTES;
 }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline bool pt_prefer_streaming(const PtSceneView &sc) { return pt_stream_sized(sc) && !sc.any_refract; } /* (refractive ones: pt_render_tiles_refr_pool_mem, pt_pick_kernel) */
 #if defined(__HIPCC__)
 __host__ __device__
 #endif

@@ -1184,7 +1184,7 @@ static void big_prune_for(const RtHipScene *scene, double near_R, double filt_sh
    * spheres fit the staging (the parked-walk kernels filter the spheres alone) */
   const bool sign_form = !scene->view.wide_range &&
                          (pt_geom_in_lds(scene->view) ? (scene->view.n_triangles == 0 ? pt_filter_in_lds(scene->view) : !pt_filter_in_lds(scene->view))
-                                                      : (scene->view.n_triangles == 0 && !scene->view.any_refract)); /* pt_render_tiles_pool_mem_s
+                                                      : (scene->view.n_triangles == 0)); /* pt_render_tiles_pool_mem_s, pt_render_tiles_refr_pool_mem
                                                                              * (scenes it takes by preference, pt_prefer_streaming, satisfy the first arm) */
   if (off || scene->n_big < 2 || !sign_form)
     return;

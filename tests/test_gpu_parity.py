@@ -924,7 +924,25 @@ def test_rooms_of_more_than_256_spheres_take_the_pooled_body(gpu, pt):
         gs.close()
         st = _full(gpu, pt, sc)
         assert st["tests"] == st["casts"] * (n + 8)
-    sc = packed_room(300, 4, 56, 32, 4, 6, glass=True)
+    # with the generator's glass (a fifth of the spheres M_REFRACTION): the pooled refraction kernel, streamed
+    for n, seed in ((120, 6), (300, 4)):
+        sc = packed_room(n, seed, 56, 32, 4, 6, glass=True)
+        gs = gpu.GpuScene(sc)
+        assert gs.kernel_name() == "pt_render_tiles_refr_pool_mem", gs.kernel_name()
+        total = gpu.n_tiles(sc.width, sc.height)
+        a_t, a_t8, a_s = gs.render_tiles(SEED, 0, 1, total)
+        b_t, b_t8, b_s = gs.render_tiles(SEED, 0, 1, total)
+        torch.cuda.synchronize()
+        assert torch.equal(a_t, b_t) and torch.equal(a_t8, b_t8) and torch.equal(a_s, b_s)
+        gs.close()
+        _full(gpu, pt, sc, hdr=True)
+    # ... and with a mesh next to the glass: the general static in-memory kernel
+    from rt_amd import scene as S
+    room = packed_room(300, 4, 40, 24, 2, 5, glass=True)
+    objs = [dict(flags=int(room.objects[i].flags), radius=float(room.objects[i].radius), center=room.objects[i].center.tuple(),
+                 color=room.objects[i].color.tuple(), emission=room.objects[i].emission.tuple()) for i in range(room.n_objects)]
+    tri = [[(-6, -3.9, 6, 0, 0), (6, -3.9, 6, 1, 0), (0, 9, 6, 0, 1)]]
+    sc = S.custom_scene(objs, 40, 24, 2, 5, (0, 0, 50), (0, 0, 0), meshes=[dict(flags=4, color=(0.9, 0.9, 0.9), triangles=tri)])
     gs = gpu.GpuScene(sc)
     assert gs.kernel_name() == "pt_render_tiles_mem"
     gs.close()

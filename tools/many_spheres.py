@@ -14,12 +14,12 @@ for p in ("raytracer.c_amd", "oracle", "tests"):
 SEED = 1666943821
 
 
-def child(n, spp, check, w, h):
+def child(n, spp, check, w, h, glass=False):
     import numpy as np
     import torch
     from rt_amd import gpu as G
     from util import packed_room, assert_parity, tile_pixels
-    sc = packed_room(n, 1, w, h, spp)
+    sc = packed_room(n, 1, w, h, spp, 5 if glass else 16, glass=glass)   # (glass: the reference's own MAX_DEPTH)
     gs = G.GpuScene(sc)
     total = G.n_tiles(sc.width, sc.height)
     chunks = gs.suggest_chunks(total)
@@ -62,23 +62,27 @@ if __name__ == "__main__":
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--glass", action="store_true", help="keep the generator's M_REFRACTION spheres (a fifth), depth 5: the refraction kernels; "
+                                                          "neighbour: RT_HIP_KERNEL_VARIANT=7, the static kernel")
     ap.add_argument("--child", type=int, default=-1)
     ap.add_argument("n", nargs="*", type=int)
     a = ap.parse_args()
     if a.child >= 0:
-        child(a.child, a.spp, a.check, a.width, a.height)
+        child(a.child, a.spp, a.check, a.width, a.height, a.glass)
         sys.exit(0)
     rows = []
     for n in a.n or [248, 249, 292, 992, 3992]:
         knobs = [{}]
-        if n + 8 <= 256:
+        if a.glass:
+            knobs.append({"RT_HIP_KERNEL_VARIANT": "7"})
+        elif n + 8 <= 256:
             knobs.append({"RT_HIP_FORCE_BIG": "1"})
         else:
             knobs.append({"RT_HIP_KERNEL_VARIANT": "4"})
             knobs.append({"RT_HIP_KERNEL_VARIANT": "3"})
         for kn in knobs:
             cmd = [sys.executable, os.path.abspath(__file__), "--child", str(n), "--spp", str(a.spp), "--width", str(a.width),
-                   "--height", str(a.height)] + (["--check"] if a.check and not kn else [])
+                   "--height", str(a.height)] + (["--check"] if a.check and not kn else []) + (["--glass"] if a.glass else [])
             p = subprocess.run(cmd, env=dict(os.environ, **kn), capture_output=True, text=True, timeout=1500)
             try:
                 d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
