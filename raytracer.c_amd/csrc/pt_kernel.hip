@@ -2443,7 +2443,7 @@ __device__ __forceinline__ void store_tile(const PtLaunch &L, const float *out_f
 template <bool CHECKER, bool TRIS, bool FILT_LDS, bool GEOM_LDS, bool REFR = false>
 __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
 {
-  static_assert(!REFR || (CHECKER && !TRIS && FILT_LDS), "the pooled refraction kernels: sphere scenes (staged, or streamed from memory), every material");
+  static_assert(!REFR || (CHECKER && FILT_LDS && (GEOM_LDS || !TRIS)), "the pooled refraction kernels: sphere scenes (staged, or streamed from memory) and small staged mesh scenes, every material");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ float out_f[PT_TILE_PIXELS * 3];
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
@@ -4057,6 +4057,11 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_REFR_POOL) void p
 {
   render_tiles_pooled<true, false, true, false, true>(L);
 }
+/* ... and for small scenes with a mesh (the flat filter + fp32 pre-test kernels' scene class) */
+extern "C" __global__ __launch_bounds__(PT_BLOCK, 3) void pt_render_tiles_tri_refr_pool(const PtLaunch L)
+{
+  render_tiles_pooled<true, true, true, true, true>(L);
+}
 PT_KERNEL(pt_render_tiles_chk, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_CHK), true, false, true)
 PT_KERNEL(pt_render_tiles_big_chk, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_CHK), true, false, false)
 PT_KERNEL(pt_render_tiles_tri_chk, __launch_bounds__(PT_BLOCK), true, true, true)
@@ -4662,7 +4667,7 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
 /* have_park_ws = false: the parked-walk kernels' workspace is missing (its allocation failed): the lane-waiting kernels */
 static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name, bool have_park_ws = true)
 {
-  static const char *const names[30] = {
+  static const char *const names[31] = {
       "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
       "pt_render_tiles_chk",  "pt_render_tiles_big_chk",  "pt_render_tiles_tri_chk",  "pt_render_tiles_tri_big_chk",
       "pt_render_tiles_refr", "pt_render_tiles_big_refr", "pt_render_tiles_tri_refr", "pt_render_tiles_tri_big_refr",
@@ -4670,7 +4675,8 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
       "pt_whitted_tiles_tri_big", "pt_render_tiles_mem",  "pt_whitted_tiles_mem",
       "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk", "pt_render_tiles_tri_queued_sph",
       "pt_render_tiles_pool_mem", "pt_render_tiles_pool_mem_chk", "pt_render_tiles_pool_mem_tri", "pt_render_tiles_pool_mem_tri_chk",
-      "pt_render_tiles_pool_mem_s", "pt_render_tiles_pool_mem_s_chk", "pt_render_tiles_refr_pool", "pt_render_tiles_refr_pool_mem"};
+      "pt_render_tiles_pool_mem_s", "pt_render_tiles_pool_mem_s_chk", "pt_render_tiles_refr_pool", "pt_render_tiles_refr_pool_mem",
+      "pt_render_tiles_tri_refr_pool"};
   const bool tris = scene.n_triangles != 0;
   const bool big = !pt_filter_in_lds(scene);
   const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
@@ -4697,7 +4703,9 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
   if (!cast_ray && refr && !tris && !scene.wide_range && variant != 7 && variant != 3 && (!pt_geom_in_lds(scene) || (variant != 5 && pt_stream_sized(scene))))
     which = 29;
   if (which == 8 && variant != 7)
-    which = 28; /* small staged sphere scenes with M_REFRACTION: the pooled body (variant 7: the static one, for A/B; the launcher also
+    which = 28;
+  if (which == 10 && variant != 7)
+    which = 30; /* ... with a small mesh */ /* small staged sphere scenes with M_REFRACTION: the pooled body (variant 7: the static one, for A/B; the launcher also
                  * falls back to it for launches whose sample x depth product could overflow the windowed sums) */
   if (which >= 19 && which <= 21 && !have_park_ws)
     which = which == 20 ? 7 : 3; /* no ring workspace: the lane-waiting kernels need none */
@@ -4709,7 +4717,7 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
 bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant)
 {
   const int which = pt_pick_kernel(scene, integrator, variant, nullptr);
-  return (which >= 8 && which <= 11) || which == 17 || which == 18 || which == 28 || which == 29; /* _refr, pt_render_tiles_mem, pt_whitted_tiles_mem, _refr_pool[_mem] */
+  return (which >= 8 && which <= 11) || which == 17 || which == 18 || (which >= 28 && which <= 30); /* _refr, pt_render_tiles_mem, pt_whitted_tiles_mem, _refr_pool[_mem] */
 }
 
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws)
@@ -4766,7 +4774,7 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }();
   size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[30] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
+  static const Kernel family[31] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
                                     pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr,
                                     pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
@@ -4774,7 +4782,7 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
                                     pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph,
                                     pt_render_tiles_pool_mem, pt_render_tiles_pool_mem_chk, pt_render_tiles_pool_mem_tri,
                                     pt_render_tiles_pool_mem_tri_chk, pt_render_tiles_pool_mem_s, pt_render_tiles_pool_mem_s_chk,
-                                    pt_render_tiles_refr_pool, pt_render_tiles_refr_pool_mem};
+                                    pt_render_tiles_refr_pool, pt_render_tiles_refr_pool_mem, pt_render_tiles_tri_refr_pool};
   int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr,
                              launch.park_ws != nullptr && launch.park_slots_per_xcd != 0u);
   /* the pooled refraction kernel's windowed sums hold 2^31 pieces per word: a sample of a refractive scene has at most
@@ -4784,10 +4792,12 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
     which = 8;
   if (which == 29 && !pt_refr_pool_fits(launch.samples, launch.max_depth))
     which = pt_geom_in_lds(launch.scene) ? 8 : 17;
+  if (which == 30 && !pt_refr_pool_fits(launch.samples, launch.max_depth))
+    which = 10;
   const Kernel kernel = family[which];
   if ((which >= 22 && which <= 27) || which == 29)
     lds_bytes = extra_lds; /* the in-memory pooled kernels stage nothing, whatever the scene's size */
-  if (((which >= 8 && which <= 11) || which == 17 || which == 18 || which == 28 || which == 29) &&
+  if (((which >= 8 && which <= 11) || which == 17 || which == 18 || (which >= 28 && which <= 30)) &&
       (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
     return hipErrorInvalidValue; /* a kernel with a pending-ray stack needs its pool (rt_hip_shim.hip: pend_pool_for) */
   if (which >= 19 && which <= 21) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */

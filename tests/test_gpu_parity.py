@@ -1219,6 +1219,15 @@ def test_refraction_on_the_pooled_body(gpu, pt):
     img, img8, st = gs.render_image(SEED)
     assert other["k"] == "pt_render_tiles_refr" and other["st"] == st
     assert abs(other["sum"] - float(img.double().sum())) <= 1e-6 * abs(other["sum"]) and abs(other["img8"] - int(img8.long().sum())) <= 64
+    # a small mesh next to the glass (and a glass mesh): the pooled refraction kernel of the flat-filter scene class
+    tri_objs = objs[1:]
+    quad = [[(-4, -2, -6, 0, 0), (4, -2, -6, 1, 0), (0, 5, -6, 0, 1)], [(-4, -2, -6, 0, 0), (0, 5, -6, 0, 1), (-5, 4, -5, 1, 1)]]
+    msc = S.custom_scene(tri_objs, 64, 40, 6, 6, (0.3, 1.0, 9.0), (0.4, 0.3, -2.0),
+                         meshes=[dict(flags=abi.M_REFRACTION, color=(1, 1, 1), triangles=quad)])
+    gsm = gpu.GpuScene(msc)
+    assert gsm.kernel_name() == "pt_render_tiles_tri_refr_pool", gsm.kernel_name()
+    gsm.close()
+    _full(gpu, pt, msc, hdr=True)
     # a launch whose samples x 2^(max_depth + 2) exceeds 2^30 goes to the static kernel inside the same library: still the oracle's image
     # (the glass of this scene is out of reach, so that depth 29 does not mean 2^29 rays a sample on the CPU side)
     far_glass = [dict(flags=abi.M_REFRACTION, radius=1.0, center=(-3.0e6, 5.0e6, 0), color=(0.9, 0.9, 0.9))] + objs[2:]
