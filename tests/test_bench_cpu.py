@@ -126,3 +126,24 @@ def test_executed_work_model():
     stale = bench.executed_work(dict(diag, source_sha256="f" * 64), 1e10, 0.25, 38, 0)
     assert stale["frac_executed"] is None and stale["diag_stale"] is True and "stale" in stale["executed_note"]
     assert bench.executed_work(None, 1e10, 0.25, 38, 0)["frac_executed"] is None
+
+
+def test_isa_and_diag_records_follow_the_sources_too():
+    """the committed ISA statistics and PT_DIAG counts are reported only while they describe today's kernel sources"""
+    sha = bench.kernel_source_sha256()
+    rec = json.load(open(os.path.join(ROOT, "profiles", "isa_stats.json")))
+    assert set(rec["kernels"]) >= {"pt_render_tiles", "pt_render_tiles_tri", "pt_render_tiles_tri_queued_sph", "pt_render_tiles_refr_pool",
+                                   "pt_render_tiles_pool_mem_s", "pt_whitted_tiles"}
+    k = bench.isa_keys("pt_render_tiles", source_sha=rec["source_sha256"])
+    assert k["vgpr"] > 0 and k["scratch_bytes"] == 0 and "isa_stale" not in k
+    assert bench.isa_keys("pt_render_tiles", source_sha="0" * 64) == {"isa_stale": True}
+    assert bench.isa_keys("no_such_kernel", source_sha=rec["source_sha256"]) is None
+    # no shipped kernel uses scratch memory (VERDICT r3 item 4): whatever the hash says today, the committed listing must say so
+    assert all(v["scratch_bytes"] == 0 and v["scratch_ops"] == 0 for v in rec["kernels"].values()), \
+        {n: v["scratch_bytes"] for n, v in rec["kernels"].items() if v["scratch_bytes"]}
+    for cfg in (1, 2, 3, 4, 5):
+        d = bench.committed_diag(cfg)
+        assert d is not None and set(d["per_ray_bounce"]) == set(bench.EXEC_FLOPS)
+        fresh = bench.executed_work(d, 1e9, 0.1, 8, 0, source_sha=d["source_sha256"])
+        assert 0 < fresh["frac_executed"] < 1
+    assert sha  # (whether the committed records are fresh TODAY is the profile session's business; bench.py says so in its line)
