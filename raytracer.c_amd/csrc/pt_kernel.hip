@@ -2232,7 +2232,7 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
     scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS, true, TRIS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2,
                                                                  S.n_sph, S.n_sph + S.n_tri, o, d, min_t, best, bary_u,
                                                                  bary_v, diag_ptr, S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri,
-                                                                 S.filt_shift, &last, S.stale_uv, S.tri32);
+                                                                 S.filt_shift, &last, S.stale_uv, S.tri32, nullptr, S.big);
     if (best >= 0)
     {
       const V3 p = v_add(o, v_scale(d, min_t));
@@ -2263,7 +2263,8 @@ __device__ __forceinline__ bool whitted_step(const SceneCtx &S, Path &P, uint32_
       scan_filtered<TRIS, TRIS && !FILT_LDS, FILT_LDS>(S.geom, S.tri, FILT_LDS ? S.filt_lds : S.filt, S.near_R2, S.n_sph,
                                                        S.n_sph + S.n_tri, p, ldir, shadow_t, blocker, su, sv, diag_ptr,
                                                        S.bvh_nodes, S.n_bvh_nodes, S.bvh_tri, S.filt_shift, nullptr, false,
-                                                       S.tri32);
+                                                       S.tri32, nullptr, S.big); /* (a shadow ray asks "any hit?": pruning walls that cannot be the
+                                                                                  * CLOSEST hit never removes the closest one, so a hit stays a hit) */
       const double lit = blocker >= 0 ? 0.0 : 1.0;
 
       if (flags & PT_FLAG_CHECKER)
@@ -4106,6 +4107,15 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   {
     atan_table_to_lds(atan_tab);
     S_init.atan_tab = atan_tab;
+  }
+  /* the leading wall-sized spheres pruned among themselves before the exact tests (BigPrune: the sign-form kernels of sphere
+   * scenes), as in the pooled body -- round 4: the static kernels had gone without */
+  __shared__ __attribute__((aligned(16))) float big_tab[12];
+  if (WHITTED && FILT_LDS && !TRIS && L.big_pairs != 0u) /* (cast_ray only: in the static M_REFRACTION kernel -- a fallback now -- it costs 8 bytes of scratch at four waves) */
+  {
+    if (threadIdx.x < 2 + 2 * PT_BIG_PAIRS)
+      big_tab[threadIdx.x] = threadIdx.x == 0 ? L.big_delta : (threadIdx.x == 1 ? L.big_tmin : L.big_qmin[threadIdx.x - 2]);
+    S_init.big = BigPrune{big_tab, L.big_pairs};
   }
   const SceneCtx S = S_init;
   if (threadIdx.x < 2)
