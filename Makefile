@@ -21,6 +21,8 @@ CC      := gcc
 CFLAGS  := -std=c99 -D_DEFAULT_SOURCE -O2 -ffp-contract=off -fPIC -Wall -Wno-unused-function -I$(INC) -I$(HOST)
 
 SHIM    := $(CSRC)/librt_hip.so
+# the device code is ONE translation unit, pt_kernel.hip, split by topic into the pt_*.h headers it includes
+KERNEL_SRC := $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(wildcard $(CSRC)/pt_*.h) $(INC)/rt_hip.h $(INC)/rt_rng.h
 HOSTLIB := $(HOST)/libraytracer_amd.so
 CLI     := $(HOST)/raytracer
 
@@ -33,7 +35,7 @@ all: shim shim-diag host oracle
 oracle: host
 
 shim: $(SHIM)
-$(SHIM): $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC)/rt_hip.h $(INC)/rt_rng.h
+$(SHIM): $(KERNEL_SRC)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl
 
 # diagnostic build: wave-level event counters in stats[4..] and the exhaustive re-checks of every conservative rule
@@ -41,7 +43,7 @@ $(SHIM): $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC
 # (child processes with RT_HIP_SHIM_PATH) and tools/diag*.py load it.  Built by `make all` so that it travels to
 # the GPU box with the snapshot like the other binaries (git-ignored, not gpurun-ignored).
 shim-diag: $(CSRC)/librt_hip_diag.so
-$(CSRC)/librt_hip_diag.so: $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(CSRC)/pt_device.h $(INC)/rt_hip.h $(INC)/rt_rng.h
+$(CSRC)/librt_hip_diag.so: $(KERNEL_SRC)
 	$(HIPCC) $(HIPFLAGS) -DPT_DIAG -shared -o $@ $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip -lrccl
 
 host: $(HOSTLIB) $(CLI)

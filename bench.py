@@ -66,8 +66,12 @@ FLOPS_NOTE = ("algorithmic model flops (SURVEY 8d: 17 per sphere test + 40 per t
               "lane_utilisation for the hardware-true picture")
 
 
-KERNEL_SOURCES = ("raytracer.c_amd/csrc/pt_kernel.hip", "raytracer.c_amd/csrc/pt_device.h",
-                  "raytracer.c_amd/csrc/rt_hip_shim.hip", "include/rt_rng.h", "include/rt_hip.h")
+# the device code's translation unit, every header it is made of (pt_math.h ... pt_body_static.h: one TU, split by topic), the
+# shim that picks and launches the kernels, and the two public headers both see
+KERNEL_SOURCES = ("raytracer.c_amd/csrc/pt_kernel.hip", "raytracer.c_amd/csrc/pt_device.h", "raytracer.c_amd/csrc/pt_math.h",
+                  "raytracer.c_amd/csrc/pt_intersect.h", "raytracer.c_amd/csrc/pt_filter.h", "raytracer.c_amd/csrc/pt_scene_ctx.h",
+                  "raytracer.c_amd/csrc/pt_trace.h", "raytracer.c_amd/csrc/pt_body_pooled.h", "raytracer.c_amd/csrc/pt_body_queued.h",
+                  "raytracer.c_amd/csrc/pt_body_static.h", "raytracer.c_amd/csrc/rt_hip_shim.hip", "include/rt_rng.h", "include/rt_hip.h")
 
 
 def kernel_source_sha256():

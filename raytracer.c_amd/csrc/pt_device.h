@@ -15,7 +15,7 @@
  *       on the camera distance (near_R), so the shim keeps one table set per (scene, near_R),
  *       built once and immutable afterwards; staged in LDS by small scenes, otherwise read with
  *       wave-uniform indices through the constant address space, i.e. by scalar loads
- *       (pt_kernel.hip, ConstPair: as plain global loads they had been compiled to vector loads).
+ *       (pt_filter.h, ConstPair: as plain global loads they had been compiled to vector loads).
  *   material   [n_spheres + n_meshes] x 8 f64    : prob, albedo_rr xyz, emission xyz, flags
  *       prob      = MAX(color) (raytracer.c:497)
  *       albedo_rr = color * (1/prob), the albedo after a survived Russian roulette (:500);
@@ -91,7 +91,7 @@
 #ifdef PT_BVH_WIDE
 #define PT_PARK_WAVE_BYTES (65536u + 512u + 8192u) /* + 32 overflow entries of the four-wide walk's traversal stacks (64 lanes x 4 bytes each) */
 #else
-#define PT_PARK_WAVE_BYTES (65536u + 512u) /* 512 entries of 128 bytes (pt_kernel.hip, PT_PARK_Q: why 512), then the tile's 64 per-pixel RNG keys */
+#define PT_PARK_WAVE_BYTES (65536u + 512u) /* 512 entries of 128 bytes (pt_body_queued.h, PT_PARK_Q: why 512), then the tile's 64 per-pixel RNG keys */
 #endif
 #endif
 #define PT_PARK_SLOTS_PER_XCD 192u
@@ -104,13 +104,13 @@
 
 #define PT_REFRACT_MAX_DEPTH 32 /* the pending-ray stacks of the two-child kernels hold max_depth + 2 entries (a pool in global memory
                                  * sized by the launch: 20 KB per entry and resident workgroup) */
-#define PT_PEND_FIELDS_HOST 10u /* doubles per pending ray: o, d, T, depth (pt_kernel.hip: PT_PEND_FIELDS) */
+#define PT_PEND_FIELDS_HOST 10u /* doubles per pending ray: o, d, T, depth (pt_scene_ctx.h: PT_PEND_FIELDS) */
 #define PT_PEND_COLUMNS 512u /* stacks per pool slot: the static body uses one per lane (256), the pooled refraction kernel 128 per wave */
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 static inline bool pt_refr_pool_fits(int32_t samples, int32_t max_depth)
-{ /* pt_kernel.hip, win_add: samples x 2^(max_depth + 2) <= 2^30 */
+{ /* pt_scene_ctx.h, win_add: samples x 2^(max_depth + 2) <= 2^30 */
   return max_depth + 2 <= 30 && ((int64_t)samples << (max_depth + 2)) <= ((int64_t)1 << 30);
 }
 #define PT_PEND_SLOTS_PER_XCD 128u /* 32 CUs x at most 3-4 resident workgroups of the static-body kernels, with slack */
@@ -265,7 +265,7 @@ struct PtLaunch
   double filt_shift; /* 12 e (max |c| + near_R): how far behind the origin the sign-test filter starts its ray */
   double hull_margin; /* a ray leaves a hull facet for good if (outward normal) . d exceeds this (rt_hip_shim.hip) */
   uint32_t diag_flags; /* PT_DIAG builds only: bit 0 = walk the rays the probe's bounding sphere rejects, to check them */
-  float mesh_bound[5]; /* bvh_probe: the triangles' bounding sphere for this near_R: cx cy cz r2_hi neg_tol (pt_kernel.hip, MeshBound) */
+  float mesh_bound[5]; /* bvh_probe: the triangles' bounding sphere for this near_R: cx cy cz r2_hi neg_tol (pt_intersect.h, MeshBound) */
   /* two constants passed in so that they live in SGPRs (as literals the compiler parks each in a
    * VGPR pair for the whole loop, and spilled them): BACKGROUND's component 10/255
    * (raytracer.h:46) and DBL_MAX, the initial min_t of intersect() (raytracer.c:396) */
@@ -276,7 +276,7 @@ struct PtLaunch
   uint32_t sample_chunks; /* workgroups per tile: each renders 1/sample_chunks of the samples */
   uint32_t integrator;    /* 0 trace_path (raytracer.c:482-554), 1 cast_ray (:556-641) */
   /* sign-test kernels: the scene's leading pairs of wall-sized spheres (radius >= 1000) are pruned among themselves before
-   * the exact tests (pt_kernel.hip, BigPrune): how many pairs (0: off), the distance margin, the least distance and per sphere the least q32 of a wall that may prune */
+   * the exact tests (pt_filter.h, BigPrune): how many pairs (0: off), the distance margin, the least distance and per sphere the least q32 of a wall that may prune */
   uint32_t big_pairs;
   float big_delta, big_tmin;
   float big_qmin[8];
@@ -287,7 +287,7 @@ struct PtLaunch
   uint32_t *park_flags;
   uint32_t park_slots_per_xcd;
   /* kernels with two-child materials (M_REFRACTION under trace_path; M_REFLECTION | M_REFRACTION under cast_ray): the pool of
-   * pending-ray stacks (pt_kernel.hip, PendStack): PT_PARK_XCDS x pend_slots_per_xcd slots of pend_slot_doubles doubles
+   * pending-ray stacks (pt_scene_ctx.h, PendStack): PT_PARK_XCDS x pend_slots_per_xcd slots of pend_slot_doubles doubles
    * (= pend_entries x 10 fields x PT_BLOCK lanes) and one in-use flag per slot */
   double *pend_ws;
   uint32_t *pend_flags;

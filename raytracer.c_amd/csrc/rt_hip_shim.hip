@@ -74,7 +74,7 @@ struct RtHipScene
   bool any_mirror_glass = false; /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children */
   double max_center = 0; /* max |centre| over the spheres (rounded up) */
   /* the scene's LEADING wall-sized spheres (radius >= 1000), whole pairs of them, at most 2 PT_BIG_PAIRS: radius and
-   * |centre| -- what big_prune_for needs to bound their hit-distance estimates (pt_kernel.hip, BigPrune) */
+   * |centre| -- what big_prune_for needs to bound their hit-distance estimates (pt_filter.h, BigPrune) */
   int n_big = 0;
   double big_r[8] = {0}, big_c[8] = {0};
   /* bounding sphere of every triangle (bvh_probe): centre, radius, |centre| -- radius < 0: no triangles */
@@ -560,7 +560,7 @@ void park_drop_ws(int device)
   }
 }
 
-/* the per-device pool of pending-ray stacks of the two-child kernels (pt_kernel.hip, PendStack): flags, then
+/* the per-device pool of pending-ray stacks of the two-child kernels (pt_scene_ctx.h, PendStack): flags, then
  * PT_PARK_XCDS x PT_PEND_SLOTS_PER_XCD slots of `entries` x 10 fields x PT_PEND_COLUMNS doubles.  Sized by the deepest launch
  * seen so far (max_depth + 2 entries: 294 MB at the reference's MAX_DEPTH 5, 1.4 GB at the limit of 32); grown -- after
  * the device has drained -- when a launch needs more, never shrunk; rt_hip_release_cache() frees it. */
@@ -1165,7 +1165,7 @@ static void mesh_bound_for(const RtHipScene *scene, double near_R, float out[5])
   out[4] = -(float)((scene->mesh_R + 10.0 * e * A) * (1.0 + 4.0 * e));
 }
 
-/* BigPrune (pt_kernel.hip, where the bounds are derived): for one near_R, the distance margin delta, the least estimate tmin
+/* BigPrune (pt_filter.h, where the bounds are derived): for one near_R, the distance margin delta, the least estimate tmin
  * and per sphere the least q32 of a leading wall-sized sphere that may prune the others.  With e = 2^-24, A = |c| + near_R +
  * tol, W >= r2_hi' - r^2 (pt_sign_widen_total of pt_device.h, the very function pt_build_filter widens by, x 1.001), E = 28 e A^2 + 6 e | |c|^2 -
  * r^2 |:  qmin = (r / 16)^2 + W + E,  tmin = 2 (tol + 11.2 e A),  delta = 1.5 max (22.4 e A + 8 (W + E) / r).
@@ -1315,7 +1315,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
      * max_depth + 2 events, so every term and every sample is bounded by
      * (max_depth + 2) * max(BACKGROUND, max emission).  Two conditions on the power-of-two scale: the sum
      * of `samples` samples stays below 2^62, and a single term stays below 2^51 -- the kernels read a
-     * term's integer off an fp64 mantissa (fixed_term in pt_kernel.hip). */
+     * term's integer off an fp64 mantissa (fixed_term in pt_math.h). */
     const double per_sample = ((double)params->max_depth + 2.0) * std::fmax(10.0 / 255.0, scene->max_emission) * 1.01;
     const double bound = per_sample * (double)params->samples;
     if (!(bound > 0) || !(bound < 1e300))

@@ -63,6 +63,25 @@ def test_sample_tiles_is_one_strided_run_inside_the_frame():
         assert (((t // tx) * 8 + pit // 8) * w + (t % tx) * 8 + pit % 8 == px).all()
 
 
+def test_the_source_hash_covers_every_file_of_the_device_code():
+    """the kernels are one translation unit (pt_kernel.hip) split by topic into pt_*.h headers: the hash that ties the
+    committed PMC / PT_DIAG / ISA records to the code must see every file the two .hip sources include from the repo"""
+    import re
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    csrc = os.path.join(root, "raytracer.c_amd", "csrc")
+    hashed = {os.path.basename(f) for f in bench.KERNEL_SOURCES}
+    seen, todo = set(), ["pt_kernel.hip", "rt_hip_shim.hip"]
+    while todo:
+        name = todo.pop()
+        path = next((p_ for p_ in (os.path.join(csrc, name), os.path.join(root, "include", name)) if os.path.exists(p_)), None)
+        if path is None or name in seen:
+            continue            # a system header
+        seen.add(name)
+        todo += re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), re.M)
+    assert seen <= hashed, sorted(seen - hashed)
+    assert {f for f in os.listdir(csrc) if re.fullmatch(r"pt_\w+\.h", f)} <= hashed
+
+
 def test_committed_pmc_records_are_tied_to_the_kernel_sources():
     sha = bench.kernel_source_sha256()
     assert len(sha) == 64 and sha == bench.kernel_source_sha256()

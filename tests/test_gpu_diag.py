@@ -4,7 +4,7 @@ The render kernels may skip exact fp64 tests only through rules that can never c
 phase-1 filter (three forms), the per-tile culling of the primary trips' filter (tile_cull: primitives no camera ray of the
 tile can reach are not even looked at), the pruning of wall-sized spheres among themselves by fp32 distance bounds (BigPrune), the per-lane fp32 Moeller-Trumbore
 pre-test (small meshes and hierarchy leaves), the bounding-sphere probe in front of a hierarchy walk, and the hull-facet rule (a bounce that leaves a convex facet
-on its outer side is not walked).  Each rests on a hand-derived error bound (pt_kernel.hip: pt_build_filter,
+on its outer side is not walked).  Each rests on a hand-derived error bound (pt_kernel.hip: pt_build_filter; pt_filter.h, pt_intersect.h:
 tri_may_hit32; rt_hip_shim.hip: mesh_bound_for, hull_margin_for).  The PT_DIAG build of the same kernels
 (`make shim-diag`, part of `make all`: raytracer.c_amd/csrc/librt_hip_diag.so) re-checks every application of every
 rule at run time: each primitive the filter or a pre-test drops is put through the exact test, and with

@@ -1001,7 +1001,7 @@ def test_golden_mesh_tiles_full_size(gpu, tag, cfg):
 def test_golden_mesh_soup_frames(gpu, integ):
     """textured + checkered triangle soup with duplicated and degenerate triangles, two meshes, under
     both integrators: the device reproduces the literal scan's hit.u / hit.v (those of the LAST
-    triangle the ray passes, TriLast in pt_kernel.hip) -- frames from the compiled reference"""
+    triangle the ray passes, TriLast in pt_intersect.h) -- frames from the compiled reference"""
     from util import mesh_soup_scene
     fr = np.load(GOLD + "/meshes.npz", allow_pickle=False)
     sc = mesh_soup_scene()
@@ -1577,7 +1577,7 @@ def test_inside_a_mesh_every_ray_is_parked(gpu, pt):
     """the camera inside a closed, bumpy mesh shell (an icosphere of 1,280 faces with every other vertex pushed in: not
     convex, so no bounce is spared its walk), lit by a small sphere inside, 48 spp: every ray of every bounce is parked for
     a hierarchy walk, a wave's pool is thousands of paths -- the ring, the waiting list and the walk-as-swap at their
-    busiest (a ring that could fill up would starve such a wave: PT_PARK_Q in pt_kernel.hip); frame and counters = oracle"""
+    busiest (a ring that could fill up would starve such a wave: PT_PARK_Q in pt_body_queued.h); frame and counters = oracle"""
     import math
     from rt_amd import abi, scene as S
     tris = []

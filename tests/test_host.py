@@ -227,7 +227,7 @@ def test_tile_partition_arithmetic():
 
 
 def test_sqrt_threshold_equivalence():
-    """pt_kernel.hip takes the square root of the rejection loop (reference raytracer.c:240,
+    """pt_trace.h (rejection_round) takes the square root of the rejection loop (reference raytracer.c:240,
     `while (vec3_length(p) > 1)`) out of the loop using  sqrt(x) > 1  <=>  x > 1 + 2^-52  for a
     correctly rounded sqrt.  Checked around the boundary and on random values."""
     import math
@@ -255,7 +255,7 @@ def test_fused_range_mapping_is_exact():
 
 
 def test_division_by_small_integer_shortcut_is_exact():
-    """div_small_int() in pt_kernel.hip: q0 = RN(a*y), r = fma(-q0, b, a), q = fma(r, y, q0) with
+    """div_small_int() in pt_scene_ctx.h: q0 = RN(a*y), r = fma(-q0, b, a), q = fma(r, y, q0) with
     y = RN(1/b) equals RN(a/b) for the numerators (x + r/2^31) and divisors (W-1, H-1) of
     raytracer.c:203-204.  Emulated here with exact rationals (float(Fraction) rounds correctly)."""
     from fractions import Fraction as Fr

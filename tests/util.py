@@ -300,7 +300,7 @@ def packed_room(n_packed, seed=1, width=1920, height=1080, samples=64, max_depth
 
 
 def fdlibm_atan2(y, x):
-    """numpy statement of the kernels' atan2_tab (pt_kernel.hip): fdlibm's e_atan2.c / s_atan.c with one division for all
+    """numpy statement of the kernels' atan2_tab (pt_math.h): fdlibm's e_atan2.c / s_atan.c with one division for all
     five reduction intervals, every operation unfused and in the same order -- so the device must agree BIT FOR BIT"""
     aT = [3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
           9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
