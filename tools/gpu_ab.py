@@ -16,9 +16,12 @@ csrc = os.path.join(ROOT, "raytracer.c_amd", "csrc")
 res = {}
 for rep in range(a.reps):
     for spec in a.libs:
+        spec, *envs = spec.split("+")
         name, _, path = spec.partition("=")
+        if envs and not path and not os.path.exists(os.path.join(csrc, "variants", f"librt_hip_{name}.so")):
+            path = os.path.join(csrc, "librt_hip.so")      # a switch on the shipped library
         path = path or (os.path.join(csrc, "librt_hip.so") if name == "base" else os.path.join(csrc, "variants", f"librt_hip_{name}.so"))
-        env = dict(os.environ, RT_HIP_SHIM_PATH=path)
+        env = dict(os.environ, RT_HIP_SHIM_PATH=path, **dict(e.split("=", 1) for e in envs))
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(a.config), "--spp", str(a.spp),
                             "--steps", str(a.steps), "--warmup", "1", "--cpu-tiles", "0", "--no-configs"],
                            env=env, capture_output=True, text=True, timeout=600)
