@@ -33,6 +33,14 @@
 #ifndef PT_DIR_ROUNDS
 #define PT_DIR_ROUNDS 4
 #endif
+/* A/B knob (round 4), default off: stop the rounds early when fewer than PT_DIR_MIN_LANES lanes still want a sample (they
+ * carry over like the stragglers of the fourth round).  A round is a wave's 44 instructions whoever still needs it and a
+ * carried lane costs one lane's share of a trip, so a lane model put the break-even at ~6 lanes and promised -1 %; measured
+ * with 4 / 6 / 8: headline +1.6 / +1.7 / +2.3 %, config 3 +0.6 / +1.3 / +2.8 %, config 5 +2.6 / +2.7 / +3.0 %, config 2 within
+ * noise (profiles/r04_dir_min_lanes_ab.txt): a carried lane also holds up its pool's tail.  1 = every round. */
+#ifndef PT_DIR_MIN_LANES
+#define PT_DIR_MIN_LANES 1
+#endif
 /* Pooled kernel body.  Its fixed-point pixel sums rest on a throughput bounded by 1; scenes with M_REFRACTION have none
  * (fresnel = 0.1 + 0.9 (1 - facing)^3 reaches 7.3 when a surface is hit from inside, kt goes negative), so no fixed-point scale
  * can be fixed in advance: they take the REFR form of this body (below: windowed sums) or, where that does not apply, the
@@ -484,6 +492,11 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
         DIAG(10, 1);
         DIAG_LANES(11);
         again = rejection_round(P.rng, q, len2);
+#if PT_DIR_MIN_LANES > 1
+        /* (wave-uniform among the lanes still in the loop: they all leave together) */
+        if (__popcll(__ballot(again)) < PT_DIR_MIN_LANES)
+          break;
+#endif
       }
       if (!again)
       {

@@ -896,6 +896,11 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         DIAG(10, 1);
         DIAG_LANES(11);
         again = rejection_round(P.rng, q, len2);
+#if PT_DIR_MIN_LANES > 1
+        /* (wave-uniform among the lanes still in the loop: they all leave together) */
+        if (__popcll(__ballot(again)) < PT_DIR_MIN_LANES)
+          break;
+#endif
       }
       if (!again)
       {

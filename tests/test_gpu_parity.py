@@ -1325,6 +1325,49 @@ def test_hierarchy_kernel_without_its_workspace(gpu, pt):
     sc.free()
 
 
+@pytest.mark.parametrize("seed", [3, 4])
+def test_hierarchy_builders_give_the_same_frame(gpu, pt, seed):
+    """the hierarchy only decides WHICH triangles get the exact test: the surface-area builder (round 4; 64 bins, within the
+    least depth leaves of 15 allow) and the median builder of rounds 1-3 (RT_HIP_BVH_MEDIAN=1) must render the same bits --
+    on a lopsided mesh, where they differ most: three clusters of triangles whose sizes range over two decades, one cluster
+    holding most of them (so the depth cap rules out most area splits near the root), plus duplicated and degenerate
+    triangles; and the frame equals the oracle's linear scan"""
+    import os
+    import numpy as np
+    import torch
+    from rt_amd import abi, scene as S
+    rng = np.random.default_rng(seed)
+    tris = []
+    for centre, spread, size, count in (((-6.0, 2.0, 0.0), 1.5, 0.05, 900), ((5.0, 3.0, -2.0), 4.0, 1.5, 60), ((0.0, 6.0, 4.0), 0.4, 0.01, 240)):
+        for _ in range(count):
+            c = np.asarray(centre) + rng.normal(size=3) * spread
+            a, b = rng.normal(size=3) * size, rng.normal(size=3) * size
+            tris.append([tuple(c), tuple(c + a), tuple(c + b)])
+    tris += tris[:40]                                                  # exact duplicates: the (t, index) rule under both orders
+    tris += [[(1.0, 1.0, 1.0), (1.0, 1.0, 1.0), (2.0, 1.0, 1.0)]]      # a degenerate one
+    meshes = [dict(flags=abi.M_DEFAULT, color=(0.8, 0.7, 0.6), triangles=tris)]
+    objs = [dict(flags=abi.M_DEFAULT, radius=4.0, center=(0, 18, 0), color=(1, 1, 1), emission=(8, 8, 8)),
+            dict(flags=abi.M_DEFAULT, radius=1000.0, center=(0, -1004, 0), color=(0.6, 0.6, 0.6)),
+            dict(flags=abi.M_REFLECTION, radius=2.0, center=(2, 0, 6), color=(0.9, 0.9, 0.9))]
+    sc = S.custom_scene(objs, 64, 40, 6, 6, (4, 6, 22), (0, 2, 0), meshes=meshes)
+    assert sc.n_triangles > 256
+    frames = []
+    for median in (False, True):
+        if median:
+            os.environ["RT_HIP_BVH_MEDIAN"] = "1"
+        try:
+            gs = gpu.GpuScene(sc)
+            assert gs.kernel_name().startswith("pt_render_tiles_tri_queued")
+            frames.append(gs.render_image(SEED))
+            gs.close()
+        finally:
+            os.environ.pop("RT_HIP_BVH_MEDIAN", None)
+    (img, img8, st), (img_m, img8_m, st_m) = frames
+    assert torch.equal(img, img_m) and torch.equal(img8, img8_m) and st == st_m
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="lopsided mesh, surface-area hierarchy")
+
+
 def test_small_mesh_kernel_partitions_and_chunks_are_bit_invariant(gpu, pt):
     """pt_render_tiles_tri (fp32 triangle pre-test, two candidate loops, throughput parked in LDS across the
     scan, radiance flushed per trip): interleaved tile subsets and sample chunks reproduce the full render
