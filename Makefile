@@ -22,7 +22,7 @@ CFLAGS  := -std=c99 -D_DEFAULT_SOURCE -O2 -ffp-contract=off -fPIC -Wall -Wno-unu
 
 SHIM    := $(CSRC)/librt_hip.so
 # the device code is ONE translation unit, pt_kernel.hip, split by topic into the pt_*.h headers it includes
-KERNEL_SRC := $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(wildcard $(CSRC)/pt_*.h) $(INC)/rt_hip.h $(INC)/rt_rng.h
+KERNEL_SRC := $(CSRC)/pt_kernel.hip $(CSRC)/rt_hip_shim.hip $(wildcard $(CSRC)/pt_*.h) $(CSRC)/bvh_build.h $(INC)/rt_hip.h $(INC)/rt_rng.h
 HOSTLIB := $(HOST)/libraytracer_amd.so
 CLI     := $(HOST)/raytracer
 

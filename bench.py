@@ -71,7 +71,7 @@ FLOPS_NOTE = ("algorithmic model flops (SURVEY 8d: 17 per sphere test + 40 per t
 KERNEL_SOURCES = ("raytracer.c_amd/csrc/pt_kernel.hip", "raytracer.c_amd/csrc/pt_device.h", "raytracer.c_amd/csrc/pt_math.h",
                   "raytracer.c_amd/csrc/pt_intersect.h", "raytracer.c_amd/csrc/pt_filter.h", "raytracer.c_amd/csrc/pt_scene_ctx.h",
                   "raytracer.c_amd/csrc/pt_trace.h", "raytracer.c_amd/csrc/pt_body_pooled.h", "raytracer.c_amd/csrc/pt_body_queued.h",
-                  "raytracer.c_amd/csrc/pt_body_static.h", "raytracer.c_amd/csrc/rt_hip_shim.hip", "include/rt_rng.h", "include/rt_hip.h")
+                  "raytracer.c_amd/csrc/pt_body_static.h", "raytracer.c_amd/csrc/rt_hip_shim.hip", "raytracer.c_amd/csrc/bvh_build.h", "include/rt_rng.h", "include/rt_hip.h")
 
 
 def kernel_source_sha256():

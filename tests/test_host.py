@@ -314,3 +314,74 @@ def test_load_obj_survives_malformed_input_fuzz(host, tmp_path):
                 _ = mesh.vertices[k].pos.x + mesh.vertices[k].tex.y
             libc.free(mesh.vertices)
     assert loaded > 0
+
+
+def test_hierarchy_builder_invariants(tmp_path):
+    """the host-side hierarchy builder (raytracer.c_amd/csrc/bvh_build.h: surface-area splits over 64 bins within the least depth
+    leaves of PT_BVH_LEAF allow, median where no admissible split exists) compiled by g++ with the checker of
+    tests/bvh_harness.cpp: order is a permutation, the leaves tile the triangle list, no leaf above PT_BVH_LEAF, the depth is the
+    least possible (the kernels' LDS stacks are sized by it), every stored child box is exactly the union of its subtree, two
+    builds agree -- on uniform, clustered, degenerate and huge inputs, under both builders"""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libbvh_harness.so")
+    # (tools/asan_host.sh sets RT_BVH_HARNESS_FLAGS="-g -fsanitize=address,undefined" and preloads the sanitizer runtimes)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-shared", "-fPIC"] + os.environ.get("RT_BVH_HARNESS_FLAGS", "").split() + ["-I", os.path.join(root, "include"), "-I",
+                    os.path.join(root, "raytracer.c_amd", "csrc"), os.path.join(root, "tests", "bvh_harness.cpp"), "-o", so], check=True)
+    lib = C.CDLL(so)
+    lib.bvh_check.restype = C.c_int
+    lib.bvh_check.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 5), C.POINTER(C.c_double)]
+
+    def check(tris, median=False):
+        g = np.ascontiguousarray(np.concatenate([tris[:, 0], tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]], axis=1), dtype=np.float64)
+        out, cost = (C.c_uint32 * 5)(), C.c_double()
+        if median:
+            os.environ["RT_HIP_BVH_MEDIAN"] = "1"
+        try:
+            rc = lib.bvh_check(g.ctypes.data, len(g), C.byref(out), C.byref(cost))
+        finally:
+            os.environ.pop("RT_HIP_BVH_MEDIAN", None)
+        assert rc == 0, f"invariant {rc} violated ({len(g)} triangles, median={median})"
+        return dict(depth=out[0], max_depth=out[1], nodes=out[2], leaves=out[3], area=bool(out[4]), cost=cost.value)
+
+    rng = np.random.default_rng(7)
+
+    def soup(n, spread=10.0, size=0.3, centre=(0, 0, 0)):
+        c = np.asarray(centre) + rng.normal(size=(n, 1, 3)) * spread
+        return c + rng.normal(size=(n, 3, 3)) * size
+
+    def uv_sphere(rings, segs, r=8.0):
+        t = np.linspace(0, np.pi, rings + 1)[:, None]
+        p = np.linspace(0, 2 * np.pi, segs + 1)[None, :]
+        v = r * np.stack([np.sin(t) * np.cos(p), np.cos(t) * np.ones_like(p), np.sin(t) * np.sin(p)], axis=-1)
+        a, b, c, d = v[:-1, :-1], v[1:, :-1], v[1:, 1:], v[:-1, 1:]
+        return np.concatenate([np.stack([a, b, c], axis=-2).reshape(-1, 3, 3), np.stack([a, c, d], axis=-2).reshape(-1, 3, 3)])
+
+    for n in (1, 2, 15, 16, 17, 30, 31, 240, 241, 255, 1000, 10240, 40000):       # leaf and depth boundaries (15 * 2^D)
+        for median in (False, True):
+            r = check(soup(n), median)
+            least = 0
+            while 15 * 2 ** least < n:
+                least += 1
+            assert r["max_depth"] == least and r["depth"] <= max(least, 1)
+            assert r["leaves"] * 15 >= n and r["nodes"] == max(r["leaves"] - 1, 1)
+    # lopsided: one dense cluster holding most of the triangles, two sparse ones with triangles 100x as large
+    lop = np.concatenate([soup(3000, 0.5, 0.01, (-20, 0, 0)), soup(200, 6.0, 2.0, (15, 5, 0)), soup(40, 0.1, 0.5, (0, 30, 9))])
+    # (little slack under the depth cap: 3,240 of 3,840 leaf slots -- greedy area splits near the root can use it up; the builder
+    # builds both trees and keeps the cheaper by its own cost model, so it is never worse than the median tree)
+    best, med = check(lop), check(lop, True)
+    assert best["depth"] <= med["max_depth"] and best["cost"] <= med["cost"] and not med["area"]
+    # config 5's kind of mesh: the area heuristic must pay within the median tree's depth
+    sph = uv_sphere(64, 80)
+    sah, med = check(sph), check(sph, True)
+    assert len(sph) == 10240 and sah["depth"] == med["depth"] == 10 and sah["area"] and sah["cost"] < 0.92 * med["cost"]
+    # degenerate inputs: all triangles identical, all centroids on one line / in one plane, zero-area triangles, huge and tiny
+    # coordinates, duplicates -- the median fallback must take over wherever no area split exists
+    one = np.tile(soup(1), (500, 1, 1))
+    line = soup(700, 0.0, 0.2) + np.linspace(0, 50, 700)[:, None, None] * np.array([1.0, 0, 0])
+    plane = soup(900) * np.array([1.0, 0.0, 1.0])
+    points = np.repeat(rng.normal(size=(300, 1, 3)), 3, axis=1)
+    for tris in (one, line, plane, points, soup(2000) * 1e12, soup(2000) * 1e-12, np.concatenate([soup(600)] * 3)):
+        for median in (False, True):
+            check(tris, median)

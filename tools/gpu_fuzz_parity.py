@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off wide fuzz: many random scenes (tests/test_gpu_parity._random_scene), both integrators,
-GPU vs the CPU oracle with the tests' parity bar.  usage: [FUZZ_SPP_MULT=24] [FUZZ_WALLS=1 | FUZZ_ROOMS=1] python tools/gpu_fuzz_parity.py [first] [count]"""
+GPU vs the CPU oracle with the tests' parity bar.  usage: [FUZZ_SPP_MULT=24] [FUZZ_WALLS=1 | FUZZ_ROOMS=1 | FUZZ_TRIS=300,900,2500,6000] python tools/gpu_fuzz_parity.py [first] [count]
+(FUZZ_TRIS: every scene gets a mesh of one of these sizes in turn -- hierarchy scenes only, for the builder)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("raytracer.c_amd", "oracle", "tests"):
@@ -10,7 +11,7 @@ import numpy as np
 import oracle_py
 from rt_amd import abi, gpu as G
 from test_gpu_parity import _random_scene
-from util import assert_parity
+from util import assert_parity, fixed_point_floor
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
@@ -19,6 +20,9 @@ both = (abi.M_REFLECTION | abi.M_REFRACTION, abi.M_REFRACTION | abi.M_CHECKERED)
 bad = 0
 for k in range(first, first + count):
     n_tris = [0, 0, 0, 7, 60, 300, 900][k % 7]
+    if os.environ.get("FUZZ_TRIS"):
+        sizes = [int(v) for v in os.environ["FUZZ_TRIS"].split(",")]
+        n_tris = sizes[k % len(sizes)]
     kind = ("all", "no_glass", "plain")[k % 3]  # the static (_refr), the pooled _chk / parked-walk _chk and the plain kernel families
     if os.environ.get("FUZZ_ROOMS") == "1":     # rooms of 90 .. 900 packed spheres (the streamed pooled kernels; every third keeps the generator's glass: static in-memory kernels)
         from util import packed_room
@@ -40,7 +44,7 @@ for k in range(first, first + count):
             continue
         mean, rgb8, ost = pt.render_pixels(sc, 1666943821 + k, integrator=integrator)
         try:
-            assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"scene {k} {integrator}", hdr=True)
+            assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"scene {k} {integrator}", hdr=True, abs_floor=fixed_point_floor(sc))
         except AssertionError as e:
             bad += 1
             print("FAIL", e)
