@@ -79,8 +79,8 @@ __device__ __forceinline__ uint32_t ring_fi(uint32_t field, uint32_t e)
                                     : (field < 10u ? PT_PARK_Q * 8u + e * 4u + (field - 6u) : PT_PARK_Q * 12u + e * 4u + (field - 11u)));
 }
 __device__ __forceinline__ uint32_t ring_ui(uint32_t field, uint32_t e)
-{ /* fields: 0 best, 1 depth << 6 | pixel slot (+ PT_DIAG flags), 2 last index */
-  return field < 2u ? e * 16u + 14u + field : PT_PARK_Q * 24u + e * 8u + 4u;
+{ /* fields: 0 best, 1 depth << 6 | pixel slot (+ PT_DIAG flags), 2 last index, 3 (REFR kernels) stack id | stack height << 16 */
+  return field < 2u ? e * 16u + 14u + field : PT_PARK_Q * 24u + e * 8u + 2u + field;
 }
 #endif
 
@@ -398,10 +398,20 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* results in L2 before anyone resumes them */
 }
 
-template <bool CHECKER, bool SPHERE_PROBE = false>
+/* REFR (pt_render_tiles_tri_queued_refr[_sph], end of round 4): hierarchy scenes with M_REFRACTION materials, until then on the
+ * static body (every lane walks the hierarchy on the spot).  What render_tiles_pooled's REFR form needs, here: pixel sums without a
+ * bound on a term (win_add: six signed 64-bit windows per channel, in dynamic LDS behind the traversal stacks -- 9 KB per wave's
+ * tile, which leaves two workgroups per CU), and pending second children in stacks addressed by a path id that travels with the
+ * path -- through the waiting list (meta word) and, new here, through the ring (word 3 of an entry): a wave can hold 64 paths in
+ * lanes, 64 on its list and up to 382 in its ring, so ids are 9 bits (PoolStackT<512, 511>: 511 ids for at most 510 paths) and a
+ * workgroup's slot of the pending-ray pool holds 4 x 512 stacks (PtLaunch.pend_slot_doubles: pend_pool_for sizes it). */
+typedef PoolStackT<512u, 511u> RingStack;
+template <bool CHECKER, bool SPHERE_PROBE = false, bool REFR = false>
 __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 {
+  static_assert(!REFR || CHECKER, "the refraction form carries every material's code");
   constexpr bool TRIS = true, FILT_LDS = false;
+  constexpr uint32_t NO_ID = 511u;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   /* ONE WAVE = ONE TILE here (a workgroup = four tiles, its waves independent of each other between the
    * barrier after staging and the one before the slot goes back): a wave's pool is its tile's 64 pixels
@@ -409,9 +419,10 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
    * pool run on with most lanes idle -- each walk costs a park / walk / resume cycle, so the tail is long in
    * these kernels -- weighs a quarter as much.  (The image is 4K-sized or the scene's cost per ray is high
    * wherever these kernels run, so a quarter as many workgroups still fill the chip many times over.) */
-  __shared__ unsigned long long pix_sum_all[PT_BLOCK / 64][PT_TILE_PIXELS * 3];
+  __shared__ unsigned long long pix_sum_all[REFR ? 1 : PT_BLOCK / 64][REFR ? 1 : PT_TILE_PIXELS * 3];
   __shared__ unsigned long long pix_nan_all[PT_BLOCK / 64][3];
-  __shared__ uint32_t park_slot_lds;
+  __shared__ unsigned long long pend_free[REFR ? PT_BLOCK / 64 : 1][8]; /* REFR: per wave, the free ids of its 511 pending-ray stacks */
+  __shared__ uint32_t park_slot_lds, pend_slot_lds;
   __shared__ double cam_lds[PT_CAM_LDS_DOUBLES]; /* the camera (camera_to_lds) */
   /* The wave's WAITING LIST in LDS: up to 64 paths that wait for a lane (render_tiles_pooled's, with two more
    * tenants).  Who puts paths there: (1) the SWAP -- idle lanes, an empty list, jobs left: every busy lane leaves
@@ -430,6 +441,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
    * next); the ray leaves a hull facet for good; a scanned ray that found the ring full and waits to be parked (scan
    * result known, park next); then the depth */
   constexpr uint32_t META_NEED_DIR = 64u, META_RESUMED = 128u, META_LEAVING = 256u, META_WAITING = 512u, META_DEPTH_SHIFT = 10u;
+  /* REFR: depth in six bits (max_depth <= 32 in scenes with M_REFRACTION), then the path's stack id (nine bits) and stack height (six) */
+  constexpr uint32_t META_ID_SHIFT = 16u, META_STACK_SHIFT = 25u;
 
 #ifdef PT_PHASE
   if ((threadIdx.x & 63u) == 0u)
@@ -468,15 +481,24 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     stack.ovf = nullptr; /* set below, once the wave's ring is known */
 #endif
   }
+  /* REFR: the windowed pixel sums of the four tiles follow the stacks (pt_launch_render sizes the dynamic LDS) */
+  unsigned long long *const pix_win_all =
+      reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(stack.lo) + (((size_t)max(L.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u));
   {
-    unsigned long long *z = &pix_sum_all[0][0];
-    for (uint32_t k = threadIdx.x; k < (PT_BLOCK / 64) * PT_TILE_PIXELS * 3; k += PT_BLOCK)
+    unsigned long long *z = REFR ? pix_win_all : &pix_sum_all[0][0];
+    for (uint32_t k = threadIdx.x; k < (PT_BLOCK / 64) * PT_TILE_PIXELS * 3 * (REFR ? PT_WIN_N : 1); k += PT_BLOCK)
       z[k] = 0;
     if (threadIdx.x < (PT_BLOCK / 64) * 3)
       (&pix_nan_all[0][0])[threadIdx.x] = 0;
+    if (REFR && threadIdx.x < (PT_BLOCK / 64) * 8)
+      (&pend_free[0][0])[threadIdx.x] = (threadIdx.x & 7u) == 7u ? 0x7FFFFFFFFFFFFFFFull : ~0ull; /* ids 0 .. 510 */
   }
   if (threadIdx.x == 0)
+  {
     park_slot_lds = pt_park_acquire(L);
+    if (REFR)
+      pend_slot_lds = pt_pool_acquire(L.pend_ws == nullptr ? nullptr : L.pend_flags, L.pend_slots_per_xcd);
+  }
   camera_to_lds(L, cam_lds);
   PHASE(9);
   __syncthreads();
@@ -497,7 +519,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   const uint32_t s_begin = (uint32_t)(((uint64_t)chunk * spp) / L.sample_chunks);
   const uint32_t s_end = (uint32_t)(((uint64_t)(chunk + 1u) * spp) / L.sample_chunks);
   const uint32_t park_slot = park_slot_lds;
-  const bool ring_ok = park_slot != 0xFFFFFFFFu;
+  const uint32_t pend_slot = REFR ? pend_slot_lds : 0u;
+  /* (REFR: without its slot of the pending-ray pool -- a sizing bug of the pool, never seen -- a workgroup renders nothing either) */
+  const bool ring_ok = park_slot != 0xFFFFFFFFu && (!REFR || pend_slot != 0xFFFFFFFFu);
   /* (the launcher takes these kernels only with a workspace: pt_launch_render; a slot can be missing only through a sizing
    * bug of the pool, never seen -- then nothing could be parked and rays that want a walk would wait for ever: the wave
    * renders nothing instead, and says so: every pixel of its tile comes out NaN, bytes 255) */
@@ -564,8 +588,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   uint32_t pix_slot = 0;
   bool busy = false;
   bool waiting = false; /* the lane's ray is scanned and wants a walk, but the ring was full: park it next trip */
-  int stack_n = 0;
+  int stack_n = 0;        /* REFR: pending second children of this lane's path */
+  uint32_t pend_id = NO_ID; /* REFR: the path's stack id */
   const PendStack no_stack = {nullptr, 0, 0u, 0u};
+  double *const pend_wave = REFR && ring_ok ? L.pend_ws + (size_t)pend_slot * L.pend_slot_doubles +
+                                                  (size_t)(threadIdx.x >> 6) * 512u * L.pend_entries * PT_PEND_FIELDS
+                                            : nullptr;
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
   const uint32_t lane = threadIdx.x & 63u;
@@ -579,6 +607,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     wf[6 * 64 + e] = P.T.x; wf[7 * 64 + e] = P.T.y; wf[8 * 64 + e] = P.T.z;
     wf[9 * 64 + e] = __longlong_as_double((long long)P.rng);
     uint32_t meta = ((uint32_t)P.depth << META_DEPTH_SHIFT) | (hit.need_dir ? META_NEED_DIR : 0u) | (hit.leaving ? META_LEAVING : 0u) | pix_slot;
+    if (REFR)
+      meta |= (pend_id << META_ID_SHIFT) | ((uint32_t)stack_n << META_STACK_SHIFT);
     if (resumed_now || waiting)
     { /* the scan's result travels with the ray */
       meta |= resumed_now ? META_RESUMED : META_WAITING;
@@ -628,7 +658,13 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           for (uint32_t f = 0; f < 11u; f++)
             wf[f * 64u + lane] = fv[f];
           wu[64u + lane] = best_w;
-          wu[lane] = (dp & 63u) | META_RESUMED | ((dp >> 6) << META_DEPTH_SHIFT);
+          uint32_t meta_w = (dp & 63u) | META_RESUMED | ((dp >> 6) << META_DEPTH_SHIFT);
+          if (REFR)
+          {
+            const uint32_t idw = ring_ldu(ring, 3u, e);
+            meta_w |= ((idw & 0x1FFu) << META_ID_SHIFT) | ((idw >> 16) << META_STACK_SHIFT);
+          }
+          wu[lane] = meta_w;
           if (CHECKER)
           {
             wf[(CHECKER ? 11u : 0u) * 64u + lane] = ring_ld(ring, 11u, e);
@@ -655,7 +691,12 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         const double f10 = wf[10 * 64 + e];
         const uint32_t meta = wu[e], w1 = wu[64 + e];
         pix_slot = meta & 63u;
-        P.depth = (int)(meta >> META_DEPTH_SHIFT);
+        P.depth = REFR ? (int)((meta >> META_DEPTH_SHIFT) & 63u) : (int)(meta >> META_DEPTH_SHIFT);
+        if (REFR)
+        {
+          pend_id = (meta >> META_ID_SHIFT) & 0x1FFu;
+          stack_n = (int)((meta >> META_STACK_SHIFT) & 63u);
+        }
         P.Ls = {0, 0, 0};
         hit.need_dir = (meta & META_NEED_DIR) != 0u;
         hit.leaving = (meta & META_LEAVING) != 0u;
@@ -703,6 +744,11 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       __builtin_amdgcn_wave_barrier();
       const uint32_t job = next_job + lane;
       busy = job < pool;
+      if (REFR)
+      { /* fresh samples: no stack yet */
+        pend_id = NO_ID;
+        stack_n = 0;
+      }
       if (busy)
       {
         DIAG(6, 1);
@@ -772,6 +818,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       P.rng = 1;
       P.depth = 0;
       pix_slot = 0;
+      pend_id = NO_ID;
+      stack_n = 0;
       hit.min_t = 0;
       hit.best = -1;
       hit.need_dir = false;
@@ -808,7 +856,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       /* ... and a fresh camera ray of a tile whose cone cannot reach the triangles' bounding ball (tile_sees_mesh, once
        * per wave: a primary trip's 64 rays are all such rays) cannot either: most of the image's primary trips skip the probe */
       const bool no_mesh = (hit.leaving && !(CHECKER && S.stale_uv)) || (primary_trip && !tile_sees_mesh);
-      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
+      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit); /* (the first half never touches the stack) */
       const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
 #ifdef PT_DIAG
       /* RT_HIP_DIAG_WALK_REJECTED=1: rays the bounding sphere rejects are parked and walked all the same, and any
@@ -862,6 +910,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 #else
         ring_stu(ring, 1u, e, ((uint32_t)P.depth << 6) | pix_slot);
 #endif
+        if (REFR)
+          ring_stu(ring, 3u, e, pend_id | ((uint32_t)stack_n << 16));
         if (CHECKER)
         { /* (the walk overwrites these; a defined value for rays it finds nothing for) */
           ring_stu(ring, 2u, e, (uint32_t)hit.last.idx);
@@ -882,7 +932,15 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
      * walked rays resumed at the top of this trip ---- */
     bool step_done = false;
     if (busy && (stepping || resumed) && !waiting)
-      step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
+    {
+      if constexpr (REFR)
+      {
+        const RingStack mine = {pend_wave, pend_free[wave_now()], &pend_id, (int)L.pend_entries};
+        step_done = trace_step<1, true, CHECKER, TRIS, FILT_LDS, 2, true, true, false, RingStack>(S, P, n_casts, diag_ptr, mine, stack_n, &hit);
+      }
+      else
+        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
+    }
     PHASE(3);
 
     /* ---- directions of diffuse hits (see render_tiles_pooled) ---- */
@@ -923,6 +981,16 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
        * associate: the sum does not depend on the order or the grouping of the terms) */
       if ((int)(P.Ls.x != 0.0) | (int)(P.Ls.y != 0.0) | (int)(P.Ls.z != 0.0))
       {
+        if (REFR)
+        { /* no bound on a term: the windowed sums (win_add); a non-finite or oversized term flags the pixel */
+          unsigned long long *const pw = pix_win_all + (size_t)wave_now() * (PT_TILE_PIXELS * 3 * PT_WIN_N) + __umul24(pix_slot, 3u * PT_WIN_N);
+          unsigned long long *const pix_nan = pix_nan_all[wave_now()];
+          if (P.Ls.x != 0.0 && !win_add(pw, P.Ls.x)) atomicOr(&pix_nan[0], 1ull << pix_slot);
+          if (P.Ls.y != 0.0 && !win_add(pw + PT_WIN_N, P.Ls.y)) atomicOr(&pix_nan[1], 1ull << pix_slot);
+          if (P.Ls.z != 0.0 && !win_add(pw + 2 * PT_WIN_N, P.Ls.z)) atomicOr(&pix_nan[2], 1ull << pix_slot);
+        }
+        else
+        {
         unsigned long long *const pix_sum = pix_sum_all[wave_now()];
         /* (3 * pix_slot through v_mul_u32_u24: the compiler's v_mul_lo_u32 issues at a quarter of the rate) */
         unsigned long long *const px = &pix_sum[__umul24(pix_slot, 3u)];
@@ -936,10 +1004,18 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
           if (P.Ls.y != P.Ls.y) atomicOr(&pix_nan[1], 1ull << pix_slot);
           if (P.Ls.z != P.Ls.z) atomicOr(&pix_nan[2], 1ull << pix_slot);
         }
+        }
         P.Ls = {0, 0, 0};
       }
       if (step_done)
+      {
         busy = false;
+        if (REFR && pend_id != NO_ID)
+        { /* the sample is complete (its stack is empty): the id goes back */
+          pend_id_give(pend_free[wave_now()], pend_id);
+          pend_id = NO_ID;
+        }
+      }
     }
     PHASE(5);
   }
@@ -959,7 +1035,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - (tile_e % L.tiles_x) * PT_TILE);
     const uint32_t vrows = min((uint32_t)PT_TILE, (uint32_t)L.height - (tile_e / L.tiles_x) * PT_TILE);
     const uint32_t n_valid = vcols * vrows;
-    unsigned long long *const pix_sum = pix_sum_all[wave_now()];
+    unsigned long long *const pix_sum = pix_sum_all[REFR ? 0u : wave_now()];
     unsigned long long *const pix_nan = pix_nan_all[wave_now()];
     uint32_t rays_w = n_rays, casts_w = n_casts;
     for (int off = 32; off > 0; off >>= 1)
@@ -984,9 +1060,19 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       const double inv_s = 1.0 / (double)L.samples;
       const double quiet_nan = __longlong_as_double(0x7FF8000000000000ll);
       V3 mean;
+      if (REFR)
+      {
+        const unsigned long long *pw = pix_win_all + (size_t)wave_now() * (PT_TILE_PIXELS * 3 * PT_WIN_N) + t * (3u * PT_WIN_N);
+        mean.x = win_value(pw) * inv_s;
+        mean.y = win_value(pw + PT_WIN_N) * inv_s;
+        mean.z = win_value(pw + 2 * PT_WIN_N) * inv_s;
+      }
+      else
+      {
       mean.x = ((double)(long long)pix_sum[3 * t + 0] * L.acc_inv_scale) * inv_s;
       mean.y = ((double)(long long)pix_sum[3 * t + 1] * L.acc_inv_scale) * inv_s;
       mean.z = ((double)(long long)pix_sum[3 * t + 2] * L.acc_inv_scale) * inv_s;
+      }
       mean.x = ((pix_nan[0] >> t) & 1ull) ? quiet_nan : mean.x; /* see finish_pixels */
       mean.y = ((pix_nan[1] >> t) & 1ull) ? quiet_nan : mean.y;
       mean.z = ((pix_nan[2] >> t) & 1ull) ? quiet_nan : mean.z;
@@ -1013,8 +1099,10 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0 && ring_ok)
+  if (threadIdx.x == 0 && park_slot != 0xFFFFFFFFu)
     atomicExch(&L.park_flags[park_slot], 0u); /* every wave is past its last ring access */
+  if (REFR && threadIdx.x == 0 && pend_slot != 0xFFFFFFFFu)
+    atomicExch(&L.pend_flags[pend_slot], 0u); /* ... and past its last pop */
 }
 
 #endif /* PT_BODY_QUEUED_H */

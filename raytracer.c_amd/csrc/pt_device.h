@@ -309,6 +309,7 @@ hipError_t pt_launch_build_hull_flags(const double *tri_geom, const double *tri_
 hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream);
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws = true);
 bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant); /* a kernel with a pending-ray stack */
+uint32_t pt_kernel_pend_columns(const PtSceneView &scene, uint32_t integrator, int variant);  /* stacks per slot of its pool */
 hipError_t pt_launch_selftest_xcc(unsigned int *counts, uint32_t n_workgroups, hipStream_t stream);
 hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream);
 hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,

@@ -117,6 +117,19 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED) void pt_r
 {
   render_tiles_queued<false, true>(L);
 }
+/* hierarchy scenes with M_REFRACTION: parked walks + windowed sums + pending second children that travel with a path, also
+ * through the ring (render_tiles_queued, REFR); the windows of four tiles leave two workgroups per CU */
+#ifndef PT_MIN_WAVES_QUEUED_REFR
+#define PT_MIN_WAVES_QUEUED_REFR 2
+#endif
+extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED_REFR) void pt_render_tiles_tri_queued_refr(const PtLaunch L)
+{
+  render_tiles_queued<true, false, true>(L);
+}
+extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED_REFR) void pt_render_tiles_tri_queued_refr_sph(const PtLaunch L)
+{
+  render_tiles_queued<true, true, true>(L);
+}
 /* small sphere scenes with M_REFRACTION on the pooled body (render_tiles_pooled, REFR) */
 #ifndef PT_MIN_WAVES_REFR_POOL
 #define PT_MIN_WAVES_REFR_POOL 4
@@ -618,7 +631,7 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
 /* have_park_ws = false: the parked-walk kernels' workspace is missing (its allocation failed): the lane-waiting kernels */
 static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name, bool have_park_ws = true)
 {
-  static const char *const names[31] = {
+  static const char *const names[33] = {
       "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
       "pt_render_tiles_chk",  "pt_render_tiles_big_chk",  "pt_render_tiles_tri_chk",  "pt_render_tiles_tri_big_chk",
       "pt_render_tiles_refr", "pt_render_tiles_big_refr", "pt_render_tiles_tri_refr", "pt_render_tiles_tri_big_refr",
@@ -627,7 +640,7 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
       "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk", "pt_render_tiles_tri_queued_sph",
       "pt_render_tiles_pool_mem", "pt_render_tiles_pool_mem_chk", "pt_render_tiles_pool_mem_tri", "pt_render_tiles_pool_mem_tri_chk",
       "pt_render_tiles_pool_mem_s", "pt_render_tiles_pool_mem_s_chk", "pt_render_tiles_refr_pool", "pt_render_tiles_refr_pool_mem",
-      "pt_render_tiles_tri_refr_pool"};
+      "pt_render_tiles_tri_refr_pool", "pt_render_tiles_tri_queued_refr", "pt_render_tiles_tri_queued_refr_sph"};
   const bool tris = scene.n_triangles != 0;
   const bool big = !pt_filter_in_lds(scene);
   const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
@@ -658,6 +671,11 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
   if (which == 10 && variant != 7)
     which = 30; /* ... with a small mesh */ /* small staged sphere scenes with M_REFRACTION: the pooled body (variant 7: the static one, for A/B; the launcher also
                  * falls back to it for launches whose sample x depth product could overflow the windowed sums) */
+  /* hierarchy scenes with M_REFRACTION: the parked-walk body's refraction form, under the conditions of its other forms (variant 7:
+   * the static kernel, for A/B; the launcher also falls back to it when the windowed sums could overflow) */
+  if (which == 11 && variant != 7 && variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) &&
+      scene.n_triangles < (1u << (23 - PT_BVH_COUNT_BITS)) && have_park_ws)
+    which = scene.mesh_round ? 32 : 31;
   if (which >= 19 && which <= 21 && !have_park_ws)
     which = which == 20 ? 7 : 3; /* no ring workspace: the lane-waiting kernels need none */
   if (name)
@@ -668,7 +686,14 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
 bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant)
 {
   const int which = pt_pick_kernel(scene, integrator, variant, nullptr);
-  return (which >= 8 && which <= 11) || which == 17 || which == 18 || (which >= 28 && which <= 30); /* _refr, pt_render_tiles_mem, pt_whitted_tiles_mem, _refr_pool[_mem] */
+  return (which >= 8 && which <= 11) || which == 17 || which == 18 || (which >= 28 && which <= 32); /* _refr, pt_render_tiles_mem, pt_whitted_tiles_mem, _refr_pool[_mem], _tri_queued_refr */
+}
+
+/* stacks per slot of the pending-ray pool: the parked-walk refraction kernels keep up to 512 path ids per wave */
+uint32_t pt_kernel_pend_columns(const PtSceneView &scene, uint32_t integrator, int variant)
+{
+  const int which = pt_pick_kernel(scene, integrator, variant, nullptr);
+  return (which == 31 || which == 32) ? 4u * 512u : PT_PEND_COLUMNS;
 }
 
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws)
@@ -725,7 +750,7 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }();
   size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
   typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[31] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
+  static const Kernel family[33] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
                                     pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
                                     pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr,
                                     pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
@@ -733,7 +758,8 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
                                     pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph,
                                     pt_render_tiles_pool_mem, pt_render_tiles_pool_mem_chk, pt_render_tiles_pool_mem_tri,
                                     pt_render_tiles_pool_mem_tri_chk, pt_render_tiles_pool_mem_s, pt_render_tiles_pool_mem_s_chk,
-                                    pt_render_tiles_refr_pool, pt_render_tiles_refr_pool_mem, pt_render_tiles_tri_refr_pool};
+                                    pt_render_tiles_refr_pool, pt_render_tiles_refr_pool_mem, pt_render_tiles_tri_refr_pool,
+                                    pt_render_tiles_tri_queued_refr, pt_render_tiles_tri_queued_refr_sph};
   int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr,
                              launch.park_ws != nullptr && launch.park_slots_per_xcd != 0u);
   /* the pooled refraction kernel's windowed sums hold 2^31 pieces per word: a sample of a refractive scene has at most
@@ -745,16 +771,22 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
     which = pt_geom_in_lds(launch.scene) ? 8 : 17;
   if (which == 30 && !pt_refr_pool_fits(launch.samples, launch.max_depth))
     which = 10;
+  if ((which == 31 || which == 32) && (!pt_refr_pool_fits(launch.samples, launch.max_depth) ||
+                                       launch.pend_slot_doubles < (uint64_t)launch.pend_entries * PT_PEND_FIELDS_HOST * 4u * 512u))
+    which = 11; /* (... or when the pool was not sized for 4 x 512 stacks per slot) */
   const Kernel kernel = family[which];
   if ((which >= 22 && which <= 27) || which == 29)
     lds_bytes = extra_lds; /* the in-memory pooled kernels stage nothing, whatever the scene's size */
-  if (((which >= 8 && which <= 11) || which == 17 || which == 18 || (which >= 28 && which <= 30)) &&
+  if (((which >= 8 && which <= 11) || which == 17 || which == 18 || (which >= 28 && which <= 32)) &&
       (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
     return hipErrorInvalidValue; /* a kernel with a pending-ray stack needs its pool (rt_hip_shim.hip: pend_pool_for) */
-  if (which >= 19 && which <= 21) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
+  const bool queued = (which >= 19 && which <= 21) || which == 31 || which == 32;
+  if (queued) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
                  (((size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u);
-  if (lds_bytes > 64 * 1024)
+  if (which == 31 || which == 32) /* ... then the four tiles' windowed pixel sums */
+    lds_bytes += (size_t)(PT_BLOCK / 64) * PT_TILE_PIXELS * 3u * 6u * sizeof(unsigned long long);
+  if (lds_bytes > 64 * 1024 || which == 31 || which == 32) /* (31, 32: ~46 KB of dynamic next to ~31 KB of static LDS) */
   { /* the attribute belongs to the (kernel, current device) pair: set whenever it is needed -- a process-wide
      * "already raised" note would skip devices 1..N-1 of the multi-device path (round-2 advisor finding) */
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -770,7 +802,7 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }
   /* the parked-walk kernels render a tile per wave, four work units per workgroup */
   const uint32_t n_units = launch.tile_count * launch.sample_chunks;
-  hipLaunchKernelGGL(kernel, dim3((which >= 19 && which <= 21) ? (n_units + PT_BLOCK / 64 - 1) / (PT_BLOCK / 64) : n_units), dim3(PT_BLOCK), lds_bytes,
+  hipLaunchKernelGGL(kernel, dim3(queued ? (n_units + PT_BLOCK / 64 - 1) / (PT_BLOCK / 64) : n_units), dim3(PT_BLOCK), lds_bytes,
                      stream, launch);
   if (launch.sample_chunks > 1)
     hipLaunchKernelGGL(pt_resolve_tiles, dim3(launch.tile_count), dim3(PT_BLOCK), 0, stream, launch);

@@ -234,41 +234,55 @@ __device__ __forceinline__ double win_value(const unsigned long long *w)
   return v;
 }
 
-/* ids of the pending-ray stacks of the pooled refraction kernel: 128 per wave (a wave never holds more than 64 paths in its lanes
- * and 64 on its waiting list), handed out lazily -- at a path's first M_REFRACTION hit -- from a 128-bit free mask in LDS, by
+/* ids of the pending-ray stacks of the pooled refraction kernels: 128 per wave in render_tiles_pooled (a wave never holds more than
+ * 64 paths in its lanes and 64 on its waiting list), 511 in render_tiles_queued (lanes + list + up to 382 parked rays in its
+ * ring), handed out lazily -- at a path's first M_REFRACTION hit -- from a free mask of WORDS 64-bit words in LDS, by
  * compare-and-swap: lanes of one wave contend in lock step, one wins per round, and few ask in the same trip */
+template <uint32_t WORDS = 2u>
 __device__ __forceinline__ uint32_t pend_id_take(unsigned long long *free_mask)
 {
   for (;;)
   {
-    const unsigned long long m0 = free_mask[0];
-    unsigned long long *word = m0 ? &free_mask[0] : &free_mask[1];
-    const unsigned long long m = m0 ? m0 : free_mask[1];
+    uint32_t w = 0u;
+    unsigned long long m = free_mask[0];
+#pragma unroll
+    for (uint32_t k = 1u; k < WORDS; k++)
+      if (m == 0ull)
+      {
+        m = free_mask[k];
+        w = k;
+      }
     if (m == 0ull)
-      return 0xFFu; /* (cannot happen: 128 ids for at most 128 paths) */
+      return 64u * WORDS; /* none free (cannot happen: as many ids as a wave can hold paths) */
     const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-    if (atomicCAS(word, m, m & ~(1ull << bit)) == m)
-      return bit + (m0 ? 0u : 64u);
+    if (atomicCAS(&free_mask[w], m, m & ~(1ull << bit)) == m)
+      return bit + 64u * w;
   }
 }
 __device__ __forceinline__ void pend_id_give(unsigned long long *free_mask, uint32_t id)
 {
   atomicOr(&free_mask[id >> 6], 1ull << (id & 63u));
 }
-/* the pooled refraction kernel's view of a path's stack: the id is taken at the FIRST push (most paths never meet an
- * M_REFRACTION surface and never ask), records are [id][entry][field], 80 contiguous bytes */
-struct PoolStack
+/* the pooled refraction kernels' view of a path's stack: the id is taken at the FIRST push (most paths never meet an
+ * M_REFRACTION surface and never ask), records are [id][entry][field], 80 contiguous bytes.  IDS = ids per wave (a power of
+ * two); NONE = "no id yet" (0xFF in render_tiles_pooled, whose meta word has eight bits for it; IDS - 1 in render_tiles_queued,
+ * whose last id is never handed out: its free mask starts without it, 511 ids for at most 510 paths) */
+template <uint32_t IDS, uint32_t NONE>
+struct PoolStackT
 {
-  double *wave_base;             /* the wave's 128 stacks in the workgroup's pool slot */
+  double *wave_base;             /* the wave's stacks in the workgroup's pool slot */
   unsigned long long *free_mask; /* LDS: the wave's free ids */
-  uint32_t *id;                  /* the path's id (a register of the calling lane), 0xFF: none yet */
+  uint32_t *id;                  /* the path's id (a register of the calling lane), NONE: none yet */
   int capacity;                  /* entries per stack */
-  /* (min: an id of 0xFF -- "none free", which 128 ids for at most 128 paths rule out -- must not address another wave's stacks) */
-  __device__ __forceinline__ double *rec(int e) const { return wave_base + ((size_t)min(*id, 127u) * (uint32_t)capacity + (uint32_t)e) * PT_PEND_FIELDS; }
+  /* (min: "none free" -- which more ids than paths rule out -- must not address another wave's stacks) */
+  __device__ __forceinline__ double *rec(int e) const { return wave_base + ((size_t)min(*id, IDS - 1u) * (uint32_t)capacity + (uint32_t)e) * PT_PEND_FIELDS; }
   __device__ __forceinline__ void push(int e, const V3 &o, const V3 &d, const V3 &T, int depth) const
   {
-    if (*id == 0xFFu)
-      *id = pend_id_take(free_mask);
+    if (*id == NONE)
+    {
+      const uint32_t got = pend_id_take<IDS / 64u>(free_mask);
+      *id = got >= IDS ? NONE : got;
+    }
     double *q = rec(e);
     q[0] = o.x; q[1] = o.y; q[2] = o.z;
     q[3] = d.x; q[4] = d.y; q[5] = d.z;
@@ -293,6 +307,7 @@ struct PoolStack
     depth = (int)__double_as_longlong(v[9]);
   }
 };
+typedef PoolStackT<128u, 0xFFu> PoolStack; /* render_tiles_pooled */
 
 /* a slot of a pool of `per` slots per XCD with one in-use flag each (zero between launches) */
 __device__ __forceinline__ uint32_t pt_pool_acquire(uint32_t *flags_base, uint32_t per)

@@ -484,7 +484,7 @@ void park_drop_ws(int device)
 struct PendPool
 {
   char *ws = nullptr;
-  uint32_t entries = 0;
+  uint32_t entries = 0, columns = 0;
 };
 std::mutex g_pend_mutex; /* held from the pool lookup until the launch that uses it is enqueued (so that a growing
                           * launch's hipDeviceSynchronize covers every kernel that holds the old pointer) */
@@ -493,21 +493,23 @@ PendPool g_pend[64];
 size_t pend_flag_bytes() { return ((size_t)PT_PARK_XCDS * PT_PEND_SLOTS_PER_XCD * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
 /* caller holds g_pend_mutex; the current device is `device` */
-int pend_pool_for(int device, uint32_t entries, PtLaunch &L)
+int pend_pool_for(int device, uint32_t entries, uint32_t columns, PtLaunch &L)
 {
   if (device < 0 || device >= 64)
     return fail(RT_HIP_ENODEV, "device %d: no pending-ray pool", device);
   PendPool &p = g_pend[device];
-  if (p.entries < entries)
+  if (p.entries < entries || p.columns < columns)
   {
+    entries = std::max(entries, p.entries); /* grown in either direction, never shrunk */
+    columns = std::max(columns, p.columns);
     if (p.ws)
     {
       HIP_TRY(hipDeviceSynchronize());
       (void)hipFree(p.ws);
       p.ws = nullptr;
-      p.entries = 0;
+      p.entries = p.columns = 0;
     }
-    const size_t slot_bytes = (size_t)entries * PT_PEND_FIELDS_HOST * PT_PEND_COLUMNS * sizeof(double);
+    const size_t slot_bytes = (size_t)entries * PT_PEND_FIELDS_HOST * columns * sizeof(double);
     const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PEND_SLOTS_PER_XCD;
     char *ws = nullptr;
     hipError_t e = hipMalloc(&ws, pend_flag_bytes() + n_slots * slot_bytes);
@@ -524,12 +526,13 @@ int pend_pool_for(int device, uint32_t entries, PtLaunch &L)
     }
     p.ws = ws;
     p.entries = entries;
+    p.columns = columns;
   }
   L.pend_flags = reinterpret_cast<uint32_t *>(p.ws);
   L.pend_ws = reinterpret_cast<double *>(p.ws + pend_flag_bytes());
   L.pend_slots_per_xcd = PT_PEND_SLOTS_PER_XCD;
   L.pend_entries = p.entries; /* slots are laid out for the pool's depth; a shallower launch uses a prefix of each */
-  L.pend_slot_doubles = (uint64_t)p.entries * PT_PEND_FIELDS_HOST * PT_PEND_COLUMNS;
+  L.pend_slot_doubles = (uint64_t)p.entries * PT_PEND_FIELDS_HOST * p.columns;
   return RT_HIP_OK;
 }
 
@@ -1289,7 +1292,7 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   if (pt_kernel_needs_pend_pool(L.scene, L.integrator, kernel_variant()))
   {
     std::lock_guard<std::mutex> pend_lock(g_pend_mutex);
-    rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, L);
+    rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, pt_kernel_pend_columns(L.scene, L.integrator, kernel_variant()), L);
     if (rc)
     {
       release_tables(scene, slot, static_cast<hipStream_t>(stream));

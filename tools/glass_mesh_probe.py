@@ -24,7 +24,26 @@ def run(sc, what):
     gs.close()
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "5":
+if len(sys.argv) > 1 and sys.argv[1] == "check":
+    # small glass-mesh hierarchy scenes against the oracle (the tests' bar), both kernels of the family
+    for p_ in ("oracle", "tests"):
+        sys.path.insert(0, os.path.join(ROOT, p_))
+    import numpy as np
+    import oracle_py
+    from util import assert_parity, fixed_point_floor
+    pt = oracle_py.PtOracle()
+    for (w, h, spp, depth, glass_sphere) in ((64, 36, 3, 5, False), (96, 54, 6, 8, True), (40, 24, 24, 3, True)):
+        sc = S.build_scene(5, w, h, spp, depth)
+        sc.meshes[0].flags = abi.M_REFRACTION
+        if glass_sphere:
+            sc.objects[sc.n_objects - 1].flags = abi.M_REFRACTION
+        mean, rgb8, ost = pt.render_pixels(sc, 1666943821)
+        gs = G.GpuScene(sc)   # (RT_HIP_KERNEL_VARIANT=7 in the environment: the static kernel of the family)
+        img, img8, st = gs.render_image(1666943821)
+        assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=gs.kernel_name(), hdr=True, abs_floor=fixed_point_floor(sc))
+        print(w, h, spp, depth, gs.kernel_name(), "ok", st, flush=True)
+        gs.close()
+elif len(sys.argv) > 1 and sys.argv[1] == "5":
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     sc = S.build_scene(5, None, None, spp, 5)
     run(sc, f"config 5 x {spp} spp, depth 5:")
