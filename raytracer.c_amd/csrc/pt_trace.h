@@ -232,8 +232,20 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
           nd = v_normalize_fast(refr);
           const V3 refl = v_normalize_fast(v_sub(v_scale(d, 1), v_scale(n, 2 * v_dot(v_scale(d, 1), n))));
           const V3 base = v_mul(P.T, albedo);
+          /* both children start on the facet and leave on the side the ray came from (A goes back along it, B is its mirror
+           * image): on a hull facet neither can meet a triangle again (pt_build_hull_flags; the margin as for the mirror
+           * and the diffuse bounce) -- kernels with parked walks skip the probe for them.  B's flag waits with it on the
+           * stack, in bit 16 of its depth word. */
+          int depth_b = P.depth + 1;
+          if (TRIS && (MODE != 0 || DEFER_DIR))
+          {
+            const double an = v_dot(nd, n), bn = v_dot(refl, n);
+            H.leaving = (hull & PT_HULL_PLUS) ? (an > S.hull_margin) : ((hull & PT_HULL_MINUS) ? (-an > S.hull_margin) : false);
+            const bool b_leaves = (hull & PT_HULL_PLUS) ? (bn > S.hull_margin) : ((hull & PT_HULL_MINUS) ? (-bn > S.hull_margin) : false);
+            depth_b |= b_leaves ? 0x10000 : 0;
+          }
           if (stack_n < stack.capacity)
-            stack.push(stack_n++, p, refl, v_scale(base, kr), P.depth + 1);
+            stack.push(stack_n++, p, refl, v_scale(base, kr), depth_b);
           if (!ONE_TERM)
             P.Ls = v_add(P.Ls, v_mul(P.T, emission));
           P.T = v_scale(base, kt);
@@ -300,6 +312,11 @@ __device__ __forceinline__ bool trace_step(const SceneCtx &S, Path &P, uint32_t 
       /* this branch of the tree is done: resume the most recent pending child; the RNG
        * stream simply continues, as it does across the reference's two recursive calls */
       stack.pop(--stack_n, P.o, P.d, P.T, P.depth);
+      if (TRIS && (MODE != 0 || DEFER_DIR))
+      { /* (the child's hull-facet flag: see the push) */
+        H.leaving = (P.depth & 0x10000) != 0;
+        P.depth &= 0xFFFF;
+      }
       path_ends = false;
     }
   }

@@ -41,7 +41,17 @@ def scene_sets(which):
         sets += [("walls %d" % k, walls_scene(k, with_mesh=k >= 4)) for k in range(8)]
         return sets + [("whitted scene", whitted_scene())]
     if which == "convex":    # convex bodies at 64 spp: ~1e6 bounces off hull facets each, all walked
-        return [("convex body %d" % k, convex_body_scene(k, 160, 100, 64)[0]) for k in range(4)]
+        sets = [("convex body %d" % k, convex_body_scene(k, 160, 100, 64)[0]) for k in range(4)]
+        # ... and two of them turned to glass: BOTH children of a refractive hit leave the facet on the side the ray came from
+        # (trace_step: the hull-facet rule for refraction children; pt_render_tiles_tri_queued_refr*)
+        from rt_amd import abi
+        for k in (4, 5):
+            sc = convex_body_scene(k, 160, 100, 32)[0]
+            sc.max_depth = 5
+            for m in range(sc.n_meshes):
+                sc.meshes[m].flags = abi.M_REFRACTION
+            sets.append(("glass convex body %d" % k, sc))
+        return sets
     if which == "rooms":     # rooms of more than 256 spheres (pt_render_tiles_pool_mem: geometry from memory, scalar-table filter)
         from util import packed_room
         return [("room %d" % n, packed_room(n, k, 160, 96, 4, 8)) for k, n in enumerate([249, 500, 1500])]

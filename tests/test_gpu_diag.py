@@ -83,9 +83,12 @@ def test_diag_convex_bodies_zero_violations():
     recs = _run("convex")
     _no_violations(recs)
     path = [r for r in recs if r["integrator"] == "path" and "skipped" not in r]
-    assert len(path) == 4
+    assert len(path) == 6
     for r in path:   # thousands of bounces off hull facets each -- all walked under RT_HIP_DIAG_WALK_REJECTED, none found a triangle
         assert r["left_hull_facet"] > 1000 and r["parked"] > 0, r
+    # the two glass bodies: the parked-walk body's refraction form, whose refraction children (both of a hit) take the rule too
+    glass = [r for r in path if r["scene"].startswith("glass")]
+    assert len(glass) == 2 and all(r["kernel"].startswith("pt_render_tiles_tri_queued_refr") for r in glass), glass
 
 
 def test_diag_full_size_tile_cones_zero_violations():

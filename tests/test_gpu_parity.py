@@ -1325,6 +1325,45 @@ def test_hierarchy_kernel_without_its_workspace(gpu, pt):
     sc.free()
 
 
+@pytest.mark.parametrize("case", ["config5", "convex", "nested"])
+def test_glass_mesh_through_the_hierarchy_on_the_parked_walk_body(gpu, pt, case):
+    """hierarchy scenes with M_REFRACTION (pt_render_tiles_tri_queued_refr[_sph], end of round 4): windowed pixel sums, pending
+    second children whose stack id travels with the path through the waiting list AND the ring, the hull-facet rule for both
+    children of a refractive hit -- frames and counters equal the oracle's linear scan and its recursion (raytracer.c:514-529).
+    config5: the 10,240-triangle sphere turned to glass (+ a glass sphere); convex: a glass polyhedron with a second body
+    inside it (children that leave a hull facet of the outer body must still find the inner one where the rule does not
+    apply); nested: depth 12 and many samples per pixel (long pools: ids are taken and given back thousands of times)"""
+    from rt_amd import abi, scene as S
+    from util import convex_body_scene, fixed_point_floor
+    if case == "config5":
+        sc = S.build_scene(5, 96, 54, 6, 8)
+        sc.meshes[0].flags = abi.M_REFRACTION
+        sc.objects[sc.n_objects - 1].flags = abi.M_REFRACTION
+    elif case == "convex":
+        sc = convex_body_scene(1, 72, 44, 12)[0]       # (odd seed: a second body inside the first)
+        sc.max_depth = 6
+        sc.meshes[0].flags = abi.M_REFRACTION
+    else:
+        sc = convex_body_scene(3, 40, 24, 96)[0]
+        sc.max_depth = 12
+        for m in range(sc.n_meshes):
+            sc.meshes[m].flags = abi.M_REFRACTION | (abi.M_CHECKERED if m else 0)
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name().startswith("pt_render_tiles_tri_queued_refr"), gs.kernel_name()
+    img, img8, st = gs.render_image(SEED)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"glass mesh, {case}", hdr=True,
+                  abs_floor=fixed_point_floor(sc))
+    # any tile partition gives the same bits (windowed integer sums: order-free)
+    total = gpu.n_tiles(sc.width, sc.height)
+    import torch
+    t_all, t8_all, _ = gs.render_tiles(SEED, 0, 1, total)
+    t_odd, t8_odd, _ = gs.render_tiles(SEED, 1, 2, total // 2)
+    torch.cuda.synchronize()
+    assert torch.equal(t_all[1::2][: total // 2], t_odd[: total // 2]) and torch.equal(t8_all[1::2][: total // 2], t8_odd[: total // 2])
+    gs.close()
+
+
 @pytest.mark.parametrize("seed", [3, 4])
 def test_hierarchy_builders_give_the_same_frame(gpu, pt, seed):
     """the hierarchy only decides WHICH triangles get the exact test: the surface-area builder (round 4; 64 bins, within the
