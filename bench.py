@@ -39,7 +39,7 @@ The JSON line also carries
                 exits non-zero when it fails (north star: "within 1e-4 per-channel RMS ... in the same run");
   configs       (N = 1) the other BASELINE configurations on the same GPU, all at their own sizes --
                 ms per frame, ray-bounces/s, kernel, fractions, and a parity block each;
-  integrators   (N = 1) trace_path's M_REFRACTION branch (a glass scene) and cast_ray, 1920x1080, with
+  integrators   (N = 1) trace_path's M_REFRACTION branch (a glass scene; config 5's mesh turned to glass, 4K) and cast_ray, 1920x1080, with
                 kernel, registers / scratch, and a parity block each;
   assembly_check (N > 1) the frame gathered from the N ranks against rank 0's own render of 2,048 of its tiles, bit for bit;
   phase_ms, ranks_seen, rank_kernel_ms, host_path   (N > 1) where a frame's time goes, how many
@@ -271,6 +271,12 @@ def make_scene(name, width=None, height=None, spp=None, depth=None):
               share the reference's own generator gives that material (main.c:107-115: r > 0.8) --, MAX_DEPTH 5: what
               trace_path's two-child branch (raytracer.c:514-539) costs; the `integrators` entries of the N = 1 line"""
     from rt_amd import abi, scene as S
+    if name == "glass_mesh":
+        # config 5's scene with its 10,240-triangle mesh turned M_REFRACTION, MAX_DEPTH 5: the two-child branch through the
+        # hierarchy (pt_render_tiles_tri_queued_refr*: parked walks + windowed sums + pending children that travel through the ring)
+        sc = S.build_scene(5, width, height, spp, GLASS_DEPTH if depth is None else depth)
+        sc.meshes[0].flags = abi.M_REFRACTION
+        return sc
     if name != "glass":
         return S.build_scene(int(name), width, height, spp, depth)
     room = S.build_scene(4, width, height, spp)
@@ -506,7 +512,7 @@ def integrator_line(kind, dev, parity_tiles=0, cpu_workers=0):
     ISA statistics, and the same-run parity block against the reference's compiled code."""
     import torch
     from rt_amd import abi, gpu as G
-    name, spp, integrator = ("glass", 64, "path") if kind == "glass" else ("4", 16, "whitted")
+    name, spp, integrator = {"glass": ("glass", 64, "path"), "glass_mesh": ("glass_mesh", 16, "path")}.get(kind, ("4", 16, "whitted"))
     sc = make_scene(name, None, None, spp)
     gs = G.GpuScene(sc, device=dev.index)
     total = G.n_tiles(sc.width, sc.height)
@@ -526,9 +532,11 @@ def integrator_line(kind, dev, parity_tiles=0, cpu_workers=0):
     ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     rays, casts, tests, samples = [int(v) / steps for v in stats.cpu().tolist()]
     kernel = gs.kernel_name(integrator)
-    line = {"integrator": "trace_path, M_REFRACTION scene (raytracer.c:514-539)" if kind == "glass" else "cast_ray (raytracer.c:556-641)",
-            "workload": f"{'config 4 room, every fifth packed sphere M_REFRACTION' if kind == 'glass' else 'BASELINE configs[3] scene'}: "
-                        f"{sc.width}x{sc.height}, {sc.samples} spp, {sc.n_objects} spheres, depth {sc.max_depth}",
+    what = {"glass": ("trace_path, M_REFRACTION scene (raytracer.c:514-539)", "config 4 room, every fifth packed sphere M_REFRACTION"),
+            "glass_mesh": ("trace_path, M_REFRACTION mesh through the hierarchy (raytracer.c:514-539)",
+                           "BASELINE configs[4] scene with its mesh turned M_REFRACTION")}.get(kind, ("cast_ray (raytracer.c:556-641)", "BASELINE configs[3] scene"))
+    line = {"integrator": what[0],
+            "workload": f"{what[1]}: {sc.width}x{sc.height}, {sc.samples} spp, {sc.n_objects} spheres + {sc.n_triangles} triangles, depth {sc.max_depth}",
             "kernel": kernel, "kernel_ms": ms, "steps": steps,
             "ray_bounces_per_s": casts / (ms * 1e-3), "scene_scans_note": "ray-bounces = scene scans (cast_ray: primary + shadow rays)",
             "mpixel_samples_per_s": samples / (ms * 1e-3) * 1e-6, "rays_per_sample": rays / max(samples, 1),
@@ -536,9 +544,11 @@ def integrator_line(kind, dev, parity_tiles=0, cpu_workers=0):
     if parity_tiles:
         try:
             image, image8 = gs.untile(tiles, tiles8, 0, 1, total)
-            _, sample = cpu_reference(name, sc.width, sc.height, sc.samples, sc.max_depth, sc.n_meshes, parity_tiles, cpu_workers,
+            # (the glass mesh: 64 tiles around the frame's centre, on the mesh -- 10,248 primitive tests per scan on the CPU)
+            budget = (135 * 480 + 208, 1, 64) if kind == "glass_mesh" else parity_tiles
+            _, sample = cpu_reference(name, sc.width, sc.height, sc.samples, sc.max_depth, sc.n_meshes, budget, cpu_workers,
                                       integrator=integrator)
-            line["parity"] = gpu_parity(gs, sc, dev, sample, image, image8, integrator=integrator, hdr=(kind == "glass"))
+            line["parity"] = gpu_parity(gs, sc, dev, sample, image, image8, integrator=integrator, hdr=(kind in ("glass", "glass_mesh")))
         except Exception as exc:
             line["parity"] = {"ok": False, "error": repr(exc)}
     gs.close()
@@ -741,7 +751,7 @@ def main():
     if args.integrators_only:
         import torch
         dev = torch.device("cuda", 0)
-        print(json.dumps({"integrators": [integrator_line(k, dev) for k in ("glass", "cast_ray")]}), flush=True)
+        print(json.dumps({"integrators": [integrator_line(k, dev) for k in ("glass", "glass_mesh", "cast_ray")]}), flush=True)
         return 0
 
     import torch
@@ -951,7 +961,7 @@ def main():
                     lines.append({"config": cfg, "error": repr(exc)})
             out["configs"] = lines
             ints = []
-            for kind in ("glass", "cast_ray"):
+            for kind in ("glass", "glass_mesh", "cast_ray"):
                 try:
                     ints.append(integrator_line(kind, dev, parity_tiles=0 if args.no_parity or args.cpu_tiles <= 0 else 1024,
                                                 cpu_workers=args.cpu_workers))

@@ -33,7 +33,7 @@
  * Kernel family: pt_render_tiles[_tri][_big][_chk] (pooled body, by scene content), pt_render_tiles_pool_mem* (the same body
  * with geometry read from memory: scenes beyond the LDS staging budget, and sphere scenes beyond ~85 spheres by preference),
  * pt_render_tiles_refr_pool (the same body for small sphere scenes with M_REFRACTION: windowed pixel sums, pending rays that
- * travel with a path), pt_render_tiles_tri_queued* (hierarchy scenes: parked walks), pt_render_tiles[..]_refr and
+ * travel with a path), pt_render_tiles_tri_queued* (hierarchy scenes: parked walks; _refr: with M_REFRACTION), pt_render_tiles[..]_refr and
  * pt_whitted_tiles[..] (static body: refraction's two-child tree where the pooled kernel does not apply, and cast_ray,
  * raytracer.c:556-641), see pt_pick_kernel.
  *
@@ -60,7 +60,7 @@
  *   pt_scene_ctx.h    SceneCtx / stage_scene, Path, pending-ray stacks, windowed sums, camera, start_sample
  *   pt_trace.h        trace_step (trace_path), whitted_step (cast_ray), finish_pixels / store_tile
  *   pt_body_pooled.h  render_tiles_pooled   (pt_render_tiles[_tri][_big][_chk], _pool_mem*, _refr_pool*)
- *   pt_body_queued.h  render_tiles_queued   (pt_render_tiles_tri_queued*: parked walks)
+ *   pt_body_queued.h  render_tiles_queued   (pt_render_tiles_tri_queued*: parked walks, also with M_REFRACTION)
  *   pt_body_static.h  render_tiles_static   (pt_render_tiles_v0, *_refr, pt_whitted_tiles*, *_mem)
  * This file keeps the kernel entry points (the family, by scene content), the table-building and self-test kernels, pt_untile,
  * and the host-side launchers (pt_pick_kernel, pt_launch_render) declared in pt_device.h.
