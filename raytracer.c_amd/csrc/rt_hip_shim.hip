@@ -1292,7 +1292,12 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   if (pt_kernel_needs_pend_pool(L.scene, L.integrator, kernel_variant()))
   {
     std::lock_guard<std::mutex> pend_lock(g_pend_mutex);
-    rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, pt_kernel_pend_columns(L.scene, L.integrator, kernel_variant()), L);
+    const uint32_t columns = pt_kernel_pend_columns(L.scene, L.integrator, kernel_variant());
+    rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, columns, L);
+    /* the parked-walk refraction kernels want four times the stacks per slot (1.2 GB at depth 5, 5.7 GB at 32): where that
+     * cannot be had, the pool of the other kernels will do -- pt_launch_render then takes the static kernel of the family */
+    if (rc == RT_HIP_ENOMEM && columns > PT_PEND_COLUMNS)
+      rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, PT_PEND_COLUMNS, L);
     if (rc)
     {
       release_tables(scene, slot, static_cast<hipStream_t>(stream));
