@@ -1325,14 +1325,16 @@ def test_hierarchy_kernel_without_its_workspace(gpu, pt):
     sc.free()
 
 
-@pytest.mark.parametrize("case", ["config5", "convex", "nested"])
+@pytest.mark.parametrize("case", ["config5", "convex", "nested", "deep"])
 def test_glass_mesh_through_the_hierarchy_on_the_parked_walk_body(gpu, pt, case):
     """hierarchy scenes with M_REFRACTION (pt_render_tiles_tri_queued_refr[_sph], end of round 4): windowed pixel sums, pending
     second children whose stack id travels with the path through the waiting list AND the ring, the hull-facet rule for both
     children of a refractive hit -- frames and counters equal the oracle's linear scan and its recursion (raytracer.c:514-529).
     config5: the 10,240-triangle sphere turned to glass (+ a glass sphere); convex: a glass polyhedron with a second body
     inside it (children that leave a hull facet of the outer body must still find the inner one where the rule does not
-    apply); nested: depth 12 and many samples per pixel (long pools: ids are taken and given back thousands of times)"""
+    apply); nested: depth 12 and many samples per pixel (long pools: ids are taken and given back thousands of times); deep:
+    max_depth 29 -- samples x 2^(max_depth + 2) beyond what the windowed sums hold, so the launcher takes the static kernel of the
+    family (which finds the wide pool's slots laid out for it as well)"""
     from rt_amd import abi, scene as S
     from util import convex_body_scene, fixed_point_floor
     if case == "config5":
@@ -1343,11 +1345,15 @@ def test_glass_mesh_through_the_hierarchy_on_the_parked_walk_body(gpu, pt, case)
         sc = convex_body_scene(1, 72, 44, 12)[0]       # (odd seed: a second body inside the first)
         sc.max_depth = 6
         sc.meshes[0].flags = abi.M_REFRACTION
-    else:
+    elif case == "nested":
         sc = convex_body_scene(3, 40, 24, 96)[0]
         sc.max_depth = 12
         for m in range(sc.n_meshes):
             sc.meshes[m].flags = abi.M_REFRACTION | (abi.M_CHECKERED if m else 0)
+    else:
+        sc = convex_body_scene(5, 32, 20, 2)[0]
+        sc.max_depth = 29
+        sc.meshes[0].flags = abi.M_REFRACTION
     gs = gpu.GpuScene(sc)
     assert gs.kernel_name().startswith("pt_render_tiles_tri_queued_refr"), gs.kernel_name()
     img, img8, st = gs.render_image(SEED)
