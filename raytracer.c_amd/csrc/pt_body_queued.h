@@ -53,7 +53,8 @@
 #endif
 #define PT_PARK_F64_FIELDS 13u /* o xyz, d xyz, T xyz, rng, min_t, (M_CHECKERED kernels: last u, v) */
 #define PT_PARK_U32_FIELDS 4u  /* best, depth << 6 | pixel slot, (last index), pad */
-static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * 128u + PT_TILE_PIXELS * 8u && PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u <= 128u, "ring bytes per wave");
+static_assert(PT_PARK_WAVE_BYTES >= PT_PARK_Q * 128u + PT_TILE_PIXELS * 8u + PT_PARK_WIN_BYTES && PT_PARK_F64_FIELDS * 8u + PT_PARK_U32_FIELDS * 4u <= 128u, "ring bytes per wave");
+static_assert(PT_PARK_WIN_BYTES == PT_TILE_PIXELS * 3u * 6u * 8u, "the refraction form's windows: PT_WIN_N words per pixel channel");
 static_assert((PT_PARK_Q & (PT_PARK_Q - 1u)) == 0u && PT_PARK_WALK + 126u <= PT_PARK_Q, "ring size: see PT_PARK_Q");
 
 /* Entry-major, in three regions per wave, by who touches what:
@@ -400,8 +401,8 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
 
 /* REFR (pt_render_tiles_tri_queued_refr[_sph], end of round 4): hierarchy scenes with M_REFRACTION materials, until then on the
  * static body (every lane walks the hierarchy on the spot).  What render_tiles_pooled's REFR form needs, here: pixel sums without a
- * bound on a term (win_add: six signed 64-bit windows per channel, in dynamic LDS behind the traversal stacks -- 9 KB per wave's
- * tile, which leaves two workgroups per CU), and pending second children in stacks addressed by a path id that travels with the
+ * bound on a term (win_add: six signed 64-bit windows per channel -- 9 KB per wave's tile, kept at the end of the wave's
+ * workspace region and added to with global integer atomics, see below), and pending second children in stacks addressed by a path id that travels with the
  * path -- through the waiting list (meta word) and, new here, through the ring (word 3 of an entry): a wave can hold 64 paths in
  * lanes, 64 on its list and up to 382 in its ring, so ids are 9 bits (PoolStackT<512, 511>: 511 ids for at most 510 paths) and a
  * workgroup's slot of the pending-ray pool holds 4 x 512 stacks (PtLaunch.pend_slot_doubles: pend_pool_for sizes it). */
@@ -481,12 +482,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     stack.ovf = nullptr; /* set below, once the wave's ring is known */
 #endif
   }
-  /* REFR: the windowed pixel sums of the four tiles follow the stacks (pt_launch_render sizes the dynamic LDS) */
-  unsigned long long *const pix_win_all =
-      reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(stack.lo) + (((size_t)max(L.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u));
   {
-    unsigned long long *z = REFR ? pix_win_all : &pix_sum_all[0][0];
-    for (uint32_t k = threadIdx.x; k < (PT_BLOCK / 64) * PT_TILE_PIXELS * 3 * (REFR ? PT_WIN_N : 1); k += PT_BLOCK)
+    unsigned long long *z = &pix_sum_all[0][0];
+    for (uint32_t k = threadIdx.x; k < (REFR ? 1u : (PT_BLOCK / 64) * PT_TILE_PIXELS * 3); k += PT_BLOCK)
       z[k] = 0;
     if (threadIdx.x < (PT_BLOCK / 64) * 3)
       (&pix_nan_all[0][0])[threadIdx.x] = 0;
@@ -545,6 +543,25 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 #ifdef PT_BVH_WIDE
   stack.ovf = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ring.f) + PT_PARK_Q * 128u + 512u);
 #endif
+  /* REFR: the windowed pixel sums of this wave's tile live in the LAST bytes of its workspace region, not in LDS: in LDS the
+   * four tiles' 36.9 KB left two workgroups per CU, and at two waves per SIMD this kernel waits (VALU busy 53 %: the walk's
+   * dependent fetches, the ring's round trips).  Integer atomics at the XCD's L2 instead -- only lanes whose trip has a
+   * non-zero term issue any, a few per cent of the L2's atomic rate --, zeroed here by the wave itself (its own earlier
+   * stores and its later atomics reach the L2 in issue order), read back L1-bypassing in the epilogue. */
+  auto pix_win_now = [&] {
+    uint32_t off = PT_PARK_WAVE_BYTES - PT_PARK_WIN_BYTES;
+    asm volatile("" : "+v"(off));
+    return reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ring.f) + off);
+  };
+  auto pend_wave_now = [&] {
+    return L.pend_ws + (size_t)pend_slot * L.pend_slot_doubles + (size_t)wave_now() * 512u * L.pend_entries * PT_PEND_FIELDS;
+  };
+  if (REFR && has_unit && ring_ok)
+  {
+    unsigned long long *const pix_win = pix_win_now();
+    for (uint32_t k = lane_of_thread(); k < PT_TILE_PIXELS * 3 * PT_WIN_N; k += 64u)
+      pix_win[k] = 0ull;
+  }
   /* can a camera ray of this wave's tile reach the triangles' bounding ball at all?  (tile_cull's cone test, for the probe's
    * own ball: its r2_hi is the radius squared plus the filter's widening, far more than the centre's rounding to fp32) */
   const bool tile_sees_mesh =
@@ -591,9 +608,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   int stack_n = 0;        /* REFR: pending second children of this lane's path */
   uint32_t pend_id = NO_ID; /* REFR: the path's stack id */
   const PendStack no_stack = {nullptr, 0, 0u, 0u};
-  double *const pend_wave = REFR && ring_ok ? L.pend_ws + (size_t)pend_slot * L.pend_slot_doubles +
-                                                  (size_t)(threadIdx.x >> 6) * 512u * L.pend_entries * PT_PEND_FIELDS
-                                            : nullptr;
+  /* (the wave's stacks in the pool slot and -- below -- its windows: addresses formed where they are used, see wave_now) */
   unsigned long long *diag_ptr = L.stats;
   (void)diag_ptr;
   const uint32_t lane = threadIdx.x & 63u;
@@ -935,7 +950,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     {
       if constexpr (REFR)
       {
-        const RingStack mine = {pend_wave, pend_free[wave_now()], &pend_id, (int)L.pend_entries};
+        const RingStack mine = {pend_wave_now(), pend_free[wave_now()], &pend_id, (int)L.pend_entries};
         step_done = trace_step<1, true, CHECKER, TRIS, FILT_LDS, 2, true, true, false, RingStack>(S, P, n_casts, diag_ptr, mine, stack_n, &hit);
       }
       else
@@ -983,7 +998,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       {
         if (REFR)
         { /* no bound on a term: the windowed sums (win_add); a non-finite or oversized term flags the pixel */
-          unsigned long long *const pw = pix_win_all + (size_t)wave_now() * (PT_TILE_PIXELS * 3 * PT_WIN_N) + __umul24(pix_slot, 3u * PT_WIN_N);
+          unsigned long long *const pw = pix_win_now() + __umul24(pix_slot, 3u * PT_WIN_N);
           unsigned long long *const pix_nan = pix_nan_all[wave_now()];
           if (P.Ls.x != 0.0 && !win_add(pw, P.Ls.x)) atomicOr(&pix_nan[0], 1ull << pix_slot);
           if (P.Ls.y != 0.0 && !win_add(pw + PT_WIN_N, P.Ls.y)) atomicOr(&pix_nan[1], 1ull << pix_slot);
@@ -1052,6 +1067,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         atomicAdd(&L.stats[3], (unsigned long long)n_valid * (unsigned long long)L.samples);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); /* the wave's own LDS atomics are done: sums are final */
+    if (REFR)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* ... and its global ones have reached the L2 */
     __builtin_amdgcn_wave_barrier();
     if (L.sample_chunks == 1)
     {
@@ -1062,10 +1079,14 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       V3 mean;
       if (REFR)
       {
-        const unsigned long long *pw = pix_win_all + (size_t)wave_now() * (PT_TILE_PIXELS * 3 * PT_WIN_N) + t * (3u * PT_WIN_N);
-        mean.x = win_value(pw) * inv_s;
-        mean.y = win_value(pw + PT_WIN_N) * inv_s;
-        mean.z = win_value(pw + 2 * PT_WIN_N) * inv_s;
+        /* (the wave's atomics have reached the L2: agent-scope release = s_waitcnt vmcnt(0); the loads bypass the L1) */
+        unsigned long long w[3 * PT_WIN_N];
+#pragma unroll
+        for (uint32_t k = 0; k < 3u * PT_WIN_N; k++)
+          w[k] = __hip_atomic_load(pix_win_now() + t * (3u * PT_WIN_N) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mean.x = win_value(w) * inv_s;
+        mean.y = win_value(w + PT_WIN_N) * inv_s;
+        mean.z = win_value(w + 2 * PT_WIN_N) * inv_s;
       }
       else
       {

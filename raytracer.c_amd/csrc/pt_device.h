@@ -87,11 +87,12 @@
 
 /* parked-walk kernels (pt_render_tiles_tri_queued*): bytes of ring per wave in the workspace, slots
  * (workgroups) per XCD the pool provides: 32 CUs x at most 5 resident workgroups, with slack */
+#define PT_PARK_WIN_BYTES 9216u /* the refraction form's windowed pixel sums of the wave's tile: 64 pixels x 3 channels x 6 words (the LAST bytes of a wave's region) */
 #ifndef PT_PARK_WAVE_BYTES
 #ifdef PT_BVH_WIDE
-#define PT_PARK_WAVE_BYTES (65536u + 512u + 8192u) /* + 32 overflow entries of the four-wide walk's traversal stacks (64 lanes x 4 bytes each) */
+#define PT_PARK_WAVE_BYTES (65536u + 512u + 8192u + PT_PARK_WIN_BYTES) /* + 32 overflow entries of the four-wide walk's traversal stacks (64 lanes x 4 bytes each) */
 #else
-#define PT_PARK_WAVE_BYTES (65536u + 512u) /* 512 entries of 128 bytes (pt_body_queued.h, PT_PARK_Q: why 512), then the tile's 64 per-pixel RNG keys */
+#define PT_PARK_WAVE_BYTES (65536u + 512u + PT_PARK_WIN_BYTES) /* 512 entries of 128 bytes (pt_body_queued.h, PT_PARK_Q: why 512), then the tile's 64 per-pixel RNG keys, then the windows */
 #endif
 #endif
 #define PT_PARK_SLOTS_PER_XCD 192u

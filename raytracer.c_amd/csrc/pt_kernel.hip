@@ -118,9 +118,9 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED) void pt_r
   render_tiles_queued<false, true>(L);
 }
 /* hierarchy scenes with M_REFRACTION: parked walks + windowed sums + pending second children that travel with a path, also
- * through the ring (render_tiles_queued, REFR); the windows of four tiles leave two workgroups per CU */
+ * through the ring (render_tiles_queued, REFR); windowed sums in the workspace (global atomics): LDS as the other forms */
 #ifndef PT_MIN_WAVES_QUEUED_REFR
-#define PT_MIN_WAVES_QUEUED_REFR 2
+#define PT_MIN_WAVES_QUEUED_REFR 3
 #endif
 extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED_REFR) void pt_render_tiles_tri_queued_refr(const PtLaunch L)
 {
@@ -784,9 +784,7 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   if (queued) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
                  (((size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u);
-  if (which == 31 || which == 32) /* ... then the four tiles' windowed pixel sums */
-    lds_bytes += (size_t)(PT_BLOCK / 64) * PT_TILE_PIXELS * 3u * 6u * sizeof(unsigned long long);
-  if (lds_bytes > 64 * 1024 || which == 31 || which == 32) /* (31, 32: ~46 KB of dynamic next to ~31 KB of static LDS) */
+  if (lds_bytes > 64 * 1024)
   { /* the attribute belongs to the (kernel, current device) pair: set whenever it is needed -- a process-wide
      * "already raised" note would skip devices 1..N-1 of the multi-device path (round-2 advisor finding) */
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),

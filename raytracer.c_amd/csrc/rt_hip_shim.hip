@@ -63,7 +63,7 @@ struct RtHipScene
   mutable uint64_t table_clock = 0;
   size_t filt_bytes = 0, bvh_nodes_bytes = 0;
   /* workspace of the parked-walk kernels (scenes with a triangle hierarchy): in-use flags, then the rings
-   * (pt_device.h).  ONE per device, shared by every scene on it and counted (park_acquire_ws / park_drop_ws): the 406 MB
+   * (pt_device.h).  ONE per device, shared by every scene on it and counted (park_acquire_ws / park_drop_ws): the 462 MB
    * used to be allocated per scene -- a test suite's every 48 x 32 fuzz scene paid it, and scenes alive at the same
    * time each held a copy (round-3 advisor finding).  Sharing is safe between concurrent launches of different scenes:
    * a workgroup takes a slot with an atomic flag, and the pool has more slots per XCD than workgroups can be resident. */
