@@ -626,74 +626,115 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
   return doubles * sizeof(double);
 }
 
+/* The kernel family: one row per member.  K_TILES .. K_TRI_BIG_REFR and K_WHITTED .. K_WHITTED_TRI_BIG are laid out so that
+ * "+ 1" = the filter table is not in LDS (_big), "+ 2" = the scene has triangles (_tri), "+ 4" / "+ 8" = M_CHECKERED / M_REFRACTION
+ * materials: pt_pick_kernel forms those indices by arithmetic (the static_asserts below pin the layout). */
+enum PtKernelId
+{
+  K_TILES = 0, K_BIG, K_TRI, K_TRI_BIG,
+  K_CHK, K_BIG_CHK, K_TRI_CHK, K_TRI_BIG_CHK,
+  K_REFR, K_BIG_REFR, K_TRI_REFR, K_TRI_BIG_REFR,
+  K_V0, K_WHITTED, K_WHITTED_BIG, K_WHITTED_TRI, K_WHITTED_TRI_BIG,
+  K_MEM, K_WHITTED_MEM,
+  K_TRI_QUEUED, K_TRI_QUEUED_CHK, K_TRI_QUEUED_SPH,
+  K_POOL_MEM, K_POOL_MEM_CHK, K_POOL_MEM_TRI, K_POOL_MEM_TRI_CHK, K_POOL_MEM_S, K_POOL_MEM_S_CHK,
+  K_REFR_POOL, K_REFR_POOL_MEM, K_TRI_REFR_POOL,
+  K_TRI_QUEUED_REFR, K_TRI_QUEUED_REFR_SPH,
+  K_COUNT
+};
+static_assert(K_CHK == K_TILES + 4 && K_REFR == K_TILES + 8 && K_TRI == K_TILES + 2 && K_BIG == K_TILES + 1 &&
+                  K_WHITTED_TRI == K_WHITTED + 2 && K_WHITTED_BIG == K_WHITTED + 1 && K_POOL_MEM_TRI == K_POOL_MEM + 2 &&
+                  K_POOL_MEM_CHK == K_POOL_MEM + 1 && K_POOL_MEM_S_CHK == K_POOL_MEM_S + 1,
+              "pt_pick_kernel's index arithmetic");
+typedef void (*PtKernelFn)(const PtLaunch);
+struct PtKernelInfo
+{
+  const char *name;
+  PtKernelFn fn;
+  bool pend_pool;    /* pushes pending second children: needs a slot of the pending-ray pool (rt_hip_shim.hip, pend_pool_for) */
+  bool queued;       /* parked walks: a tile per WAVE (four work units per workgroup), filter pairs + traversal stacks in dynamic LDS */
+  bool stages_none;  /* geometry and tables from memory: no staged scene in LDS, whatever the scene's size */
+  bool wide_pend;    /* 4 x 512 stacks per pool slot (path ids that travel through the ring) */
+};
+#define PT_K(fn, pend, queued, none, wide) {#fn, fn, pend, queued, none, wide}
+static const PtKernelInfo pt_kernels[K_COUNT] = {
+    PT_K(pt_render_tiles, false, false, false, false),          PT_K(pt_render_tiles_big, false, false, false, false),
+    PT_K(pt_render_tiles_tri, false, false, false, false),      PT_K(pt_render_tiles_tri_big, false, false, false, false),
+    PT_K(pt_render_tiles_chk, false, false, false, false),      PT_K(pt_render_tiles_big_chk, false, false, false, false),
+    PT_K(pt_render_tiles_tri_chk, false, false, false, false),  PT_K(pt_render_tiles_tri_big_chk, false, false, false, false),
+    PT_K(pt_render_tiles_refr, true, false, false, false),      PT_K(pt_render_tiles_big_refr, true, false, false, false),
+    PT_K(pt_render_tiles_tri_refr, true, false, false, false),  PT_K(pt_render_tiles_tri_big_refr, true, false, false, false),
+    PT_K(pt_render_tiles_v0, false, false, false, false),
+    PT_K(pt_whitted_tiles, false, false, false, false),         PT_K(pt_whitted_tiles_big, false, false, false, false),
+    PT_K(pt_whitted_tiles_tri, false, false, false, false),     PT_K(pt_whitted_tiles_tri_big, false, false, false, false),
+    PT_K(pt_render_tiles_mem, true, false, false, false),       PT_K(pt_whitted_tiles_mem, true, false, false, false),
+    PT_K(pt_render_tiles_tri_queued, false, true, false, false), PT_K(pt_render_tiles_tri_queued_chk, false, true, false, false),
+    PT_K(pt_render_tiles_tri_queued_sph, false, true, false, false),
+    PT_K(pt_render_tiles_pool_mem, false, false, true, false),  PT_K(pt_render_tiles_pool_mem_chk, false, false, true, false),
+    PT_K(pt_render_tiles_pool_mem_tri, false, false, true, false), PT_K(pt_render_tiles_pool_mem_tri_chk, false, false, true, false),
+    PT_K(pt_render_tiles_pool_mem_s, false, false, true, false), PT_K(pt_render_tiles_pool_mem_s_chk, false, false, true, false),
+    PT_K(pt_render_tiles_refr_pool, true, false, false, false), PT_K(pt_render_tiles_refr_pool_mem, true, false, true, false),
+    PT_K(pt_render_tiles_tri_refr_pool, true, false, false, false),
+    PT_K(pt_render_tiles_tri_queued_refr, true, true, false, true), PT_K(pt_render_tiles_tri_queued_refr_sph, true, true, false, true)};
+#undef PT_K
+
 /* which member of the kernel family a launch of this scene takes (the selection of
  * pt_launch_render, also reported by rt_hip_kernel_name for profiles and bench lines) */
 /* have_park_ws = false: the parked-walk kernels' workspace is missing (its allocation failed): the lane-waiting kernels */
 static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name, bool have_park_ws = true)
 {
-  static const char *const names[33] = {
-      "pt_render_tiles",      "pt_render_tiles_big",      "pt_render_tiles_tri",      "pt_render_tiles_tri_big",
-      "pt_render_tiles_chk",  "pt_render_tiles_big_chk",  "pt_render_tiles_tri_chk",  "pt_render_tiles_tri_big_chk",
-      "pt_render_tiles_refr", "pt_render_tiles_big_refr", "pt_render_tiles_tri_refr", "pt_render_tiles_tri_big_refr",
-      "pt_render_tiles_v0",   "pt_whitted_tiles",         "pt_whitted_tiles_big",     "pt_whitted_tiles_tri",
-      "pt_whitted_tiles_tri_big", "pt_render_tiles_mem",  "pt_whitted_tiles_mem",
-      "pt_render_tiles_tri_queued", "pt_render_tiles_tri_queued_chk", "pt_render_tiles_tri_queued_sph",
-      "pt_render_tiles_pool_mem", "pt_render_tiles_pool_mem_chk", "pt_render_tiles_pool_mem_tri", "pt_render_tiles_pool_mem_tri_chk",
-      "pt_render_tiles_pool_mem_s", "pt_render_tiles_pool_mem_s_chk", "pt_render_tiles_refr_pool", "pt_render_tiles_refr_pool_mem",
-      "pt_render_tiles_tri_refr_pool", "pt_render_tiles_tri_queued_refr", "pt_render_tiles_tri_queued_refr_sph"};
   const bool tris = scene.n_triangles != 0;
   const bool big = !pt_filter_in_lds(scene);
   const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
   const bool cast_ray = integrator == 1;
-  int which = cast_ray ? 13 + (tris ? 2 : 0) + (big ? 1 : 0) : (refr ? 8 : (chk ? 4 : 0)) + (tris ? 2 : 0) + (big ? 1 : 0);
+  /* the parked-walk body's conditions: not the A/B variant 2, no scene beyond fp32's comfortable range (its filter needs the
+   * NaN-safe compares), references that fit the walk's 24-bit stack entries */
+  const bool can_park = variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) && scene.n_triangles < (1u << (23 - PT_BVH_COUNT_BITS));
+  int which = cast_ray ? K_WHITTED + (tris ? 2 : 0) + (big ? 1 : 0) : (refr ? K_REFR : (chk ? K_CHK : K_TILES)) + (tris ? 2 : 0) + (big ? 1 : 0);
   /* too large to stage, or cast_ray with two-child materials: the two general kernels */
   const bool in_memory = !pt_geom_in_lds(scene) || (cast_ray && scene.any_mirror_glass);
   if (in_memory)
   {
-    which = cast_ray ? 18 : 17;
+    which = cast_ray ? K_WHITTED_MEM : K_MEM;
     /* trace_path without M_REFRACTION: the pooled body with geometry from memory (variant 3: the static kernel, for A/B) */
     if (!cast_ray && !refr && variant != 3)
-      which = (!tris && !scene.wide_range && variant != 4) ? 26 + (chk ? 1 : 0) : 22 + (tris ? 2 : 0) + (chk ? 1 : 0); /* (variant 4: the compare-form kernel, for A/B) */
+      which = (!tris && !scene.wide_range && variant != 4) ? K_POOL_MEM_S + (chk ? 1 : 0)
+                                                           : K_POOL_MEM + (tris ? 2 : 0) + (chk ? 1 : 0); /* (variant 4: the compare-form kernel, for A/B) */
   }
   else if (variant == 0 && !refr && !cast_ray)
-    which = 12;
+    which = K_V0;
   else if (!cast_ray && variant != 5 && pt_prefer_streaming(scene))
-    which = 26 + (chk ? 1 : 0); /* a sphere scene that would fit the staging budget but is faster streamed (pt_device.h; variant 5: staged, for A/B) */
-  else if ((which == 3 || which == 7) && variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) && scene.n_triangles < (1u << (23 - PT_BVH_COUNT_BITS)))
-    which = which == 3 ? (scene.mesh_round ? 21 : 19) : 20; /* hierarchy scenes: parked walks (variant 2, scenes beyond fp32's comfortable range,
-                                   * whose filter needs the NaN-safe compares, and meshes whose references do not fit the walk's
-                                   * 24-bit stack entries keep the lane-waiting pooled kernels) */
+    which = K_POOL_MEM_S + (chk ? 1 : 0); /* a sphere scene that would fit the staging budget but is faster streamed (pt_device.h; variant 5: staged, for A/B) */
+  else if ((which == K_TRI_BIG || which == K_TRI_BIG_CHK) && can_park)
+    which = which == K_TRI_BIG ? (scene.mesh_round ? K_TRI_QUEUED_SPH : K_TRI_QUEUED) : K_TRI_QUEUED_CHK; /* hierarchy scenes: parked walks (otherwise the lane-waiting pooled kernels) */
   /* refractive sphere scenes that are streamed (beyond the staging budget, or beyond ~85 spheres by preference: pt_stream_sized) */
   if (!cast_ray && refr && !tris && !scene.wide_range && variant != 7 && variant != 3 && (!pt_geom_in_lds(scene) || (variant != 5 && pt_stream_sized(scene))))
-    which = 29;
-  if (which == 8 && variant != 7)
-    which = 28;
-  if (which == 10 && variant != 7)
-    which = 30; /* ... with a small mesh */ /* small staged sphere scenes with M_REFRACTION: the pooled body (variant 7: the static one, for A/B; the launcher also
-                 * falls back to it for launches whose sample x depth product could overflow the windowed sums) */
-  /* hierarchy scenes with M_REFRACTION: the parked-walk body's refraction form, under the conditions of its other forms (variant 7:
-   * the static kernel, for A/B; the launcher also falls back to it when the windowed sums could overflow) */
-  if (which == 11 && variant != 7 && variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) &&
-      scene.n_triangles < (1u << (23 - PT_BVH_COUNT_BITS)) && have_park_ws)
-    which = scene.mesh_round ? 32 : 31;
-  if (which >= 19 && which <= 21 && !have_park_ws)
-    which = which == 20 ? 7 : 3; /* no ring workspace: the lane-waiting kernels need none */
+    which = K_REFR_POOL_MEM;
+  /* small staged scenes with M_REFRACTION: the pooled body (variant 7: the static one, for A/B; the launcher also falls back
+   * to it for launches whose sample x depth product could overflow the windowed sums) */
+  if (which == K_REFR && variant != 7)
+    which = K_REFR_POOL;
+  if (which == K_TRI_REFR && variant != 7)
+    which = K_TRI_REFR_POOL; /* ... with a small mesh */
+  /* hierarchy scenes with M_REFRACTION: the parked-walk body's refraction form, under the conditions of its other forms */
+  if (which == K_TRI_BIG_REFR && variant != 7 && can_park && have_park_ws)
+    which = scene.mesh_round ? K_TRI_QUEUED_REFR_SPH : K_TRI_QUEUED_REFR;
+  if (!have_park_ws && pt_kernels[which].queued) /* no ring workspace: the lane-waiting kernels need none */
+    which = which == K_TRI_QUEUED_CHK ? K_TRI_BIG_CHK : K_TRI_BIG;
   if (name)
-    *name = names[which];
+    *name = pt_kernels[which].name;
   return which;
 }
 
 bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant)
 {
-  const int which = pt_pick_kernel(scene, integrator, variant, nullptr);
-  return (which >= 8 && which <= 11) || which == 17 || which == 18 || (which >= 28 && which <= 32); /* _refr, pt_render_tiles_mem, pt_whitted_tiles_mem, _refr_pool[_mem], _tri_queued_refr */
+  return pt_kernels[pt_pick_kernel(scene, integrator, variant, nullptr)].pend_pool;
 }
 
 /* stacks per slot of the pending-ray pool: the parked-walk refraction kernels keep up to 512 path ids per wave */
 uint32_t pt_kernel_pend_columns(const PtSceneView &scene, uint32_t integrator, int variant)
 {
-  const int which = pt_pick_kernel(scene, integrator, variant, nullptr);
-  return (which == 31 || which == 32) ? 4u * 512u : PT_PEND_COLUMNS;
+  return pt_kernels[pt_pick_kernel(scene, integrator, variant, nullptr)].wide_pend ? 4u * 512u : PT_PEND_COLUMNS;
 }
 
 const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws)
@@ -749,38 +790,28 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
     return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)0;
   }();
   size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
-  typedef void (*Kernel)(const PtLaunch);
-  static const Kernel family[33] = {pt_render_tiles,      pt_render_tiles_big,      pt_render_tiles_tri,      pt_render_tiles_tri_big,
-                                    pt_render_tiles_chk,  pt_render_tiles_big_chk,  pt_render_tiles_tri_chk,  pt_render_tiles_tri_big_chk,
-                                    pt_render_tiles_refr, pt_render_tiles_big_refr, pt_render_tiles_tri_refr, pt_render_tiles_tri_big_refr,
-                                    pt_render_tiles_v0,   pt_whitted_tiles,         pt_whitted_tiles_big,     pt_whitted_tiles_tri,
-                                    pt_whitted_tiles_tri_big, pt_render_tiles_mem,  pt_whitted_tiles_mem,
-                                    pt_render_tiles_tri_queued, pt_render_tiles_tri_queued_chk, pt_render_tiles_tri_queued_sph,
-                                    pt_render_tiles_pool_mem, pt_render_tiles_pool_mem_chk, pt_render_tiles_pool_mem_tri,
-                                    pt_render_tiles_pool_mem_tri_chk, pt_render_tiles_pool_mem_s, pt_render_tiles_pool_mem_s_chk,
-                                    pt_render_tiles_refr_pool, pt_render_tiles_refr_pool_mem, pt_render_tiles_tri_refr_pool,
-                                    pt_render_tiles_tri_queued_refr, pt_render_tiles_tri_queued_refr_sph};
   int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr,
                              launch.park_ws != nullptr && launch.park_slots_per_xcd != 0u);
-  /* the pooled refraction kernel's windowed sums hold 2^31 pieces per word: a sample of a refractive scene has at most
+  /* the pooled refraction kernels' windowed sums hold 2^31 pieces per word: a sample of a refractive scene has at most
    * 2^(max_depth + 2) terms (a full binary tree of children), so keep samples x 2^(max_depth + 2) <= 2^30 -- any other launch
    * (4,097 spp at depth 16, say) takes the static kernel, whose fp64 sums have no such limit */
-  if (which == 28 && !pt_refr_pool_fits(launch.samples, launch.max_depth))
-    which = 8;
-  if (which == 29 && !pt_refr_pool_fits(launch.samples, launch.max_depth))
-    which = pt_geom_in_lds(launch.scene) ? 8 : 17;
-  if (which == 30 && !pt_refr_pool_fits(launch.samples, launch.max_depth))
-    which = 10;
-  if ((which == 31 || which == 32) && (!pt_refr_pool_fits(launch.samples, launch.max_depth) ||
-                                       launch.pend_slot_doubles < (uint64_t)launch.pend_entries * PT_PEND_FIELDS_HOST * 4u * 512u))
-    which = 11; /* (... or when the pool was not sized for 4 x 512 stacks per slot) */
-  const Kernel kernel = family[which];
-  if ((which >= 22 && which <= 27) || which == 29)
+  const bool windows_fit = pt_refr_pool_fits(launch.samples, launch.max_depth);
+  if (which == K_REFR_POOL && !windows_fit)
+    which = K_REFR;
+  if (which == K_REFR_POOL_MEM && !windows_fit)
+    which = pt_geom_in_lds(launch.scene) ? K_REFR : K_MEM;
+  if (which == K_TRI_REFR_POOL && !windows_fit)
+    which = K_TRI_REFR;
+  if (pt_kernels[which].wide_pend &&
+      (!windows_fit || launch.pend_slot_doubles < (uint64_t)launch.pend_entries * PT_PEND_FIELDS_HOST * 4u * 512u))
+    which = K_TRI_BIG_REFR; /* (... or when the pool was not sized for 4 x 512 stacks per slot) */
+  const PtKernelInfo &k = pt_kernels[which];
+  const PtKernelFn kernel = k.fn;
+  if (k.stages_none)
     lds_bytes = extra_lds; /* the in-memory pooled kernels stage nothing, whatever the scene's size */
-  if (((which >= 8 && which <= 11) || which == 17 || which == 18 || (which >= 28 && which <= 32)) &&
-      (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
+  if (k.pend_pool && (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
     return hipErrorInvalidValue; /* a kernel with a pending-ray stack needs its pool (rt_hip_shim.hip: pend_pool_for) */
-  const bool queued = (which >= 19 && which <= 21) || which == 31 || which == 32;
+  const bool queued = k.queued;
   if (queued) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
     lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
                  (((size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u);
