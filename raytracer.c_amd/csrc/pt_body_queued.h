@@ -5,7 +5,7 @@
 #ifndef PT_BODY_QUEUED_H
 #define PT_BODY_QUEUED_H
 
-/* ---- hierarchy scenes: pooled samples + PARKED walks (pt_render_tiles_tri_big[_chk]) ---------
+/* ---- hierarchy scenes: pooled samples + PARKED walks (pt_render_tiles_tri_queued[_chk][_sph][_refr]) ---------
  *
  * Scenes with a triangle hierarchy (more than PT_FILT_LDS_MAX primitives).  The pooled body above
  * makes a ray that can reach the mesh WAIT in its lane until enough lanes wait, then walks the

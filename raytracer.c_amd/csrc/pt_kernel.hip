@@ -117,6 +117,10 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED) void pt_r
 {
   render_tiles_queued<false, true>(L);
 }
+extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_tri_queued_chk_sph(const PtLaunch L)
+{
+  render_tiles_queued<true, true>(L);
+}
 /* hierarchy scenes with M_REFRACTION: parked walks + windowed sums + pending second children that travel with a path, also
  * through the ring (render_tiles_queued, REFR); windowed sums in the workspace (global atomics): LDS as the other forms */
 #ifndef PT_MIN_WAVES_QUEUED_REFR
@@ -639,7 +643,7 @@ enum PtKernelId
   K_TRI_QUEUED, K_TRI_QUEUED_CHK, K_TRI_QUEUED_SPH,
   K_POOL_MEM, K_POOL_MEM_CHK, K_POOL_MEM_TRI, K_POOL_MEM_TRI_CHK, K_POOL_MEM_S, K_POOL_MEM_S_CHK,
   K_REFR_POOL, K_REFR_POOL_MEM, K_TRI_REFR_POOL,
-  K_TRI_QUEUED_REFR, K_TRI_QUEUED_REFR_SPH,
+  K_TRI_QUEUED_REFR, K_TRI_QUEUED_REFR_SPH, K_TRI_QUEUED_CHK_SPH,
   K_COUNT
 };
 static_assert(K_CHK == K_TILES + 4 && K_REFR == K_TILES + 8 && K_TRI == K_TILES + 2 && K_BIG == K_TILES + 1 &&
@@ -675,7 +679,8 @@ static const PtKernelInfo pt_kernels[K_COUNT] = {
     PT_K(pt_render_tiles_pool_mem_s, false, false, true, false), PT_K(pt_render_tiles_pool_mem_s_chk, false, false, true, false),
     PT_K(pt_render_tiles_refr_pool, true, false, false, false), PT_K(pt_render_tiles_refr_pool_mem, true, false, true, false),
     PT_K(pt_render_tiles_tri_refr_pool, true, false, false, false),
-    PT_K(pt_render_tiles_tri_queued_refr, true, true, false, true), PT_K(pt_render_tiles_tri_queued_refr_sph, true, true, false, true)};
+    PT_K(pt_render_tiles_tri_queued_refr, true, true, false, true), PT_K(pt_render_tiles_tri_queued_refr_sph, true, true, false, true),
+    PT_K(pt_render_tiles_tri_queued_chk_sph, false, true, false, false)};
 #undef PT_K
 
 /* which member of the kernel family a launch of this scene takes (the selection of
@@ -706,7 +711,8 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
   else if (!cast_ray && variant != 5 && pt_prefer_streaming(scene))
     which = K_POOL_MEM_S + (chk ? 1 : 0); /* a sphere scene that would fit the staging budget but is faster streamed (pt_device.h; variant 5: staged, for A/B) */
   else if ((which == K_TRI_BIG || which == K_TRI_BIG_CHK) && can_park)
-    which = which == K_TRI_BIG ? (scene.mesh_round ? K_TRI_QUEUED_SPH : K_TRI_QUEUED) : K_TRI_QUEUED_CHK; /* hierarchy scenes: parked walks (otherwise the lane-waiting pooled kernels) */
+    which = which == K_TRI_BIG ? (scene.mesh_round ? K_TRI_QUEUED_SPH : K_TRI_QUEUED)
+                               : (scene.mesh_round ? K_TRI_QUEUED_CHK_SPH : K_TRI_QUEUED_CHK); /* hierarchy scenes: parked walks (otherwise the lane-waiting pooled kernels) */
   /* refractive sphere scenes that are streamed (beyond the staging budget, or beyond ~85 spheres by preference: pt_stream_sized) */
   if (!cast_ray && refr && !tris && !scene.wide_range && variant != 7 && variant != 3 && (!pt_geom_in_lds(scene) || (variant != 5 && pt_stream_sized(scene))))
     which = K_REFR_POOL_MEM;
@@ -720,7 +726,7 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
   if (which == K_TRI_BIG_REFR && variant != 7 && can_park && have_park_ws)
     which = scene.mesh_round ? K_TRI_QUEUED_REFR_SPH : K_TRI_QUEUED_REFR;
   if (!have_park_ws && pt_kernels[which].queued) /* no ring workspace: the lane-waiting kernels need none */
-    which = which == K_TRI_QUEUED_CHK ? K_TRI_BIG_CHK : K_TRI_BIG;
+    which = (which == K_TRI_QUEUED_CHK || which == K_TRI_QUEUED_CHK_SPH) ? K_TRI_BIG_CHK : K_TRI_BIG;
   if (name)
     *name = pt_kernels[which].name;
   return which;

@@ -1325,6 +1325,26 @@ def test_hierarchy_kernel_without_its_workspace(gpu, pt):
     sc.free()
 
 
+@pytest.mark.parametrize("what", ["wall", "mesh"])
+def test_checkered_materials_with_a_round_mesh_take_the_sphere_probe_kernel(gpu, pt, what):
+    """config 5's scene with M_CHECKERED on a wall sphere, or on the mesh itself (then hit.u / hit.v follow every passing
+    triangle: no pruning by the closest hit, no hull-facet rule): the parked-walk kernel whose probe is the bounding sphere
+    alone (the mesh is round), with the checker code -- pt_render_tiles_tri_queued_chk_sph; frame and counters = oracle"""
+    from rt_amd import abi, scene as S
+    sc = S.build_scene(5, 80, 48, 4)
+    if what == "wall":
+        sc.objects[0].flags |= abi.M_CHECKERED
+    else:
+        sc.meshes[0].flags |= abi.M_CHECKERED
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name() == "pt_render_tiles_tri_queued_chk_sph", gs.kernel_name()
+    img, img8, st = gs.render_image(SEED)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"config 5, checkered {what}")
+    gs.close()
+    sc.free()
+
+
 @pytest.mark.parametrize("case", ["config5", "convex", "nested", "deep"])
 def test_glass_mesh_through_the_hierarchy_on_the_parked_walk_body(gpu, pt, case):
     """hierarchy scenes with M_REFRACTION (pt_render_tiles_tri_queued_refr[_sph], end of round 4): windowed pixel sums, pending
