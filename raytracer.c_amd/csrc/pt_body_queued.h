@@ -407,7 +407,10 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
  * lanes, 64 on its list and up to 382 in its ring, so ids are 9 bits (PoolStackT<512, 511>: 511 ids for at most 510 paths) and a
  * workgroup's slot of the pending-ray pool holds 4 x 512 stacks (PtLaunch.pend_slot_doubles: pend_pool_for sizes it). */
 typedef PoolStackT<512u, 511u> RingStack;
-template <bool CHECKER, bool SPHERE_PROBE = false, bool REFR = false>
+/* GEOM_LDS = false (pt_render_tiles_tri_queued_mem*): scenes whose spheres exceed the LDS staging budget AND that have a mesh of
+ * more than 256 triangles -- sphere geometry and materials gathered from memory, the spheres' sign-form filter pairs read from
+ * memory by scalar loads (as pt_render_tiles_pool_mem_s does for sphere-only scenes); everything else as the staged form. */
+template <bool CHECKER, bool SPHERE_PROBE = false, bool REFR = false, bool GEOM_LDS = true>
 __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 {
   static_assert(!REFR || CHECKER, "the refraction form carries every material's code");
@@ -453,7 +456,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     pt_phase_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
   }
 #endif
-  SceneCtx S_init = stage_scene<true, FILT_LDS, true>(L, lds);
+  SceneCtx S_init = stage_scene<GEOM_LDS, FILT_LDS, true>(L, lds);
   __shared__ double atan_tab[CHECKER ? PT_ATAN_TAB : 1];
   if (CHECKER)
   {
@@ -474,8 +477,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   WalkStack stack;
   {
     const uint32_t levels = max(L.scene.bvh_depth, 1u);
-    stack.lo = reinterpret_cast<uint16_t *>(lds + (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
-                                                   pt_filt_pair_slots(S.n_sph)));
+    stack.lo = reinterpret_cast<uint16_t *>(lds + (GEOM_LDS ? (PT_GEOM_STRIDE * (size_t)S.n_sph + PT_MAT_STRIDE * (size_t)(L.scene.n_spheres + L.scene.n_meshes) +
+                                                               pt_filt_pair_slots(S.n_sph))
+                                                            : (size_t)0));
     stack.hi = reinterpret_cast<uint8_t *>(stack.lo + (size_t)levels * PT_BLOCK);
 #ifdef PT_BVH_WIDE
     stack.cap = levels; /* the LDS array keeps the binary walk's size; deeper entries overflow (WalkStack) */
@@ -871,7 +875,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       /* ... and a fresh camera ray of a tile whose cone cannot reach the triangles' bounding ball (tile_sees_mesh, once
        * per wave: a primary trip's 64 rays are all such rays) cannot either: most of the image's primary trips skip the probe */
       const bool no_mesh = (hit.leaving && !(CHECKER && S.stale_uv)) || (primary_trip && !tile_sees_mesh);
-      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit); /* (the first half never touches the stack) */
+      (void)trace_step<1, false, CHECKER, TRIS, FILT_LDS, 1, true, true, !GEOM_LDS>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit); /* (the first half never touches the stack) */
       const bool far_origin = !(v_dot(P.o, P.o) <= S.near_R2);
 #ifdef PT_DIAG
       /* RT_HIP_DIAG_WALK_REJECTED=1: rays the bounding sphere rejects are parked and walked all the same, and any
@@ -951,10 +955,10 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
       if constexpr (REFR)
       {
         const RingStack mine = {pend_wave_now(), pend_free[wave_now()], &pend_id, (int)L.pend_entries};
-        step_done = trace_step<1, true, CHECKER, TRIS, FILT_LDS, 2, true, true, false, RingStack>(S, P, n_casts, diag_ptr, mine, stack_n, &hit);
+        step_done = trace_step<1, true, CHECKER, TRIS, FILT_LDS, 2, true, true, !GEOM_LDS, RingStack>(S, P, n_casts, diag_ptr, mine, stack_n, &hit);
       }
       else
-        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
+        step_done = trace_step<1, false, CHECKER, TRIS, FILT_LDS, 2, true, true, !GEOM_LDS>(S, P, n_casts, diag_ptr, no_stack, stack_n, &hit);
     }
     PHASE(3);
 

@@ -608,7 +608,7 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
     uint32_t cand_lo, cand_hi;
     uint32_t pruned = 0u; /* wall-sized spheres of this chunk that cannot be the closest hit (BigPrune): PT_DIAG re-checks them */
     if (SPH_LDS)
-      filter_chunk<false, true>(filt, base, chunk, fr, cand_lo, cand_hi, big, &pruned);
+      filter_chunk<false, true, FILT_MEM>(filt, base, chunk, fr, cand_lo, cand_hi, big, &pruned);
     else if (FILT_LDS && prim_pairs != nullptr)
       filter_chunk_listed<SHIFT, FILT_MEM>(filt, base, chunk, prim_pairs[base >> 6], fr, cand_lo, cand_hi);
     else

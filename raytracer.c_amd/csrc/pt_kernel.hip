@@ -134,6 +134,18 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED_REFR) void
 {
   render_tiles_queued<true, true, true>(L);
 }
+/* ... and the two forms for scenes whose SPHERES exceed the LDS staging budget next to such a mesh (render_tiles_queued,
+ * GEOM_LDS = false: sphere geometry, materials and the spheres' filter pairs from memory); the probe is the general one */
+extern "C" __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_QUEUED) void pt_render_tiles_tri_queued_mem(const PtLaunch L)
+{
+  render_tiles_queued<false, false, false, false>(L);
+}
+extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_render_tiles_tri_queued_mem_chk(const PtLaunch L)
+{
+  render_tiles_queued<true, false, false, false>(L);
+}
+/* (no refraction form here: at three waves it spills two doubles inside the trip loop, and scenes with M_REFRACTION, more
+ * spheres than the staging holds AND a large mesh are the rarest class there is -- they keep pt_render_tiles_mem) */
 /* small sphere scenes with M_REFRACTION on the pooled body (render_tiles_pooled, REFR) */
 #ifndef PT_MIN_WAVES_REFR_POOL
 #define PT_MIN_WAVES_REFR_POOL 4
@@ -644,6 +656,7 @@ enum PtKernelId
   K_POOL_MEM, K_POOL_MEM_CHK, K_POOL_MEM_TRI, K_POOL_MEM_TRI_CHK, K_POOL_MEM_S, K_POOL_MEM_S_CHK,
   K_REFR_POOL, K_REFR_POOL_MEM, K_TRI_REFR_POOL,
   K_TRI_QUEUED_REFR, K_TRI_QUEUED_REFR_SPH, K_TRI_QUEUED_CHK_SPH,
+  K_TRI_QUEUED_MEM, K_TRI_QUEUED_MEM_CHK,
   K_COUNT
 };
 static_assert(K_CHK == K_TILES + 4 && K_REFR == K_TILES + 8 && K_TRI == K_TILES + 2 && K_BIG == K_TILES + 1 &&
@@ -680,7 +693,8 @@ static const PtKernelInfo pt_kernels[K_COUNT] = {
     PT_K(pt_render_tiles_refr_pool, true, false, false, false), PT_K(pt_render_tiles_refr_pool_mem, true, false, true, false),
     PT_K(pt_render_tiles_tri_refr_pool, true, false, false, false),
     PT_K(pt_render_tiles_tri_queued_refr, true, true, false, true), PT_K(pt_render_tiles_tri_queued_refr_sph, true, true, false, true),
-    PT_K(pt_render_tiles_tri_queued_chk_sph, false, true, false, false)};
+    PT_K(pt_render_tiles_tri_queued_chk_sph, false, true, false, false),
+    PT_K(pt_render_tiles_tri_queued_mem, false, true, true, false), PT_K(pt_render_tiles_tri_queued_mem_chk, false, true, true, false)};
 #undef PT_K
 
 /* which member of the kernel family a launch of this scene takes (the selection of
@@ -705,6 +719,11 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
     if (!cast_ray && !refr && variant != 3)
       which = (!tris && !scene.wide_range && variant != 4) ? K_POOL_MEM_S + (chk ? 1 : 0)
                                                            : K_POOL_MEM + (tris ? 2 : 0) + (chk ? 1 : 0); /* (variant 4: the compare-form kernel, for A/B) */
+    /* ... and with a mesh of more than 256 triangles: the parked-walk body with the spheres from memory (variants 3, 4: the
+     * kernels above, for A/B; a small mesh next to many spheres has no leaf-order pre-test table: it keeps them too) */
+    const bool big_mesh = scene.n_triangles > PT_FILT_LDS_MAX && scene.n_bvh_nodes != 0u;
+    if (!cast_ray && !refr && big_mesh && can_park && have_park_ws && variant != 3 && variant != 4)
+      which = chk ? K_TRI_QUEUED_MEM_CHK : K_TRI_QUEUED_MEM;
   }
   else if (variant == 0 && !refr && !cast_ray)
     which = K_V0;
@@ -725,7 +744,7 @@ static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int var
   /* hierarchy scenes with M_REFRACTION: the parked-walk body's refraction form, under the conditions of its other forms */
   if (which == K_TRI_BIG_REFR && variant != 7 && can_park && have_park_ws)
     which = scene.mesh_round ? K_TRI_QUEUED_REFR_SPH : K_TRI_QUEUED_REFR;
-  if (!have_park_ws && pt_kernels[which].queued) /* no ring workspace: the lane-waiting kernels need none */
+  if (!have_park_ws && pt_kernels[which].queued) /* no ring workspace: the lane-waiting kernels need none (the _mem forms are only picked with one) */
     which = (which == K_TRI_QUEUED_CHK || which == K_TRI_QUEUED_CHK_SPH) ? K_TRI_BIG_CHK : K_TRI_BIG;
   if (name)
     *name = pt_kernels[which].name;
@@ -818,8 +837,8 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   if (k.pend_pool && (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
     return hipErrorInvalidValue; /* a kernel with a pending-ray stack needs its pool (rt_hip_shim.hip: pend_pool_for) */
   const bool queued = k.queued;
-  if (queued) /* the spheres' filter pairs, then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
-    lds_bytes += (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u +
+  if (queued) /* the spheres' filter pairs (staged forms), then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
+    lds_bytes += (k.stages_none ? (size_t)0 : (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u) +
                  (((size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u);
   if (lds_bytes > 64 * 1024)
   { /* the attribute belongs to the (kernel, current device) pair: set whenever it is needed -- a process-wide

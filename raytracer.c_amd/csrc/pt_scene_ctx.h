@@ -45,7 +45,7 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
    * the filter -- sign tests, descending pairs, per-tile culling, wall pruning -- with the pair table read from memory
    * (wave-uniform addresses: scalar loads) instead of from an LDS copy */
   constexpr bool FILT_FROM_MEMORY = FILT_LDS && !GEOM_LDS;
-  static_assert(!SPH_FILT || (GEOM_LDS && !FILT_LDS), "SPH_FILT: the sphere pairs only, for the hierarchy kernels");
+  static_assert(!SPH_FILT || !FILT_LDS, "SPH_FILT: the sphere pairs only, for the hierarchy kernels");
   const PtSceneView &sc = L.scene;
   const uint32_t n_sph = sc.n_spheres, n_mat = sc.n_spheres + sc.n_meshes;
   constexpr bool staged = GEOM_LDS;
@@ -70,7 +70,9 @@ __device__ __forceinline__ SceneCtx stage_scene(const PtLaunch &L, double *lds)
    * it through the constant cache. */
   const uint32_t n_entries = n_sph + sc.n_triangles;
   f32x2 *filt_lds = nullptr;
-  if (SPH_FILT)
+  if (SPH_FILT && !GEOM_LDS) /* (pt_render_tiles_tri_queued_mem*: the sphere pairs from memory too, by scalar loads) */
+    filt_lds = reinterpret_cast<f32x2 *>(sc.filt);
+  if (SPH_FILT && GEOM_LDS)
   { /* the pairs that cover the spheres (the last may carry the first triangle's bound: masked in the scan) */
     filt_lds = reinterpret_cast<f32x2 *>(mat + PT_MAT_STRIDE * (size_t)n_mat);
     const uint32_t n_slots = pt_filt_pair_slots(n_sph);

@@ -54,7 +54,9 @@ def scene_sets(which):
         return sets
     if which == "rooms":     # rooms of more than 256 spheres (pt_render_tiles_pool_mem: geometry from memory, scalar-table filter)
         from util import packed_room
-        return [("room %d" % n, packed_room(n, k, 160, 96, 4, 8)) for k, n in enumerate([249, 500, 1500])]
+        from util import room_with_mesh   # ... and one with a mesh of 600 triangles: the parked-walk body with the spheres from memory
+        return [("room %d" % n, packed_room(n, k, 160, 96, 4, 8)) for k, n in enumerate([249, 500, 1500])] + \
+               [("room 300 + mesh", room_with_mesh(300, 3, 160, 96, 4, 8))]
     if which == "wide":      # the wider sweep of tools/diag_fuzz.py
         kinds = ["all", "no_glass", "plain"]
         sets = [("fuzz %d" % k, _random_scene(k, False, 0, materials=kinds[k % 3])) for k in range(40)]

@@ -104,7 +104,13 @@ def test_diag_rooms_beyond_the_staging_budget_zero_violations():
     recs = _run("rooms")
     _no_violations(recs)
     path = [r for r in recs if r["integrator"] == "path" and "skipped" not in r]
+    mesh = [r for r in path if r["scene"].endswith("mesh")]
+    path = [r for r in path if not r["scene"].endswith("mesh")]
     assert len(path) == 3 and {r["kernel"] for r in path} == {"pt_render_tiles_pool_mem_s"}
     assert all(r["walls_pruned"] > 0 for r in path)   # the six walls lead these rooms too: pruned among themselves here as well
     for r in path:
         assert 0 < r["candidates"] < r["casts"] * r["n_primitives"] // 4, r
+    # the room with a mesh: parked walks with the spheres' sign-form filter pairs read from memory -- the filter dropped spheres,
+    # rays were parked and walked (also those the probe rejects), leaves were pre-tested: 0 violations above
+    assert len(mesh) == 1 and mesh[0]["kernel"] == "pt_render_tiles_tri_queued_mem", mesh
+    assert 0 < mesh[0]["candidates"] < mesh[0]["casts"] * 308 and mesh[0]["parked"] > mesh[0]["parked_probe_would_park"] > 0 and mesh[0]["leaf_pretests"] > 0

@@ -949,6 +949,27 @@ def test_rooms_of_more_than_256_spheres_take_the_pooled_body(gpu, pt):
     _full(gpu, pt, sc, hdr=True)
 
 
+@pytest.mark.parametrize("checker", [False, True])
+def test_rooms_beyond_the_staging_budget_with_a_large_mesh_take_parked_walks(gpu, pt, checker):
+    """300 packed spheres (beyond the LDS staging) next to a mesh of 600 triangles: the parked-walk body with sphere geometry,
+    materials and the spheres' filter pairs from memory (pt_render_tiles_tri_queued_mem[_chk], end of round 4; until then the
+    lane-waiting pt_render_tiles_pool_mem_tri) -- frame and counters = oracle, partitions bit-equal"""
+    import torch
+    from util import room_with_mesh
+    sc = room_with_mesh(300, 9, 56, 32, 4, 6, checker=checker)
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name() == ("pt_render_tiles_tri_queued_mem_chk" if checker else "pt_render_tiles_tri_queued_mem"), gs.kernel_name()
+    img, img8, st = gs.render_image(SEED)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="room of 308 spheres + 600 triangles")
+    total = gpu.n_tiles(sc.width, sc.height)
+    t_all, t8_all, _ = gs.render_tiles(SEED, 0, 1, total)
+    t_odd, t8_odd, _ = gs.render_tiles(SEED, 1, 2, total // 2)
+    torch.cuda.synchronize()
+    assert torch.equal(t_all[1::2][: total // 2], t_odd[: total // 2]) and torch.equal(t8_all[1::2][: total // 2], t8_odd[: total // 2])
+    gs.close()
+
+
 def test_many_samples_per_pixel(gpu, pt):
     """16x16 pixels x 20,000 spp: long job pools (1,250 refills of a wave's sample queue), 5 million
     fixed-point additions per tile, and the same again split over 7 sample chunks"""

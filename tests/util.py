@@ -310,6 +310,25 @@ def packed_room(n_packed, seed=1, width=1920, height=1080, samples=64, max_depth
     return S.custom_scene(objs, width, height, samples, max_depth, (0, 0, 50), (0, 0, 0))
 
 
+def room_with_mesh(n_packed, seed, width, height, samples, max_depth, n_tris=600, checker=False):
+    """packed_room(n_packed) -- more spheres than the LDS staging holds from ~250 on -- with a bumpy sheet of n_tris random
+    triangles across it: the scene class of pt_render_tiles_tri_queued_mem[_chk] (checker: one packed sphere M_CHECKERED)"""
+    from rt_amd import abi, scene as S
+    room = packed_room(n_packed, seed, width, height, samples, max_depth)
+    objs = [dict(flags=int(room.objects[i].flags) | (abi.M_CHECKERED if checker and i == 9 else 0), radius=float(room.objects[i].radius),
+                 center=room.objects[i].center.tuple(), color=room.objects[i].color.tuple(), emission=room.objects[i].emission.tuple())
+            for i in range(room.n_objects)]
+    room.free()
+    rng = np.random.default_rng(77 + seed)
+    tris = []
+    for _ in range(n_tris):
+        c = np.array([rng.uniform(-25, 25), rng.uniform(-15, 15), rng.uniform(-20, 20)])
+        a, b = rng.normal(size=3) * 1.5, rng.normal(size=3) * 1.5
+        tris.append([tuple(c), tuple(c + a), tuple(c + b)])
+    return S.custom_scene(objs, width, height, samples, max_depth, (0, 0, 50), (0, 0, 0),
+                          meshes=[dict(flags=abi.M_DEFAULT, color=(0.8, 0.7, 0.6), triangles=tris)])
+
+
 def fdlibm_atan2(y, x):
     """numpy statement of the kernels' atan2_tab (pt_math.h): fdlibm's e_atan2.c / s_atan.c with one division for all
     five reduction intervals, every operation unfused and in the same order -- so the device must agree BIT FOR BIT"""

@@ -22,6 +22,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     scenes.append(("room of 120 spheres", packed_room(120, 1, 64, 40, 2, 5)))
     scenes.append(("room of 300 spheres", packed_room(300, 1, 64, 40, 2, 5)))
     scenes.append(("room of 300, glass", packed_room(300, 1, 64, 40, 2, 5, glass=True)))
+    from util import room_with_mesh
+    scenes.append(("room of 300 + 600 triangles", room_with_mesh(300, 1, 64, 40, 2, 5)))
     out = {}
     for name, sc in scenes:
         gs = G.GpuScene(sc)
