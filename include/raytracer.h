@@ -227,7 +227,7 @@ void render_ex(uint8_t *framebuffer, float *linear_rgb, Object *objects, size_t 
  * state.  Defaults: depth MAX_DEPTH (5), seed 1666943821 (main.c:182), 1 GPU. */
 void rt_set_max_depth(int max_depth);
 void rt_set_seed(uint64_t seed);
-void rt_set_devices(int n_devices);
+void rt_set_devices(int n_devices); /* a host that never calls it: RT_DEVICES=N of the environment, else 1 */
 int rt_get_max_depth(void);
 uint64_t rt_get_seed(void);
 

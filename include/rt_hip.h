@@ -218,12 +218,17 @@ int rt_hip_selftest_xcc(uint32_t n_workgroups, uint32_t h_counts[16], int device
 void rt_hip_set_cancel_flag(const volatile int *flag);
 
 /* Renders width x height on n_devices GPUs of this process (tiles interleaved
- * over devices, tile buffers gathered onto device 0 with RCCL when
- * n_devices > 1), then copies to the host.  Calls are serialised (one frame at a time).
- * n_devices > 1 is EXPERIMENTAL: written (grouped ncclSend / ncclRecv to device 0 over cached
- * communicators) but, as of this writing, run on one-GPU machines only; `bench.py --gpus N`
- * exercises it in a child process whenever N > 1 GPUs are present and compares its frame with the
- * one-device frame.  h_image_rgb (w*h*3 floats) and
+ * over devices: logical device g renders tiles g, g + n_devices, ...; the compact tile buffers
+ * are gathered onto logical device 0, scattered to the row-major image there and copied to the
+ * host).  Calls are serialised (one frame at a time).  A segment travels by grouped ncclSend /
+ * ncclRecv over cached communicators when its device differs from the root's, and as a
+ * device-to-device copy when it does not (see rt_hip_set_device_map).
+ * n_devices > 1 is EXPERIMENTAL in one respect only: its indexing, slabs, cancellation, caching
+ * and counters run in the GPU tests at 2, 3 and 8 LOGICAL devices mapped onto one GPU, and its
+ * RCCL calls run there with one rank (RT_HIP_FORCE_COMM=1) -- but as of this writing no machine
+ * with two physical GPUs has run it; `bench.py --gpus N` exercises it in a child process whenever
+ * N > 1 GPUs are present and compares its frame with the one-device frame.
+ * h_image_rgb (w*h*3 floats) and
  * h_image_rgb8 (w*h*3 bytes) may each be NULL.  h_stats: RT_HIP_NSTATS values,
  * overwritten.  kernel_seconds: device time of the render kernels (max over
  * devices), may be NULL.  params->tile_* are ignored. */
@@ -240,6 +245,17 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
  * rt_hip_cache_builds() counts how often a context had to be (re)built (for tests). */
 void rt_hip_release_cache(void);
 uint64_t rt_hip_cache_builds(void);
+
+/* Logical -> physical device map of rt_hip_render_image(): with a map of n entries, n_devices may be up to n and logical
+ * device g runs on HIP device map[g]; entries may repeat.  Logical devices that share a physical one keep separate scenes,
+ * streams and tile buffers (their kernels run concurrently on it); the partition, the slabs, the gather's slot arithmetic,
+ * the per-segment scatter and the counter sums are the code that runs with n distinct GPUs, so a one-GPU machine executes
+ * the whole n_devices > 1 path (map = {0, 0, 0}) and the image is bit-identical to n_devices = 1.  n = 0 removes the map
+ * (logical = physical).  The environment variable RT_HIP_DEVICE_MAP="0,0,0", read at the first frame, sets the same map for
+ * hosts that cannot call this (the reference's main.c behind libraytracer_amd.so).  Changing the map rebuilds the cached
+ * context at the next frame.  Replaces nothing in the reference (its one parallel construct is the `omp parallel for` of
+ * raytracer.c:184-185). */
+int rt_hip_set_device_map(const int *map, int n);
 
 #ifdef __cplusplus
 }

@@ -608,6 +608,7 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
                       uint8_t *h_image_rgb8, uint64_t *h_stats, double *kernel_seconds);
 void release_cache_impl();
 uint64_t cache_builds_impl();
+int set_device_map_impl(const int *map, int n);
 } // namespace
 
 extern "C" {
@@ -631,6 +632,18 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
 }
 
 void rt_hip_release_cache(void) { release_cache_impl(); }
+
+int rt_hip_set_device_map(const int *map, int n)
+{
+  try
+  {
+    return set_device_map_impl(map, n);
+  }
+  catch (...)
+  {
+    return fail(RT_HIP_ENOMEM, "host allocation failed in rt_hip_set_device_map");
+  }
+}
 
 uint64_t rt_hip_cache_builds(void) { return cache_builds_impl(); }
 
@@ -1478,10 +1491,17 @@ struct ImageCtx
     uint32_t count = 0;
   };
   int G = 0, W = 0, H = 0;
+  /* logical device g runs on physical device phys[g] (rt_hip_set_device_map; the identity without a map).  Logical devices
+   * that share a physical one each keep their own scene, stream and tile buffers -- everything above the gather is the same
+   * code as with G distinct GPUs.  comm_of[g]: index of phys[g] among the DISTINCT physical devices = its RCCL rank (RCCL
+   * refuses two ranks on one device); lead[g]: the first logical device on phys[g], whose stream carries that rank's sends. */
+  std::vector<int> phys, comm_of, lead;
+  int n_phys = 0;
   bool force_comm = false; /* RT_HIP_FORCE_COMM=1: communicators and the gather's send/recv block even with one device */
   std::vector<unsigned char> scene_bytes; /* the scene this context was built for (scene_walk's runs): compared run by run */
   std::vector<Dev> dev;
-  std::vector<ncclComm_t> comms;
+  std::vector<ncclComm_t> comms; /* one per distinct physical device (comm_of) */
+  std::vector<hipEvent_t> done;  /* per logical device: its tiles are complete (what a same-device copy or the lead's sends wait for) */
   float *all_tiles = nullptr, *image = nullptr;
   uint8_t *all_tiles8 = nullptr, *image8 = nullptr;
   uint64_t builds = 0; /* how many times a context was (re)built: exposed for tests */
@@ -1489,18 +1509,64 @@ struct ImageCtx
 ImageCtx g_ctx;
 std::mutex g_ctx_mutex;
 
+/* The logical -> physical device map of rt_hip_render_image (rt_hip_set_device_map, or RT_HIP_DEVICE_MAP=0,0,1 read at
+ * the first frame).  Empty = the identity.  Guarded by g_ctx_mutex. */
+std::vector<int> g_device_map;
+bool g_device_map_env_read = false;
+
+void device_map_from_env()
+{
+  if (g_device_map_env_read)
+    return;
+  g_device_map_env_read = true;
+  const char *e = getenv("RT_HIP_DEVICE_MAP");
+  if (!e || !*e || !g_device_map.empty())
+    return;
+  std::vector<int> m;
+  for (const char *p = e; *p;)
+  {
+    char *end = nullptr;
+    const long v = strtol(p, &end, 10);
+    if (end == p || v < 0 || v > 63)
+      return; /* malformed: ignored as a whole */
+    m.push_back((int)v);
+    p = end;
+    if (*p == ',')
+      p++;
+    else if (*p)
+      return;
+  }
+  g_device_map = m;
+}
+
 void ctx_release(ImageCtx &c)
 {
   int prev = 0;
   (void)hipGetDevice(&prev);
   for (int g = 0; g < (int)c.dev.size(); g++)
   {
-    (void)hipSetDevice(g);
+    (void)hipSetDevice(g < (int)c.phys.size() ? c.phys[g] : g);
     ImageCtx::Dev &d = c.dev[g];
     if (d.stream) (void)hipStreamSynchronize(d.stream);
-    if (g < (int)c.comms.size() && c.comms[g]) (void)ncclCommDestroy(c.comms[g]);
+  }
+  for (int r = 0; r < (int)c.comms.size(); r++)
+    if (c.comms[r])
+    {
+      for (int g = 0; g < (int)c.comm_of.size(); g++)
+        if (c.comm_of[g] == r)
+        {
+          (void)hipSetDevice(c.phys[g]);
+          break;
+        }
+      (void)ncclCommDestroy(c.comms[r]);
+    }
+  for (int g = 0; g < (int)c.dev.size(); g++)
+  {
+    (void)hipSetDevice(g < (int)c.phys.size() ? c.phys[g] : g);
+    ImageCtx::Dev &d = c.dev[g];
     if (d.t0) (void)hipEventDestroy(d.t0);
     if (d.t1) (void)hipEventDestroy(d.t1);
+    if (g < (int)c.done.size() && c.done[g]) (void)hipEventDestroy(c.done[g]);
     if (d.stream) (void)hipStreamDestroy(d.stream);
     (void)hipFree(d.tiles);
     (void)hipFree(d.tiles8);
@@ -1510,7 +1576,7 @@ void ctx_release(ImageCtx &c)
   }
   if (!c.dev.empty())
   {
-    (void)hipSetDevice(0);
+    (void)hipSetDevice(c.phys.empty() ? 0 : c.phys[0]);
     (void)hipFree(c.all_tiles);
     (void)hipFree(c.all_tiles8);
     (void)hipFree(c.image);
@@ -1587,56 +1653,79 @@ void scene_serialise(std::vector<unsigned char> &bytes, const RtHipSphere *spher
     }                                                                                               \
   } while (0)
 
-/* makes g_ctx fit this call (device count, image size, scene); caller holds g_ctx_mutex */
-int ctx_prepare(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes, int G, int W, int H,
-                int prev)
+/* makes g_ctx fit this call (device count and map, image size, scene); caller holds g_ctx_mutex */
+int ctx_prepare(const RtHipSphere *spheres, size_t n_spheres, const RtHipMesh *meshes, size_t n_meshes, int G,
+                const std::vector<int> &phys, int W, int H, int prev)
 {
-  /* RT_HIP_FORCE_COMM=1: build the RCCL communicator(s) and run the gather's grouped send / recv block even with ONE
-   * device (the device sends its tile buffers to itself): how a one-GPU box exercises library load, bootstrap,
-   * communicator creation / destruction and the send / recv kernels of the N > 1 path */
+  /* RT_HIP_FORCE_COMM=1: build the RCCL communicator(s) and run the gather's grouped send / recv block even where no
+   * tile has to change devices (one device, or logical devices that all share one): every segment then travels through
+   * RCCL as a send to self -- how a one-GPU box exercises library load, bootstrap, communicator creation / destruction
+   * and the send / recv kernels of the N > 1 path */
   const char *fc = getenv("RT_HIP_FORCE_COMM");
   const bool force_comm = fc && fc[0] == '1';
   ImageCtx &c = g_ctx;
-  if (c.G == G && c.W == W && c.H == H && c.force_comm == force_comm && (int)c.dev.size() == G &&
+  if (c.G == G && c.W == W && c.H == H && c.force_comm == force_comm && (int)c.dev.size() == G && c.phys == phys &&
       scene_matches(c.scene_bytes, spheres, n_spheres, meshes, n_meshes))
     return RT_HIP_OK;
   ctx_release(c);
   c.builds++;
   c.dev.resize(G);
-  c.comms.assign(G, nullptr);
+  c.phys = phys;
+  c.comm_of.assign(G, 0);
+  c.lead.assign(G, 0);
+  c.done.assign(G, nullptr);
+  c.n_phys = 0;
+  for (int g = 0; g < G; g++)
+  {
+    int first = g;
+    for (int j = 0; j < g; j++)
+      if (phys[j] == phys[g])
+      {
+        first = j;
+        break;
+      }
+    c.lead[g] = first;
+    c.comm_of[g] = first == g ? c.n_phys++ : c.comm_of[first];
+  }
+  c.comms.assign(c.n_phys, nullptr);
   const uint32_t n_tiles = tiles_x_of(W) * tiles_y_of(H);
   const size_t n_px = (size_t)W * H;
   for (int g = 0; g < G; g++)
   {
     ImageCtx::Dev &d = c.dev[g];
     d.count = (n_tiles > (uint32_t)g) ? (n_tiles - g + G - 1) / G : 0;
-    int rc = rt_hip_scene_create(spheres, n_spheres, meshes, n_meshes, g, &d.scene);
+    int rc = rt_hip_scene_create(spheres, n_spheres, meshes, n_meshes, phys[g], &d.scene);
     if (rc)
     {
       ctx_release(c);
       (void)hipSetDevice(prev);
       return rc;
     }
-    CTX_TRY(hipSetDevice(g));
+    CTX_TRY(hipSetDevice(phys[g]));
     CTX_TRY(hipStreamCreate(&d.stream));
     CTX_TRY(hipEventCreate(&d.t0));
     CTX_TRY(hipEventCreate(&d.t1));
+    CTX_TRY(hipEventCreateWithFlags(&c.done[g], hipEventDisableTiming));
     const size_t slots = d.count ? d.count : 1;
     CTX_TRY(hipMalloc(&d.tiles, slots * 192 * sizeof(float)));
     CTX_TRY(hipMalloc(&d.tiles8, slots * 192));
     CTX_TRY(hipMalloc(&d.stats, RT_HIP_NSTATS * sizeof(uint64_t)));
   }
-  CTX_TRY(hipSetDevice(0));
+  CTX_TRY(hipSetDevice(phys[0]));
   CTX_TRY(hipMalloc(&c.image, n_px * 3 * sizeof(float)));
   CTX_TRY(hipMalloc(&c.image8, n_px * 3));
   if (G > 1 || force_comm)
   {
     CTX_TRY(hipMalloc(&c.all_tiles, (size_t)n_tiles * 192 * sizeof(float)));
     CTX_TRY(hipMalloc(&c.all_tiles8, (size_t)n_tiles * 192));
-    std::vector<int> ids(G);
+  }
+  if (c.n_phys > 1 || force_comm)
+  {
+    std::vector<int> ids(c.n_phys);
     for (int g = 0; g < G; g++)
-      ids[g] = g;
-    ncclResult_t nr = ncclCommInitAll(c.comms.data(), G, ids.data());
+      if (c.lead[g] == g)
+        ids[c.comm_of[g]] = phys[g];
+    ncclResult_t nr = ncclCommInitAll(c.comms.data(), c.n_phys, ids.data());
     if (nr != ncclSuccess)
     {
       int code = fail(RT_HIP_ERUNTIME, "ncclCommInitAll: %s", ncclGetErrorString(nr));
@@ -1665,16 +1754,25 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   const int have = usable_devices();
   if (have < 1)
     return fail(RT_HIP_ENODEV, "no HIP device is available (this library has no CPU path)");
-  if (n_devices < 1 || n_devices > have)
-    return fail(RT_HIP_ENODEV, "asked for %d devices, %d available", n_devices, have);
-  const int G = n_devices;
   const int W = params->width, H = params->height;
   const size_t n_px = (size_t)W * H;
 
   std::lock_guard<std::mutex> lock(g_ctx_mutex); /* one frame at a time: the context is shared */
+  device_map_from_env();
+  const int limit = g_device_map.empty() ? have : (int)g_device_map.size();
+  if (n_devices < 1 || n_devices > limit)
+    return fail(RT_HIP_ENODEV, "asked for %d devices, %d available%s", n_devices, limit, g_device_map.empty() ? "" : " in the device map");
+  const int G = n_devices;
+  std::vector<int> phys(G);
+  for (int g = 0; g < G; g++)
+  {
+    phys[g] = g_device_map.empty() ? g : g_device_map[g];
+    if (phys[g] < 0 || phys[g] >= have)
+      return fail(RT_HIP_ENODEV, "device map entry %d -> %d: %d devices available", g, phys[g], have);
+  }
   int prev = 0;
   (void)hipGetDevice(&prev);
-  rc = ctx_prepare(spheres, n_spheres, meshes, n_meshes, G, W, H, prev);
+  rc = ctx_prepare(spheres, n_spheres, meshes, n_meshes, G, phys, W, H, prev);
   if (rc)
     return rc;
   ImageCtx &c = g_ctx;
@@ -1698,7 +1796,7 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   for (int g = 0; g < G; g++)
   {
     ImageCtx::Dev &d = dev[g];
-    IMG_TRY(hipSetDevice(g));
+    IMG_TRY(hipSetDevice(phys[g]));
     const size_t slots = d.count ? d.count : 1;
     IMG_TRY(hipMemsetAsync(d.stats, 0, RT_HIP_NSTATS * sizeof(uint64_t), d.stream));
     IMG_TRY(hipMemsetAsync(d.tiles, 0, slots * 192 * sizeof(float), d.stream));  /* unrendered tiles stay black, */
@@ -1721,7 +1819,7 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
       const uint32_t k1 = (uint32_t)(((uint64_t)d.count * (slab + 1)) / n_slabs);
       if (k1 == k0)
         continue;
-      IMG_TRY(hipSetDevice(g));
+      IMG_TRY(hipSetDevice(phys[g]));
       RtHipParams p = *params;
       p.tile_first = (uint32_t)g + k0 * (uint32_t)G;
       p.tile_stride = (uint32_t)G;
@@ -1742,7 +1840,7 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     {
       for (int g = 0; g < G; g++)
       {
-        IMG_TRY(hipSetDevice(g));
+        IMG_TRY(hipSetDevice(phys[g]));
         IMG_TRY(hipStreamSynchronize(dev[g].stream));
       }
       cancelled = g_cancel && *g_cancel != 0;
@@ -1750,29 +1848,59 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   }
   for (int g = 0; g < G; g++)
   {
-    IMG_TRY(hipSetDevice(g));
+    IMG_TRY(hipSetDevice(phys[g]));
     IMG_TRY(hipEventRecord(dev[g].t1, dev[g].stream));
+    IMG_TRY(hipEventRecord(c.done[g], dev[g].stream));
   }
 
-  /* ---- gather on device 0: grouped point-to-point, every sender straight to the root ---- */
-  IMG_TRY(hipSetDevice(0));
+  /* ---- gather on logical device 0 (the root): every segment straight to it ----
+   * A segment whose sender shares the root's physical device is a device-to-device copy on the root's stream, ordered after
+   * the sender's `done` event; any other travels by grouped ncclSend / ncclRecv (point-to-point over xGMI: a gather to one
+   * root uses the root's direct links concurrently, there is no ring).  A physical device is ONE RCCL rank however many
+   * logical devices it carries: the rank's sends go on its lead's stream, which first waits for the other senders' `done`.
+   * force_comm: every segment, the root's own included, goes through RCCL. */
+  IMG_TRY(hipSetDevice(phys[0]));
   std::vector<size_t> first_slot(G, 0);
   for (int g = 1; g < G; g++)
     first_slot[g] = first_slot[g - 1] + dev[g - 1].count;
-  /* force_comm with one device: g = 0 sends to itself (send and recv of one group on one communicator) */
-  const int g_first = (G == 1 && c.force_comm) ? 0 : 1;
-  if (G > 1 || c.force_comm)
+  auto by_rccl = [&](int g) { return c.force_comm || phys[g] != phys[0]; };
+  bool any_rccl = false;
+  for (int g = 0; g < G; g++)
+  {
+    if (!dev[g].count || (g == 0 && !c.force_comm))
+      continue;
+    if (by_rccl(g))
+    {
+      any_rccl = true;
+      if (c.lead[g] != g)
+      {
+        IMG_TRY(hipSetDevice(phys[g]));
+        IMG_TRY(hipStreamWaitEvent(dev[c.lead[g]].stream, c.done[g], 0));
+      }
+    }
+    else
+    {
+      IMG_TRY(hipSetDevice(phys[0]));
+      IMG_TRY(hipStreamWaitEvent(dev[0].stream, c.done[g], 0));
+      const size_t nf = (size_t)dev[g].count * 192;
+      IMG_TRY(hipMemcpyAsync(c.all_tiles + first_slot[g] * 192, dev[g].tiles, nf * sizeof(float), hipMemcpyDeviceToDevice, dev[0].stream));
+      IMG_TRY(hipMemcpyAsync(c.all_tiles8 + first_slot[g] * 192, dev[g].tiles8, nf, hipMemcpyDeviceToDevice, dev[0].stream));
+    }
+  }
+  if (any_rccl)
   {
     ncclResult_t nr = ncclGroupStart();
-    for (int g = g_first; g < G && nr == ncclSuccess; g++)
+    for (int g = 0; g < G && nr == ncclSuccess; g++)
     {
-      if (!dev[g].count)
+      if (!dev[g].count || (g == 0 && !c.force_comm) || !by_rccl(g))
         continue;
       const size_t nf = (size_t)dev[g].count * 192;
-      nr = ncclSend(dev[g].tiles, nf, ncclFloat, 0, c.comms[g], dev[g].stream);
-      if (nr == ncclSuccess) nr = ncclSend(dev[g].tiles8, nf, ncclUint8, 0, c.comms[g], dev[g].stream);
-      if (nr == ncclSuccess) nr = ncclRecv(c.all_tiles + first_slot[g] * 192, nf, ncclFloat, g, c.comms[0], dev[0].stream);
-      if (nr == ncclSuccess) nr = ncclRecv(c.all_tiles8 + first_slot[g] * 192, nf, ncclUint8, g, c.comms[0], dev[0].stream);
+      const int from = c.comm_of[g];
+      hipStream_t send_stream = dev[c.lead[g]].stream;
+      nr = ncclSend(dev[g].tiles, nf, ncclFloat, 0, c.comms[from], send_stream);
+      if (nr == ncclSuccess) nr = ncclSend(dev[g].tiles8, nf, ncclUint8, 0, c.comms[from], send_stream);
+      if (nr == ncclSuccess) nr = ncclRecv(c.all_tiles + first_slot[g] * 192, nf, ncclFloat, from, c.comms[0], dev[0].stream);
+      if (nr == ncclSuccess) nr = ncclRecv(c.all_tiles8 + first_slot[g] * 192, nf, ncclUint8, from, c.comms[0], dev[0].stream);
     }
     ncclResult_t ne = ncclGroupEnd();
     if (nr == ncclSuccess)
@@ -1785,12 +1913,13 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
       return code;
     }
   }
-  /* scatter each device's segment into the row-major image (device 0) */
+  /* scatter each device's segment into the row-major image (root) */
+  IMG_TRY(hipSetDevice(phys[0]));
   for (int g = 0; g < G; g++)
   {
     if (!dev[g].count)
       continue;
-    const bool local = g == 0 && g_first != 0; /* device 0's own tiles never travel -- unless force_comm sent them through RCCL */
+    const bool local = g == 0 && !c.force_comm; /* the root's own tiles never travel -- unless force_comm sent them through RCCL */
     const float *src = local ? dev[0].tiles : c.all_tiles + first_slot[g] * 192;
     const uint8_t *src8 = local ? dev[0].tiles8 : c.all_tiles8 + first_slot[g] * 192;
     rc = rt_hip_untile(src, src8, W, H, (uint32_t)g, (uint32_t)G, dev[g].count, c.image, c.image8, dev[0].stream);
@@ -1803,12 +1932,12 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   }
   for (int g = 0; g < G; g++)
   {
-    IMG_TRY(hipSetDevice(g));
+    IMG_TRY(hipSetDevice(phys[g]));
     IMG_TRY(hipStreamSynchronize(dev[g].stream));
   }
 
   /* ---- results ---- */
-  IMG_TRY(hipSetDevice(0));
+  IMG_TRY(hipSetDevice(phys[0]));
   if (h_image_rgb)
     IMG_TRY(hipMemcpy(h_image_rgb, c.image, n_px * 3 * sizeof(float), hipMemcpyDeviceToHost));
   if (h_image_rgb8)
@@ -1817,7 +1946,7 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   uint64_t sums[RT_HIP_NSTATS] = {0, 0, 0, 0};
   for (int g = 0; g < G; g++)
   {
-    IMG_TRY(hipSetDevice(g));
+    IMG_TRY(hipSetDevice(phys[g]));
     float ms = 0;
     IMG_TRY(hipEventElapsedTime(&ms, dev[g].t0, dev[g].t1));
     if (ms * 1e-3 > worst)
@@ -1835,6 +1964,20 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
 #undef IMG_TRY
   if (cancelled)
     return fail(RT_HIP_ECANCELLED, "render cancelled: the image holds the tiles finished so far");
+  return RT_HIP_OK;
+}
+
+int set_device_map_impl(const int *map, int n)
+{
+  if (n < 0 || n > 64 || (n > 0 && !map))
+    return fail(RT_HIP_EINVAL, "device map: 0 <= n <= 64 entries");
+  const int have = usable_devices();
+  for (int k = 0; k < n; k++)
+    if (map[k] < 0 || map[k] >= have)
+      return fail(RT_HIP_ENODEV, "device map entry %d -> %d: %d devices available", k, map[k], have);
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  g_device_map_env_read = true; /* an explicit map (or its removal) overrides RT_HIP_DEVICE_MAP */
+  g_device_map.assign(map, map + n);
   return RT_HIP_OK;
 }
 

@@ -24,7 +24,7 @@ long long intersection_test_count = 0;
 
 static int g_max_depth = MAX_DEPTH;
 static uint64_t g_seed = 1666943821ull; /* reference main.c:182 */
-static int g_devices = 1;
+static int g_devices = 0; /* 0: not set -- RT_DEVICES of the environment, else 1 (devices_to_use) */
 static int g_integrator = RT_TRACE_PATH;
 static uint64_t g_host_rng = 0;
 static double g_last_seconds = 0;
@@ -194,6 +194,17 @@ void init_camera(Camera *camera, vec3 position, vec3 target, Options *options)
 
 /* ---- render ---------------------------------------------------------------------- */
 
+/* rt_set_devices() wins; a host that never calls it (the reference's main.c, unmodified, behind this library) can be
+ * given a device count through RT_DEVICES=N in the environment. */
+static int devices_to_use(void)
+{
+  if (g_devices > 0)
+    return g_devices;
+  const char *e = getenv("RT_DEVICES");
+  const int n = e ? atoi(e) : 0;
+  return n >= 1 ? n : 1;
+}
+
 void render_ex(uint8_t *framebuffer, float *linear_rgb, Object *objects, size_t n_objects,
                MeshObject *meshes, size_t n_meshes, Camera *camera, Options *options)
 {
@@ -228,7 +239,7 @@ void render_ex(uint8_t *framebuffer, float *linear_rgb, Object *objects, size_t 
   uint64_t stats[RT_HIP_NSTATS] = {0, 0, 0, 0};
   double seconds = 0;
   int rc = rt_hip_render_image((const RtHipSphere *)objects, n_objects, hm, n_meshes, (const RtHipCamera *)camera,
-                               &p, g_devices, linear_rgb, framebuffer, stats, &seconds);
+                               &p, devices_to_use(), linear_rgb, framebuffer, stats, &seconds);
   free(hm);
   g_last_cancelled = rc == RT_HIP_ECANCELLED;
   if (rc != RT_HIP_OK && rc != RT_HIP_ECANCELLED)

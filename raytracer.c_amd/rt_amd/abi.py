@@ -109,6 +109,7 @@ SHIM_SYMBOLS = {
     "rt_hip_set_cancel_flag": (None, [C.c_void_p]),
     "rt_hip_release_cache": (None, []),
     "rt_hip_cache_builds": (C.c_uint64, []),
+    "rt_hip_set_device_map": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "rt_hip_render_image": (C.c_int, [C.POINTER(Object), C.c_size_t, C.POINTER(RtHipMesh), C.c_size_t,
                                       C.POINTER(Camera), C.POINTER(RtHipParams), C.c_int, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),

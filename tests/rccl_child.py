@@ -7,6 +7,8 @@ mode `torch`: torch.distributed's "nccl" backend (= RCCL on ROCm), world size 1:
 mode `shim` : RT_HIP_FORCE_COMM=1 makes rt_hip_render_image(n_devices = 1) create its cached communicator with
               ncclCommInitAll(.., 1, ..), send device 0's tile buffers to itself through the grouped ncclSend / ncclRecv
               block of the N > 1 path, and destroy the communicator in rt_hip_release_cache().
+mode `shim_map`: the same switch under rt_hip_set_device_map({0 x 8}): 1, 2, 3 and 8 LOGICAL devices on the one GPU, one
+              communicator (a physical device is one rank), every segment sent to self through RCCL.
 Prints one JSON line.  A separate process so that a bootstrap problem (no NIC, library mismatch) or a hang is the
 child's, under the parent's time-out."""
 import json
@@ -69,5 +71,30 @@ def shim_mode():
     print(json.dumps({"mode": "shim", "frame_equal": bool(eq), "context_builds_with_comm": int(builds)}), flush=True)
 
 
+def shim_map_mode():
+    import ctypes as C
+    import numpy as np
+    import torch  # noqa: F401
+    from rt_amd import abi, gpu as G, scene as S
+    shim = abi.load_shim()
+    sc = S.build_scene(3, 204, 116, 4)
+    os.environ.pop("RT_HIP_FORCE_COMM", None)
+    plain = G.render_image_host(sc, SEED, n_devices=1)
+    shim.rt_hip_release_cache()
+    os.environ["RT_HIP_FORCE_COMM"] = "1"
+    m = (C.c_int * 8)(*([0] * 8))
+    assert shim.rt_hip_set_device_map(m, 8) == 0
+    b0 = shim.rt_hip_cache_builds()
+    devices, eq = [1, 2, 3, 8], True
+    for g in devices:
+        x = G.render_image_host(sc, SEED, n_devices=g)
+        eq = eq and np.array_equal(x[0], plain[0]) and np.array_equal(x[1], plain[1]) and x[2] == plain[2]
+    builds = shim.rt_hip_cache_builds() - b0
+    shim.rt_hip_release_cache()
+    shim.rt_hip_set_device_map(None, 0)
+    del os.environ["RT_HIP_FORCE_COMM"]
+    print(json.dumps({"mode": "shim_map", "frame_equal": bool(eq), "devices": devices, "context_builds": int(builds)}), flush=True)
+
+
 if __name__ == "__main__":
-    {"torch": torch_mode, "shim": shim_mode}[sys.argv[1]]()
+    {"torch": torch_mode, "shim": shim_mode, "shim_map": shim_map_mode}[sys.argv[1]]()
