@@ -322,14 +322,14 @@ def sample_tiles(width, height, budget_tiles):
     return first, stride, count
 
 
-def tile_pixel_indices(width, height, first, stride, count):
+def tile_pixel_indices(width, height, first, stride, count, tiles=None):
     """-> (linear pixel indices [n], slot in the compact tile buffer [n], pixel-in-tile [n]) of the inside-image pixels of
-    tiles first, first + stride, ...: tile by tile, row-major inside a tile"""
+    tiles first, first + stride, ... (or of the explicit list `tiles`): tile by tile, row-major inside a tile"""
     import numpy as np
     tx = (width + 7) // 8
     px, slot, pit = [], [], []
-    for k in range(count):
-        t = first + k * stride
+    ids = [first + k * stride for k in range(count)] if tiles is None else [int(t) for t in tiles]
+    for k, t in enumerate(ids):
         x0, y0 = (t % tx) * 8, (t // tx) * 8
         for r in range(8):
             for c in range(8):
@@ -351,9 +351,13 @@ def cpu_reference(config, width, height, spp, depth, n_meshes, budget_tiles, wor
     import oracle_py
     have_ref = oracle_py.ref_mesh_available(depth) if n_meshes else oracle_py.ref_available(depth)
     kind = "reference" if have_ref else "port"
-    first, stride, count = budget_tiles if isinstance(budget_tiles, tuple) else sample_tiles(width, height, budget_tiles)
+    tile_list = budget_tiles["tiles"] if isinstance(budget_tiles, dict) else None    # an explicit list of tiles
+    if tile_list is not None:
+        first, stride, count = -1, 0, len(tile_list)
+    else:
+        first, stride, count = budget_tiles if isinstance(budget_tiles, tuple) else sample_tiles(width, height, budget_tiles)
     total = ((width + 7) // 8) * ((height + 7) // 8)
-    px, _, _ = tile_pixel_indices(width, height, first, stride, count)
+    px, _, _ = tile_pixel_indices(width, height, first, stride, count, tiles=tile_list)
     nproc, usable, quota = host_cpus()
     cores = max(1, min(workers or usable, len(px)))
     chunks = [px[i::cores] for i in range(cores)]  # interleaved: even load
@@ -371,12 +375,12 @@ def cpu_reference(config, width, height, spp, depth, n_meshes, budget_tiles, wor
                    if kind == "reference" else "oracle/pt_oracle.c (CPU restatement, bit-pinned to oracle/_ref by tests/test_oracle_ref.py)")
     baseline = {"value": casts / dt, "unit": "ray-bounces/s", "cores": len(jobs), "kind": kind,
                 "host_nproc": nproc, "host_usable_cpus": usable, "host_cgroup_cpu_quota": quota,
-                "sample": f"{count} of {total} 8x8 tiles (tile {first} + {stride} k; {len(px)} pixels) at full {spp} spp, "
+                "sample": f"{count} of {total} 8x8 tiles ({'an explicit list' if tile_list is not None else f'tile {first} + {stride} k'}; {len(px)} pixels) at {spp} spp, "
                           f"{len(jobs)} single-thread processes (host: {nproc} logical CPUs, {usable} usable by this "
                           f"process), {dt:.1f} s wall",
                 "mpixel_samples_per_s": len(px) * spp / dt * 1e-6}
     sample = {"first": first, "stride": stride, "count": count, "px": px, "rays": rays, "casts": casts, "spp": spp,
-              "oracle": oracle_name, "seconds": dt}
+              "oracle": oracle_name, "seconds": dt, "tiles": tile_list}
     if want_pixels:
         mean = np.zeros((len(px), 3))
         rgb8 = np.zeros((len(px), 3), dtype=np.uint8)
@@ -445,6 +449,41 @@ def gpu_parity(gs, sc, dev, sample, frame, frame8, integrator="path", hdr=False)
     out["ok"] = bool(out["ok"] and out["timed_frame_equals_rerender"])
     out["compared"] = ("the frame the timed steps produced, at the sample's pixels, against the CPU reference's means; "
                        "counters from a re-render of exactly those tiles")
+    return out
+
+
+def config5_wide_parity(gs, sc, dev, cpu_workers, spp=4, n_sil=128, n_in=128, n_out=768):
+    """The second parity sample of BASELINE configs[4] AT ITS OWN 3840x2160: 1,024 tiles = 65,536 pixels at
+    `spp` samples against the reference's compiled code with its mesh scan revived (RefMeshOracle: 10,248 tests per scan) --
+    128 tiles that straddle the mesh's outline, 128 inside it, 768 strided over the rest of the frame, which see the mesh only
+    through a bounce (rt_amd.scene.mesh_view_tiles).  What this pins at full resolution and the two 4096-spp tiles cannot: the
+    resolution-dependent conservative rules of the hierarchy kernels (a tile's cone of camera rays against the mesh's
+    bounding ball, the probe that lets most camera rays skip the walk) across the frame.  Each tile is rendered on its own
+    (render_tiles, tile_first = t, count 1, samples = spp): pixels, bytes, rays and ray-bounces of the subset."""
+    import numpy as np
+    import torch
+    from rt_amd import abi, scene as S
+    view = S.mesh_view_tiles(sc)
+    tiles = np.concatenate([S.pick_evenly(view["silhouette"], n_sil), S.pick_evenly(view["inside"], n_in),
+                            S.pick_evenly(view["outside"], n_out)]).astype(np.uint32)
+    _, sample = cpu_reference(sc.config, sc.width, sc.height, spp, sc.max_depth, sc.n_meshes, {"tiles": tiles}, cpu_workers)
+    px, slot, pit = tile_pixel_indices(sc.width, sc.height, -1, 0, len(tiles), tiles=tiles)
+    assert (px == sample["px"]).all()
+    t_all = torch.empty((len(tiles), abi.TILE_PIXELS, 3), dtype=torch.float32, device=dev)
+    t8_all = torch.empty((len(tiles), abi.TILE_PIXELS, 3), dtype=torch.uint8, device=dev)
+    st = torch.zeros(abi.NSTATS, dtype=torch.int64, device=dev)
+    for k, t in enumerate(tiles):
+        gs.render_tiles(SEED, int(t), 1, 1, t_all[k:k + 1], t8_all[k:k + 1], st, samples=spp)
+    torch.cuda.synchronize(dev)
+    gs.launch_status()
+    st = st.cpu().tolist()
+    out = parity_numbers(t_all.cpu().numpy()[slot, pit], t8_all.cpu().numpy()[slot, pit], st[abi.STAT_RAYS], st[abi.STAT_CASTS], sample)
+    out["tiles_by_view"] = {"straddle_the_mesh_outline": int(min(n_sil, len(view["silhouette"]))),
+                            "inside_the_outline": int(min(n_in, len(view["inside"]))),
+                            "see_the_mesh_only_through_a_bounce": int(min(n_out, len(view["outside"])))}
+    out["kernel"] = gs.last_launch_kernel()
+    out["compared"] = (f"{len(tiles)} tiles of the {sc.width}x{sc.height} frame, each rendered on its own at {spp} spp, against the "
+                       "CPU reference's means of the same pixels and samples")
     return out
 
 
@@ -531,7 +570,7 @@ def integrator_line(kind, dev, parity_tiles=0, cpu_workers=0):
     torch.cuda.synchronize(dev)
     ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     rays, casts, tests, samples = [int(v) / steps for v in stats.cpu().tolist()]
-    kernel = gs.kernel_name(integrator)
+    kernel = gs.last_launch_kernel()   # what the timed launches took (the launch's own facts included), not only what the scene suggests
     what = {"glass": ("trace_path, M_REFRACTION scene (raytracer.c:514-539)", "config 4 room, every fifth packed sphere M_REFRACTION"),
             "glass_mesh": ("trace_path, M_REFRACTION mesh through the hierarchy (raytracer.c:514-539)",
                            "BASELINE configs[4] scene with its mesh turned M_REFRACTION")}.get(kind, ("cast_ray (raytracer.c:556-641)", "BASELINE configs[3] scene"))
@@ -588,9 +627,9 @@ def config_line(cfg, spp, steps, dev, parity_tiles=0, cpu_workers=0):  # parity_
     fr = flops_per_ray(sc.n_objects, sc.n_triangles)
     line = {"config": cfg, "workload": f"BASELINE configs[{cfg - 1}]: {sc.width}x{sc.height}, {sc.samples} spp, "
                                        f"{sc.n_objects} spheres + {sc.n_triangles} triangles, depth {sc.max_depth}",
-            "kernel": gs.kernel_name(), "kernel_ms": ms, "steps": steps, "ray_bounces_per_s": casts / (ms * 1e-3),
+            "kernel": gs.last_launch_kernel(), "kernel_ms": ms, "steps": steps, "ray_bounces_per_s": casts / (ms * 1e-3),
             "mpixel_samples_per_s": samples / (ms * 1e-3) * 1e-6, "rays_per_sample": rays / max(samples, 1),
-            "flops_per_ray_bounce": fr, "frac": casts * fr / (ms * 1e-3) * 1e-12 / PEAK_FP64_TFLOPS, "isa": isa_keys(gs.kernel_name())}
+            "flops_per_ray_bounce": fr, "frac": casts * fr / (ms * 1e-3) * 1e-12 / PEAK_FP64_TFLOPS, "isa": isa_keys(gs.last_launch_kernel())}
     line.update(pmc_keys(committed_pmc(cfg, sc.width, sc.height, sc.samples, 1, any_spp=True), sc.samples, ms))
     line.update(executed_work(committed_diag(cfg), casts, ms * 1e-3, sc.n_objects, sc.n_triangles))
     if parity_tiles:
@@ -598,6 +637,11 @@ def config_line(cfg, spp, steps, dev, parity_tiles=0, cpu_workers=0):  # parity_
             image, image8 = gs.untile(tiles, tiles8, 0, 1, total)     # the last timed frame, row-major
             _, sample = cpu_reference(cfg, sc.width, sc.height, sc.samples, sc.max_depth, sc.n_meshes, parity_tiles, cpu_workers)
             line["parity"] = gpu_parity(gs, sc, dev, sample, image, image8)
+            if cfg == 5 and sc.width >= 1920:
+                # ... and the wide sample at the frame's own resolution: >= 65k pixels, few samples each
+                wide = config5_wide_parity(gs, sc, dev, cpu_workers)
+                line["parity"]["wide"] = wide
+                line["parity"]["ok"] = bool(line["parity"]["ok"] and wide["ok"])
         except Exception as exc:
             line["parity"] = {"ok": False, "error": repr(exc)}
     nominal = S.scene_info(cfg).samples
@@ -628,38 +672,64 @@ def host_path_main(args):
     (grouped RCCL send/recv to device 0 inside the shim): what the C host's render() does."""
     import torch  # noqa: F401  (one HIP runtime: load it before the shim)
     from rt_amd import abi, gpu as G, scene as S
+    import ctypes as C
     shim = abi.load_shim()
     have = shim.rt_hip_device_count()
     n = args.gpus
-    if have < n:
+    logical = args.logical_devices
+    if logical:
+        # N LOGICAL devices on this box's GPU 0 (rt_hip_set_device_map): the whole n_devices > 1 path of the C host -- partition,
+        # per-device launches, the gather's slot arithmetic, the per-segment scatter, the counter sums -- executed on one GPU
+        m = (C.c_int * n)(*([0] * n))
+        if shim.rt_hip_set_device_map(m, n) != 0:
+            print(json.dumps({"host_path": {"error": shim.rt_hip_last_error().decode()}}))
+            return 0
+    elif have < n:
         print(json.dumps({"host_path": {"error": f"{have} devices visible, {n} requested"}}))
         return 0
     sc = S.build_scene(args.config, args.width or None, args.height or None, args.spp or None)
     out = {"n_devices": n, "workload": f"{sc.width}x{sc.height}, {sc.samples} spp"}
-    times, kernel_s = [], []
+    if logical:
+        out["logical_devices_on_one_gpu"] = True
+        out["note"] = (f"{n} logical devices mapped onto GPU 0: the C host's multi-device code path executed and checked on one "
+                       "GPU; its time is NOT a scaling measurement (the devices share the GPU)")
+    times, kernel_s, phases = [], [], []
     ref_img = None
+    ph = (C.c_double * 3)()
     for k in range(args.warmup + args.steps):
         t0 = time.perf_counter()
         img, img8, st, secs = G.render_image_host(sc, SEED, n_devices=n)
         dt = time.perf_counter() - t0
+        shim.rt_hip_last_image_phases(ph)
+        if k == 0:
+            out["first_call_ms"] = dt * 1e3   # context build included: scene upload, buffers, workspaces (communicators for N > 1)
+            out["first_call_context_ms"] = ph[0] * 1e3
         if k >= args.warmup:
             times.append(dt)
             kernel_s.append(secs)
+            phases.append([ph[0] * 1e3, ph[1] * 1e3, ph[2] * 1e3])
         if ref_img is None:
             ref_img = img
-    out["call_ms"] = [t * 1e3 for t in times]           # incl. scene upload, D2H of the frame, PCIe
+    out["call_ms"] = [t * 1e3 for t in times]           # the whole call: scene compare, launches, kernels, gather, the frame over PCIe
     out["kernel_ms"] = [t * 1e3 for t in kernel_s]      # render kernels, max over devices
+    out["phase_ms"] = {"context": min(p[0] for p in phases), "launch_to_idle": min(p[1] for p in phases), "copy_out": min(p[2] for p in phases),
+                       "note": "host clock inside rt_hip_render_image: [context] scene compare (a rebuild on the first call only), "
+                               "[launch_to_idle] launches + kernels + gather + scatter until every stream is idle, [copy_out] frame, "
+                               "bytes and counters over PCIe"}
     out["ray_bounces_per_s"] = st["casts"] / min(times)
+    out["kernel"] = shim.rt_hip_last_launch_kernel().decode()
     if n > 1:  # the assembled frame must equal the one-device frame bit for bit
-        one, _, st1, _ = G.render_image_host(sc, SEED, n_devices=1)
-        out["equals_one_device_frame"] = bool((one == ref_img).all()) and st1 == st
+        one, one8, st1, _ = G.render_image_host(sc, SEED, n_devices=1)
+        out["equals_one_device_frame"] = bool((one == ref_img).all()) and bool((one8 == img8).all()) and st1 == st
     print(json.dumps({"host_path": out}), flush=True)
     return 0
 
 
-def run_host_path_child(args, n, timeout_s=240):
+def run_host_path_child(args, n, timeout_s=240, logical=False):
     cmd = [sys.executable, os.path.abspath(__file__), "--host-path", "--gpus", str(n), "--steps", "2", "--warmup", "1",
            "--config", str(args.config), "--spp", str(args.spp), "--width", str(args.width), "--height", str(args.height)]
+    if logical:
+        cmd.append("--logical-devices")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                             "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     try:
@@ -672,6 +742,39 @@ def run_host_path_child(args, n, timeout_s=240):
         return {"error": f"timed out after {timeout_s} s"}
     except Exception as exc:
         return {"error": repr(exc)}
+
+
+def run_cli_host(args, timeout_s=300):
+    """The C command-line host (raytracer.c_amd/host/raytracer = the reference's main.c flags) as a process: wall time from
+    exec to exit for the bench's workload, and where it went -- the host prints its own phase clock (HIP runtime start,
+    context = scene upload + buffers + workspaces, render, frame over PCIe, PNG encode + write)."""
+    exe = os.path.join(ROOT, "raytracer.c_amd", "host", "raytracer")
+    if not os.path.exists(exe):
+        return {"error": "raytracer.c_amd/host/raytracer is not built"}
+    import tempfile
+    from rt_amd import scene as S
+    info = S.scene_info(args.config)
+    w, h, spp = args.width or info.width, args.height or info.height, args.spp or info.samples
+    with tempfile.TemporaryDirectory() as tmp:
+        out_png = os.path.join(tmp, "bench_cli.png")
+        cmd = [exe, "-w", str(w), "-h", str(h), "-s", str(spp), "-c", str(args.config), "-d", str(info.max_depth), "-o", out_png]
+        try:
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            wall = time.perf_counter() - t0
+        except subprocess.TimeoutExpired:
+            return {"error": f"timed out after {timeout_s} s"}
+        if p.returncode != 0:
+            return {"error": f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}"}
+        res = {"command": " ".join(cmd[:-1] + ["<tmp>.png"]), "process_wall_ms": wall * 1e3, "png_bytes": os.path.getsize(out_png)}
+        for ln in p.stdout.splitlines():
+            if ln.startswith("phases: "):
+                for part in ln[len("phases: "):].split(", "):
+                    k, v = part.rsplit(" ", 2)[0], part.rsplit(" ", 2)[1]
+                    res.setdefault("phase_ms", {})[k.replace(" ", "_")] = float(v) * 1e3
+            if ln.startswith("cast "):
+                res["rays"] = int(ln.split()[1])
+        return res
 
 
 # ---- `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves ---------
@@ -741,6 +844,8 @@ def main():
                     help="spp of config 5 in the per-configuration array (0 = its own 4096: ~4 s a frame on one GPU)")
     ap.add_argument("--integrators-only", action="store_true",
                     help="dev: only the `integrators` entries (glass scene, cast_ray), one JSON line, no CPU legs")
+    ap.add_argument("--logical-devices", action="store_true",
+                    help="with --host-path: --gpus N LOGICAL devices mapped onto GPU 0 (rt_hip_set_device_map)")
     ap.add_argument("--host-path", action="store_true",
                     help="single process: time rt_hip_render_image() over --gpus devices (the C host's path) and exit")
     args = ap.parse_args()
@@ -997,13 +1102,20 @@ def main():
                 out["error"] = "parity check failed: " + "; ".join(f"{w}: {json.dumps(p_)[:300]}" for w, p_ in bad)
                 rc = 5
 
-    # N > 1 on real GPUs: the single-process C path (rt_hip_render_image over N devices, grouped RCCL
-    # send/recv inside the shim) in a child of rank 0 while every rank idles at the barrier below -- so it
-    # runs whenever more than one GPU is present.  A failure or time-out is reported, never fatal.
-    if world > 1 and not rehearse and os.environ.get("RT_BENCH_HOST_PATH", "1") != "0":
+    # The single-process C path -- rt_hip_render_image, what render() of the raytracer.h boundary calls (reference
+    # main.c:427-443): scene compare, launches, the frame over PCIe -- in a child of rank 0.  N > 1 on real GPUs: over the N
+    # devices (grouped RCCL send / recv inside the shim) while every rank idles at the barrier below.  N = 1: the headline's
+    # whole-call time (PCIe-inclusive; never `value`), then the same frame on 8 LOGICAL devices mapped onto this GPU -- the
+    # multi-device path executed and compared bit for bit on the one GPU there is -- and the C command-line host's process
+    # wall time by phase.  A failure or time-out is reported, never fatal.
+    if not rehearse and not args.shard and os.environ.get("RT_BENCH_HOST_PATH", "1") != "0":
         if rank == 0:
             out["host_path"] = run_host_path_child(args, world)
-        dist.barrier(group=ctrl)
+            if world == 1:
+                out["host_path_logical8"] = run_host_path_child(args, 8, logical=True)
+                out["cli_host"] = run_cli_host(args)
+        if world > 1:
+            dist.barrier(group=ctrl)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

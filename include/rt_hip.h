@@ -153,6 +153,43 @@ int rt_hip_scene_hull_facets(const RtHipScene *scene, uint32_t *n_plus, uint32_t
  * triangles, table size, M_CHECKERED / M_REFRACTION materials) -- for profiles and bench lines */
 const char *rt_hip_kernel_name(const RtHipScene *scene, uint32_t integrator);
 
+/* ... and of the kernel the calling thread's last rt_hip_render_tiles / _chunked call actually launched: the launch's own
+ * facts (samples x depth against the windowed sums of the M_REFRACTION kernels, the width of the pending-ray pool that could
+ * be had) can name another row of the pick table than the scene alone does. */
+const char *rt_hip_last_launch_kernel(void);
+
+/* The kernel family by index (0 .. rt_hip_kernel_count() - 1): name, and how many render launches of it this PROCESS has
+ * made (*launches, may be NULL) -- what a test run actually exercised.  NULL beyond the family. */
+int rt_hip_kernel_count(void);
+const char *rt_hip_kernel_launches(int index, uint64_t *launches);
+
+/* The pick table itself, without a device: which kernel a launch of a scene of this class takes.  A class is what the family is
+ * split by (pt_kernel.hip, pt_pick_table): counts decide staging and the mesh form, the flags the material code. */
+typedef struct
+{
+  uint32_t integrator;              /* RT_HIP_TRACE_PATH | RT_HIP_CAST_RAY */
+  uint32_t n_spheres, n_meshes, n_triangles;
+  uint32_t any_checker, any_refract, any_mirror_glass; /* materials: M_CHECKERED, M_REFRACTION, M_REFLECTION | M_REFRACTION on one object */
+  uint32_t wide_range;              /* a centre or radius beyond 1e17 */
+  uint32_t mesh_round;              /* the triangles' bounding sphere is no larger a target than their box */
+  int32_t samples_per_chunk, max_depth;
+  uint32_t have_park_ws;            /* the parked-walk workspace could be allocated */
+  uint32_t wide_pend_ok;            /* the pending-ray pool could be had at 4 x 512 stacks per slot */
+} RtHipSceneClass;
+const char *rt_hip_kernel_for_class(const RtHipSceneClass *scene_class);
+
+/* Device-side failures of the render launches on `device` since the last call: sticky bits, read and cleared here.  A
+ * workgroup that cannot get a slot of a per-device pool renders nothing; its tile reads NaN (bytes 255) -- which is also what
+ * a legitimate NaN sample gives (raytracer.c:218-220), so the pixel values cannot tell the caller: this can.  Call it after
+ * synchronising the streams launched on.  Returns RT_HIP_OK with *flags = 0, or RT_HIP_ERUNTIME with the reason in
+ * rt_hip_last_error().  rt_hip_render_image() checks it itself and returns the error. */
+enum
+{
+  RT_HIP_FAIL_PEND_SLOT = 1, /* no free slot in the pending-ray pool (two-child materials) */
+  RT_HIP_FAIL_PARK_SLOT = 2  /* no free slot in the parked-walk workspace (mesh hierarchies) */
+};
+int rt_hip_launch_status(int device, uint32_t *flags);
+
 /* ---- the hot path: replaces the loop nest of render() (raytracer.c:184-222) ---- */
 
 /* d_tiles_rgb : tile_count*192 floats  (linear per-pixel sample mean)
@@ -167,8 +204,15 @@ int rt_hip_render_tiles(const RtHipScene *scene, const RtHipCamera *camera, cons
  * rt_hip_chunk_workspace_bytes(tile_count) bytes of device memory (may be NULL when
  * sample_chunks == 1); it is cleared, filled and resolved on `stream`.
  * rt_hip_suggest_chunks() returns a good value for the scene's device. */
-size_t rt_hip_chunk_workspace_bytes(uint32_t tile_count);
+size_t rt_hip_chunk_workspace_bytes(uint32_t tile_count);   /* enough for any scene */
+/* ... for this scene: scenes without M_REFRACTION need a sixth of it (plain fixed-point sums; the others keep windowed sums) */
+size_t rt_hip_scene_chunk_workspace_bytes(const RtHipScene *scene, uint32_t tile_count);
 uint32_t rt_hip_suggest_chunks(const RtHipScene *scene, uint32_t tile_count, int32_t samples);
+/* ... knowing the launch's max_depth: scenes with M_REFRACTION need samples_per_chunk x 2^(max_depth + 1) <= 2^30 for the pooled
+ * and parked-walk kernels (their windowed pixel sums) -- the suggestion is at least that many chunks.  A launch that gets fewer
+ * (or no workspace) and does not fit runs on the static kernel of the family, three times slower on a glass mesh: the image is
+ * the same.  rt_hip_render_tiles_chunked raises a too-small chunk count itself whenever a workspace was handed over. */
+uint32_t rt_hip_suggest_chunks_depth(const RtHipScene *scene, uint32_t tile_count, int32_t samples, int32_t max_depth);
 int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *camera, const RtHipParams *params,
                                 uint32_t sample_chunks, void *d_workspace, float *d_tiles_rgb,
                                 uint8_t *d_tiles_rgb8, uint64_t *d_stats, void *stream);
@@ -203,6 +247,21 @@ int rt_hip_selftest_math(int op, const double *h_a, const double *h_b, double *h
  * as rt_hip_render_tiles builds it for a camera.  |centre|, |radius| <= 1e17. */
 int rt_hip_selftest_intersect(int kind, const double *h_rays, const double *h_prims, size_t n, double near_R,
                               uint8_t *h_hit, double *h_tuv, uint64_t *h_keep, int device);
+
+/* Fault injection: from now on the named optional device allocations of the shim behave as if hipMalloc had failed, so that
+ * the fallback rows of the pick table (no parked-walk workspace: the lane-waiting kernels; no pending-ray pool of 4 x 512 stacks
+ * per slot: the static kernel of the family) are reachable on a device with 288 GB.  0 switches it off.  A scene that has
+ * already met its workspace keeps it. */
+enum
+{
+  RT_HIP_FAIL_ALLOC_PARK_WS = 1,
+  RT_HIP_FAIL_ALLOC_WIDE_PEND = 2
+};
+void rt_hip_selftest_fail_alloc(uint32_t mask);
+
+/* How many slots per XCD the two per-device pools get on `device` (the parked-walk workspace, the pending-ray pool): CUs per
+ * XCD x the most workgroups of any slot-taking kernel a CU can hold, + 25 %, rounded up to a multiple of 32. */
+int rt_hip_selftest_pool_slots(int device, uint32_t *park_slots_per_xcd, uint32_t *pend_slots_per_xcd);
 
 /* Launches n_workgroups one-wave workgroups; h_counts[x] = how many of them read HW_REG_XCC_ID == x
  * (bits 3:0).  The parked-walk kernels partition their workspace by that id (every owner a slot ever
@@ -245,6 +304,11 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
  * rt_hip_cache_builds() counts how often a context had to be (re)built (for tests). */
 void rt_hip_release_cache(void);
 uint64_t rt_hip_cache_builds(void);
+
+/* Where the host time of the last rt_hip_render_image() went, seconds: [0] context (scene compare; on a rebuild: upload,
+ * buffers, workspaces, communicators), [1] launches + kernels + gather + scatter until every stream is idle, [2] the frame,
+ * bytes and counters over PCIe. */
+void rt_hip_last_image_phases(double seconds[3]);
 
 /* Logical -> physical device map of rt_hip_render_image(): with a map of n entries, n_devices may be up to n and logical
  * device g runs on HIP device map[g]; entries may repeat.  Logical devices that share a physical one keep separate scenes,

@@ -254,8 +254,12 @@ struct BvhBuild
     max_depth = 0;
     while (((uint64_t)PT_BVH_LEAF << max_depth) < n_tri)
       max_depth++;
-    const char *e = getenv("RT_HIP_BVH_MEDIAN"); /* development switch (A/B): round 1-3's median builder alone */
+#ifdef PT_DEV_KERNELS
+    const char *e = getenv("RT_HIP_BVH_MEDIAN"); /* development builds (A/B, and the two-builders-one-frame test): round 1-3's median builder alone */
     const bool median_asked = e && e[0] == '1';
+#else
+    const bool median_asked = false;
+#endif
     bin_of.assign(n_tri, 0);
     const std::vector<uint32_t> order0 = order;
     median_only = true;

@@ -122,7 +122,7 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     if (threadIdx.x < 2 * (PT_BLOCK / 64))
       pend_free[threadIdx.x >> 1][threadIdx.x & 1u] = ~0ull;
     if (threadIdx.x == 0)
-      pend_slot_lds = pt_pool_acquire(L.pend_flags, L.pend_slots_per_xcd);
+      pend_slot_lds = pt_pool_acquire(L.pend_flags, L.pend_slots_per_xcd, L.status, PT_FAIL_PEND_SLOT);
   }
   if (threadIdx.x < PT_TILE_PIXELS)
   {
@@ -195,7 +195,8 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
   uint32_t pend_id = 0xFFu; /* REFR: the path's stack id, 0xFF = none yet */
   const PendStack no_stack = {nullptr, 0, 0u, 0u};
   /* REFR: this wave's 128 stacks in the workgroup's pool slot, [id][entry][field] (PendStack); no slot (a sizing bug of the
-   * pool, never seen): the tile comes out NaN, as in the static body */
+   * pool; RT_HIP_POOL_SLOTS=1 of the development build provokes it): the tile comes out NaN, as in the static body, and the launch is reported as
+   * failed through the status word (pt_pool_acquire) */
   const uint32_t pend_slot = REFR ? pend_slot_lds : 0u;
   const bool pend_ok = !REFR || pend_slot != 0xFFFFFFFFu;
   const uint32_t pool = pend_ok ? pool_jobs : 0u;
@@ -571,18 +572,41 @@ __device__ __forceinline__ void render_tiles_pooled(const PtLaunch &L)
     if (!pend_ok && threadIdx.x < 3)
       pix_nan[threadIdx.x] = ~0ull;
     __syncthreads();
-    /* thread = (pixel, channel), as finish_pixels: the windowed sum -> mean -> float + tonemapped byte */
-    if (threadIdx.x < PT_TILE_PIXELS * 3)
+    if (L.sample_chunks == 1)
     {
-      const uint32_t t = threadIdx.x / 3u, c = threadIdx.x - 3u * t;
-      const bool inside = (tile % L.tiles_x) * PT_TILE + (t & 7u) < (uint32_t)L.width && (tile / L.tiles_x) * PT_TILE + (t >> 3) < (uint32_t)L.height;
-      double mean = win_value(&pix_win[threadIdx.x * PT_WIN_N]) * (1.0 / (double)L.samples);
-      mean = ((pix_nan[c] >> t) & 1ull) ? __longlong_as_double(0x7FF8000000000000ll) : mean;
-      out_f[threadIdx.x] = inside ? (float)mean : 0.f;
-      out_b[threadIdx.x] = inside ? tonemap(mean) : 0;
+      /* thread = (pixel, channel), as finish_pixels: the windowed sum -> mean -> float + tonemapped byte */
+      if (threadIdx.x < PT_TILE_PIXELS * 3)
+      {
+        const uint32_t t = threadIdx.x / 3u, c = threadIdx.x - 3u * t;
+        const bool inside = (tile % L.tiles_x) * PT_TILE + (t & 7u) < (uint32_t)L.width && (tile / L.tiles_x) * PT_TILE + (t >> 3) < (uint32_t)L.height;
+        win_normalize(&pix_win[threadIdx.x * PT_WIN_N]);
+        double mean = win_value(&pix_win[threadIdx.x * PT_WIN_N]) * (1.0 / (double)L.samples);
+        mean = ((pix_nan[c] >> t) & 1ull) ? __longlong_as_double(0x7FF8000000000000ll) : mean;
+        out_f[threadIdx.x] = inside ? (float)mean : 0.f;
+        out_b[threadIdx.x] = inside ? tonemap(mean) : 0;
+      }
+      __syncthreads();
+      store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, true, true);
     }
-    __syncthreads();
-    store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, true, true);
+    else
+    {
+      /* one of several sample chunks of this tile: its windows, carry-normalised (words below 2^32: the tile's record takes one
+       * piece per chunk and word), are added to the tile's record in HBM -- integer atomics: exact, order-free;
+       * pt_resolve_tiles normalises the total and finishes the pixels */
+      if (threadIdx.x < PT_TILE_PIXELS * 3)
+      {
+        unsigned long long *const w = &pix_win[threadIdx.x * PT_WIN_N];
+        win_normalize(w);
+        unsigned long long *const acc = L.acc_ws + ((size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x) * PT_WIN_N;
+#pragma unroll
+        for (int k = 0; k < PT_WIN_N; k++)
+          if (w[k] != 0ull)
+            atomicAdd(&acc[k], w[k]);
+      }
+      if (threadIdx.x < 3 && pix_nan[threadIdx.x] != 0)
+        atomicOr(&L.acc_ws[(size_t)L.tile_count * (PT_TILE_PIXELS * 3 * PT_WIN_N) + (size_t)slot * 3 + threadIdx.x], pix_nan[threadIdx.x]);
+      store_tile(L, out_f, out_b, wg_stats, tile, slot, S.n_sph + S.n_tri, false, chunk == 0);
+    }
     if (pend_ok && threadIdx.x == 0)
       atomicExch(&L.pend_flags[pend_slot], 0u); /* every lane is past its last pop (the barriers above) */
   }

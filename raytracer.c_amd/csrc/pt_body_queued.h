@@ -110,14 +110,15 @@ __device__ __forceinline__ void ring_st3(const ParkRing &r, uint32_t field, uint
 }
 
 /* The workgroup's workspace slot, or 0xFFFFFFFF when there is none: no workspace (cannot happen: without one
- * pt_launch_render takes the lane-waiting _tri_big kernels), or -- a sizing bug of the pool, never seen: it has
- * PT_PARK_SLOTS_PER_XCD = 192 slots for at most 160 resident workgroups -- every slot of this XCD taken after a bounded
- * search.  The waves of such a workgroup render nothing and say so: every pixel of their tiles comes out NaN (bytes 255;
- * render_tiles_queued), rather than spin for ever or walk rays from registers the kernel does not have.  Thread 0 only. */
+ * pt_launch_render refuses the parked-walk kernels), or -- a sizing bug of the pool (pt_pool_slots_per_xcd gives it 25 % more
+ * slots than workgroups can be resident; RT_HIP_POOL_SLOTS=1 of the development build gives it one) -- every slot of this XCD taken after a
+ * bounded search.  The waves of such a workgroup render nothing and say so twice: PT_FAIL_PARK_SLOT in the device's status word,
+ * which fails the launch for the host (rt_hip_launch_status), and every pixel of their tiles NaN (bytes 255;
+ * render_tiles_queued) -- rather than spin for ever or walk rays from registers the kernel does not have.  Thread 0 only. */
 __device__ __forceinline__ uint32_t lane_of_thread() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t pt_park_acquire(const PtLaunch &L)
 {
-  return pt_pool_acquire(L.park_ws == nullptr ? nullptr : L.park_flags, L.park_slots_per_xcd);
+  return pt_pool_acquire(L.park_ws == nullptr ? nullptr : L.park_flags, L.park_slots_per_xcd, L.status, PT_FAIL_PARK_SLOT);
 }
 
 /* The per-lane traversal stacks of the parked-walk kernels: 24-bit entries (a 16-bit and an 8-bit array, entry-major,
@@ -499,7 +500,7 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   {
     park_slot_lds = pt_park_acquire(L);
     if (REFR)
-      pend_slot_lds = pt_pool_acquire(L.pend_ws == nullptr ? nullptr : L.pend_flags, L.pend_slots_per_xcd);
+      pend_slot_lds = pt_pool_acquire(L.pend_ws == nullptr ? nullptr : L.pend_flags, L.pend_slots_per_xcd, L.status, PT_FAIL_PEND_SLOT);
   }
   camera_to_lds(L, cam_lds);
   PHASE(9);
@@ -1088,6 +1089,9 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
 #pragma unroll
         for (uint32_t k = 0; k < 3u * PT_WIN_N; k++)
           w[k] = __hip_atomic_load(pix_win_now() + t * (3u * PT_WIN_N) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        win_normalize(w);
+        win_normalize(w + PT_WIN_N);
+        win_normalize(w + 2 * PT_WIN_N);
         mean.x = win_value(w) * inv_s;
         mean.y = win_value(w + PT_WIN_N) * inv_s;
         mean.z = win_value(w + 2 * PT_WIN_N) * inv_s;
@@ -1112,6 +1116,26 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
         ob[1] = inside ? tonemap(mean.y) : 0;
         ob[2] = inside ? tonemap(mean.z) : 0;
       }
+    }
+    else if (REFR)
+    {
+      /* one of several sample chunks of this tile, windowed form: the wave's windows (in its workspace region; its atomics have
+       * reached the L2, the loads bypass the L1), carry-normalised per pixel channel, added to the tile's record */
+      for (uint32_t pc = lane; ring_ok && pc < PT_TILE_PIXELS * 3; pc += 64) /* (no slot: no windows of its own; the NaN masks below say so) */
+      {
+        unsigned long long w[PT_WIN_N];
+#pragma unroll
+        for (uint32_t k = 0; k < PT_WIN_N; k++)
+          w[k] = __hip_atomic_load(pix_win_now() + pc * PT_WIN_N + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        win_normalize(w);
+        unsigned long long *const acc = L.acc_ws + ((size_t)slot * (PT_TILE_PIXELS * 3) + pc) * PT_WIN_N;
+#pragma unroll
+        for (uint32_t k = 0; k < PT_WIN_N; k++)
+          if (w[k] != 0ull)
+            atomicAdd(&acc[k], w[k]);
+      }
+      if (lane < 3 && pix_nan[lane] != 0)
+        atomicOr(&L.acc_ws[(size_t)L.tile_count * (PT_TILE_PIXELS * 3 * PT_WIN_N) + (size_t)slot * 3 + lane], pix_nan[lane]);
     }
     else
     {

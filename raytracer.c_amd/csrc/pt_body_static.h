@@ -70,12 +70,12 @@ __device__ __forceinline__ void render_tiles_static(const PtLaunch &L)
   if (STACKED)
   {
     if (threadIdx.x == 0)
-      pend_slot_lds = pt_pool_acquire(L.pend_flags, L.pend_slots_per_xcd);
+      pend_slot_lds = pt_pool_acquire(L.pend_flags, L.pend_slots_per_xcd, L.status, PT_FAIL_PEND_SLOT);
     __syncthreads();
   }
   const uint32_t pend_slot = STACKED ? pend_slot_lds : 0u;
-  /* (no slot: a sizing bug of the pool, never seen -- the launcher refuses to launch without a pool.  The tile then comes
-   * out NaN, bytes 255, rather than wrong: see the epilogue) */
+  /* (no slot: a sizing bug of the pool -- the launcher refuses to launch without a pool.  The tile then comes
+   * out NaN, bytes 255, rather than wrong (see the epilogue), and the status word says why: pt_pool_acquire) */
   const bool pend_ok = !STACKED || pend_slot != 0xFFFFFFFFu;
   const PendStack stack = {STACKED && pend_ok ? L.pend_ws + (size_t)pend_slot * L.pend_slot_doubles + threadIdx.x : nullptr,
                            STACKED && pend_ok ? (int)L.pend_entries : 0, PT_BLOCK, PT_PEND_FIELDS * PT_BLOCK};

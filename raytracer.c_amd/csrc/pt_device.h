@@ -95,13 +95,20 @@
 #define PT_PARK_WAVE_BYTES (65536u + 512u + PT_PARK_WIN_BYTES) /* 512 entries of 128 bytes (pt_body_queued.h, PT_PARK_Q: why 512), then the tile's 64 per-pixel RNG keys, then the windows */
 #endif
 #endif
-#define PT_PARK_SLOTS_PER_XCD 192u
+/* slots per XCD of the two pools (this one and the pending-ray pool below): derived per device from the occupancy of the kernels
+ * that take slots, with 25 % slack (pt_pool_slots_per_xcd).  The development build (librt_hip_dev.so) takes RT_HIP_POOL_SLOTS=n
+ * instead: with n = 1 acquisition FAILS for all but eight workgroups, which is how the failure path is tested. */
 #define PT_PARK_XCDS 8u
+/* device-side failures a launch can report through PtLaunch.status (rt_hip.h: RT_HIP_FAIL_*) */
+#define PT_FAIL_PEND_SLOT 1u
+#define PT_FAIL_PARK_SLOT 2u
 
 #define PT_HULL_PLUS 0x80000000u
 #define PT_HULL_MINUS 0x40000000u
 #define PT_HULL_MAX_TRIS 65536u /* pt_build_hull_flags is quadratic: larger triangle sets go without the flags */
 #define PT_ACC_WS_WORDS (PT_TILE_PIXELS * 3 + 3) /* chunked renders: u64 per tile in the workspace: 192 sums + 3 NaN masks */
+#define PT_WIN_N 6 /* words of a windowed pixel-channel sum (pt_scene_ctx.h, win_add): the M_REFRACTION forms of the pooled and parked-walk kernels */
+#define PT_ACC_WS_WORDS_WIN (PT_TILE_PIXELS * 3 * PT_WIN_N + 3) /* ... whose chunked renders keep 192 x PT_WIN_N words + 3 NaN masks per tile */
 
 #define PT_REFRACT_MAX_DEPTH 32 /* the pending-ray stacks of the two-child kernels hold max_depth + 2 entries (a pool in global memory
                                  * sized by the launch: 20 KB per entry and resident workgroup) */
@@ -111,10 +118,23 @@
 __host__ __device__
 #endif
 static inline bool pt_refr_pool_fits(int32_t samples, int32_t max_depth)
-{ /* pt_scene_ctx.h, win_add: samples x 2^(max_depth + 2) <= 2^30 */
-  return max_depth + 2 <= 30 && ((int64_t)samples << (max_depth + 2)) <= ((int64_t)1 << 30);
+{ /* pt_scene_ctx.h, win_add: a window word holds 2^31 pieces.  A path adds one piece per word when it ends, and a sample has at
+   * most 2^max_depth paths (every one of its refractive hits starts one more: a full binary tree's leaves) -- the rule keeps
+   * samples x 2^(max_depth + 1) <= 2^30, a factor four inside the capacity.  (`samples`: of one sample chunk; until round 5 the
+   * rule was 2^(max_depth + 2) on a launch's whole sample count.) */
+  return max_depth + 1 <= 30 && ((int64_t)samples << (max_depth + 1)) <= ((int64_t)1 << 30);
 }
-#define PT_PEND_SLOTS_PER_XCD 128u /* 32 CUs x at most 3-4 resident workgroups of the static-body kernels, with slack */
+/* the fewest sample chunks with which a launch of `samples` per pixel fits the rule; 0: none does (max_depth > 29) */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint32_t pt_refr_pool_chunks_needed(int32_t samples, int32_t max_depth)
+{
+  if (max_depth + 1 > 30 || samples < 1)
+    return 0u;
+  const int64_t per_chunk = ((int64_t)1 << 30) >> (max_depth + 1); /* >= 1 */
+  return (uint32_t)(((int64_t)samples + per_chunk - 1) / per_chunk);
+}
 
 #define PT_FLAG_DIFFUSE 2u
 #define PT_FLAG_MIRROR 4u
@@ -275,6 +295,7 @@ struct PtLaunch
   double acc_scale, acc_inv_scale; /* power-of-two fixed-point scale of the pixel sums */
   uint32_t tile_first, tile_stride, tile_count, tiles_x;
   uint32_t sample_chunks; /* workgroups per tile: each renders 1/sample_chunks of the samples */
+  uint32_t acc_windows;   /* sample_chunks > 1: acc_ws holds WINDOWED sums (tile_count x 192 x PT_WIN_N words, then the NaN masks): the M_REFRACTION forms */
   uint32_t integrator;    /* 0 trace_path (raytracer.c:482-554), 1 cast_ray (:556-641) */
   /* sign-test kernels: the scene's leading pairs of wall-sized spheres (radius >= 1000) are pruned among themselves before
    * the exact tests (pt_filter.h, BigPrune): how many pairs (0: off), the distance margin, the least distance and per sphere the least q32 of a wall that may prune */
@@ -294,6 +315,9 @@ struct PtLaunch
   uint32_t *pend_flags;
   uint32_t pend_slots_per_xcd, pend_entries;
   uint64_t pend_slot_doubles; /* = pend_entries x 10 fields x PT_PEND_COLUMNS */
+  /* the device's status word (rt_hip_launch_status): a workgroup that cannot get a pool slot ORs PT_FAIL_* into it, renders
+   * nothing and leaves its tile NaN -- the caller gets an error code, not a plausible image */
+  uint32_t *status;
   unsigned long long *acc_ws;        /* sample_chunks > 1: tile_count x 192 fixed-point sums, then tile_count x 3 NaN masks */
   float *tiles_rgb;
   uint8_t *tiles_rgb8;
@@ -304,13 +328,31 @@ struct PtLaunch
 #include <hip/hip_runtime.h>
 /* host-side launchers, defined next to the kernels in pt_kernel.hip */
 size_t pt_render_lds_bytes(const PtSceneView &scene);
-hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant);
+/* what a launch adds to the scene's content when the kernel is picked (pt_kernel.hip: pt_pick_table) */
+struct PtPickFacts
+{
+  uint32_t integrator;
+  int32_t samples, max_depth; /* samples: per sample chunk */
+  bool have_park_ws;          /* the parked-walk kernels' ring workspace exists on the device */
+  bool wide_pend_ok;          /* the pending-ray pool can be had at 4 x 512 stacks per slot */
+};
+int pt_pick_kernel(const PtSceneView &scene, const PtPickFacts &facts);          /* -> index into the family */
+hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int which);
+const char *pt_kernel_name_of(int which);
+int pt_kernel_count(void);
+bool pt_kernel_uses_pend_pool(int which);
+bool pt_kernel_is_queued(int which);
+bool pt_kernel_takes_chunks(int which);
+bool pt_kernel_is_windowed(int which); /* pixel sums are windowed (win_add): the chunk workspace has PT_ACC_WS_WORDS_WIN words per tile */
+uint32_t pt_kernel_pend_columns_of(int which);
+unsigned long long pt_kernel_launches(int which);
+uint32_t pt_pool_slots_per_xcd(bool park_pool); /* on the current device */
+#ifdef PT_DEV_KERNELS
+int pt_dev_variant();
+#endif
 hipError_t pt_launch_build_hull_flags(const double *tri_geom, const double *tri_normal, uint32_t n_tri, double tau,
                                       uint32_t *tri_object, hipStream_t stream);
 hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float *filt, float *bvh_nodes, hipStream_t stream);
-const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws = true);
-bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant); /* a kernel with a pending-ray stack */
-uint32_t pt_kernel_pend_columns(const PtSceneView &scene, uint32_t integrator, int variant);  /* stacks per slot of its pool */
 hipError_t pt_launch_selftest_xcc(unsigned int *counts, uint32_t n_workgroups, hipStream_t stream);
 hipError_t pt_launch_selftest(int op, const double *a, const double *b, double *out, size_t n, hipStream_t stream);
 hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,

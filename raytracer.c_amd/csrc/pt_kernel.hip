@@ -68,6 +68,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "pt_device.h"
 #include "rt_rng.h"
@@ -202,7 +203,9 @@ PT_KERNEL_G(pt_render_tiles_pool_mem_s_chk, __launch_bounds__(PT_BLOCK), true, f
   {                                                                                         \
     render_tiles_static<VARIANT, REFRACT, CHECKER, TRIS, FILT_LDS, 0, true>(L);             \
   }
+#ifdef PT_DEV_KERNELS
 PT_KERNEL_STATIC(pt_render_tiles_v0, 1, 0, false, true, true, false)
+#endif
 PT_KERNEL_STATIC(pt_render_tiles_refr, PT_MIN_WAVES_REFR, 1, true, true, false, true)
 PT_KERNEL_STATIC(pt_render_tiles_big_refr, PT_MIN_WAVES_REFR, 1, true, true, false, false)
 PT_KERNEL_STATIC(pt_render_tiles_tri_refr, PT_MIN_WAVES_REFR_TRI, 1, true, true, true, true)
@@ -251,8 +254,27 @@ extern "C" __global__ __launch_bounds__(PT_BLOCK) void pt_resolve_tiles(const Pt
   __shared__ uint8_t out_b[PT_TILE_PIXELS * 3 + 64];
   const uint32_t slot = blockIdx.x;
   const uint32_t tile = L.tile_first + slot * L.tile_stride;
-  finish_pixels(L, L.acc_ws + (size_t)slot * (PT_TILE_PIXELS * 3),
-                L.acc_ws + (size_t)L.tile_count * (PT_TILE_PIXELS * 3) + (size_t)slot * 3, tile, out_f, out_b);
+  if (L.acc_windows)
+  { /* the M_REFRACTION forms: windowed sums (win_add), merged chunk by chunk in carry-normalised form */
+    if (threadIdx.x < PT_TILE_PIXELS * 3)
+    {
+      const uint32_t t = threadIdx.x / 3u, c = threadIdx.x - 3u * t;
+      const bool inside = (tile % L.tiles_x) * PT_TILE + (t & 7u) < (uint32_t)L.width && (tile / L.tiles_x) * PT_TILE + (t >> 3) < (uint32_t)L.height;
+      unsigned long long w[PT_WIN_N];
+#pragma unroll
+      for (int k = 0; k < PT_WIN_N; k++)
+        w[k] = L.acc_ws[((size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x) * PT_WIN_N + k];
+      win_normalize(w);
+      double mean = win_value(w) * (1.0 / (double)L.samples);
+      const unsigned long long nan_mask = L.acc_ws[(size_t)L.tile_count * (PT_TILE_PIXELS * 3 * PT_WIN_N) + (size_t)slot * 3 + c];
+      mean = ((nan_mask >> t) & 1ull) ? __longlong_as_double(0x7FF8000000000000ll) : mean;
+      out_f[threadIdx.x] = inside ? (float)mean : 0.f;
+      out_b[threadIdx.x] = inside ? tonemap(mean) : 0;
+    }
+  }
+  else
+    finish_pixels(L, L.acc_ws + (size_t)slot * (PT_TILE_PIXELS * 3),
+                  L.acc_ws + (size_t)L.tile_count * (PT_TILE_PIXELS * 3) + (size_t)slot * 3, tile, out_f, out_b);
   __syncthreads();
   if (threadIdx.x < PT_TILE_PIXELS * 3)
     L.tiles_rgb[(size_t)slot * (PT_TILE_PIXELS * 3) + threadIdx.x] = out_f[threadIdx.x];
@@ -642,27 +664,24 @@ size_t pt_render_lds_bytes(const PtSceneView &sc)
   return doubles * sizeof(double);
 }
 
-/* The kernel family: one row per member.  K_TILES .. K_TRI_BIG_REFR and K_WHITTED .. K_WHITTED_TRI_BIG are laid out so that
- * "+ 1" = the filter table is not in LDS (_big), "+ 2" = the scene has triangles (_tri), "+ 4" / "+ 8" = M_CHECKERED / M_REFRACTION
- * materials: pt_pick_kernel forms those indices by arithmetic (the static_asserts below pin the layout). */
+/* The kernel family: one row per member. */
 enum PtKernelId
 {
   K_TILES = 0, K_BIG, K_TRI, K_TRI_BIG,
   K_CHK, K_BIG_CHK, K_TRI_CHK, K_TRI_BIG_CHK,
   K_REFR, K_BIG_REFR, K_TRI_REFR, K_TRI_BIG_REFR,
-  K_V0, K_WHITTED, K_WHITTED_BIG, K_WHITTED_TRI, K_WHITTED_TRI_BIG,
+  K_WHITTED, K_WHITTED_BIG, K_WHITTED_TRI, K_WHITTED_TRI_BIG,
   K_MEM, K_WHITTED_MEM,
   K_TRI_QUEUED, K_TRI_QUEUED_CHK, K_TRI_QUEUED_SPH,
   K_POOL_MEM, K_POOL_MEM_CHK, K_POOL_MEM_TRI, K_POOL_MEM_TRI_CHK, K_POOL_MEM_S, K_POOL_MEM_S_CHK,
   K_REFR_POOL, K_REFR_POOL_MEM, K_TRI_REFR_POOL,
   K_TRI_QUEUED_REFR, K_TRI_QUEUED_REFR_SPH, K_TRI_QUEUED_CHK_SPH,
   K_TRI_QUEUED_MEM, K_TRI_QUEUED_MEM_CHK,
+#ifdef PT_DEV_KERNELS
+  K_V0, /* the literal single-phase scan: development builds only (RT_HIP_KERNEL_VARIANT=0) */
+#endif
   K_COUNT
 };
-static_assert(K_CHK == K_TILES + 4 && K_REFR == K_TILES + 8 && K_TRI == K_TILES + 2 && K_BIG == K_TILES + 1 &&
-                  K_WHITTED_TRI == K_WHITTED + 2 && K_WHITTED_BIG == K_WHITTED + 1 && K_POOL_MEM_TRI == K_POOL_MEM + 2 &&
-                  K_POOL_MEM_CHK == K_POOL_MEM + 1 && K_POOL_MEM_S_CHK == K_POOL_MEM_S + 1,
-              "pt_pick_kernel's index arithmetic");
 typedef void (*PtKernelFn)(const PtLaunch);
 struct PtKernelInfo
 {
@@ -672,101 +691,252 @@ struct PtKernelInfo
   bool queued;       /* parked walks: a tile per WAVE (four work units per workgroup), filter pairs + traversal stacks in dynamic LDS */
   bool stages_none;  /* geometry and tables from memory: no staged scene in LDS, whatever the scene's size */
   bool wide_pend;    /* 4 x 512 stacks per pool slot (path ids that travel through the ring) */
+  bool chunks;       /* takes sample_chunks > 1 (integer partial sums merged by pt_resolve_tiles) */
+  bool windowed;     /* ... as windowed sums (win_add): PT_ACC_WS_WORDS_WIN words per tile of the chunk workspace */
 };
-#define PT_K(fn, pend, queued, none, wide) {#fn, fn, pend, queued, none, wide}
+#define PT_K(fn, pend, queued, none, wide, chunks) {#fn, fn, pend, queued, none, wide, chunks, false}
+#define PT_KW(fn, pend, queued, none, wide) {#fn, fn, pend, queued, none, wide, true, true}
 static const PtKernelInfo pt_kernels[K_COUNT] = {
-    PT_K(pt_render_tiles, false, false, false, false),          PT_K(pt_render_tiles_big, false, false, false, false),
-    PT_K(pt_render_tiles_tri, false, false, false, false),      PT_K(pt_render_tiles_tri_big, false, false, false, false),
-    PT_K(pt_render_tiles_chk, false, false, false, false),      PT_K(pt_render_tiles_big_chk, false, false, false, false),
-    PT_K(pt_render_tiles_tri_chk, false, false, false, false),  PT_K(pt_render_tiles_tri_big_chk, false, false, false, false),
-    PT_K(pt_render_tiles_refr, true, false, false, false),      PT_K(pt_render_tiles_big_refr, true, false, false, false),
-    PT_K(pt_render_tiles_tri_refr, true, false, false, false),  PT_K(pt_render_tiles_tri_big_refr, true, false, false, false),
-    PT_K(pt_render_tiles_v0, false, false, false, false),
-    PT_K(pt_whitted_tiles, false, false, false, false),         PT_K(pt_whitted_tiles_big, false, false, false, false),
-    PT_K(pt_whitted_tiles_tri, false, false, false, false),     PT_K(pt_whitted_tiles_tri_big, false, false, false, false),
-    PT_K(pt_render_tiles_mem, true, false, false, false),       PT_K(pt_whitted_tiles_mem, true, false, false, false),
-    PT_K(pt_render_tiles_tri_queued, false, true, false, false), PT_K(pt_render_tiles_tri_queued_chk, false, true, false, false),
-    PT_K(pt_render_tiles_tri_queued_sph, false, true, false, false),
-    PT_K(pt_render_tiles_pool_mem, false, false, true, false),  PT_K(pt_render_tiles_pool_mem_chk, false, false, true, false),
-    PT_K(pt_render_tiles_pool_mem_tri, false, false, true, false), PT_K(pt_render_tiles_pool_mem_tri_chk, false, false, true, false),
-    PT_K(pt_render_tiles_pool_mem_s, false, false, true, false), PT_K(pt_render_tiles_pool_mem_s_chk, false, false, true, false),
-    PT_K(pt_render_tiles_refr_pool, true, false, false, false), PT_K(pt_render_tiles_refr_pool_mem, true, false, true, false),
-    PT_K(pt_render_tiles_tri_refr_pool, true, false, false, false),
-    PT_K(pt_render_tiles_tri_queued_refr, true, true, false, true), PT_K(pt_render_tiles_tri_queued_refr_sph, true, true, false, true),
-    PT_K(pt_render_tiles_tri_queued_chk_sph, false, true, false, false),
-    PT_K(pt_render_tiles_tri_queued_mem, false, true, true, false), PT_K(pt_render_tiles_tri_queued_mem_chk, false, true, true, false)};
+    PT_K(pt_render_tiles, false, false, false, false, true),          PT_K(pt_render_tiles_big, false, false, false, false, true),
+    PT_K(pt_render_tiles_tri, false, false, false, false, true),      PT_K(pt_render_tiles_tri_big, false, false, false, false, true),
+    PT_K(pt_render_tiles_chk, false, false, false, false, true),      PT_K(pt_render_tiles_big_chk, false, false, false, false, true),
+    PT_K(pt_render_tiles_tri_chk, false, false, false, false, true),  PT_K(pt_render_tiles_tri_big_chk, false, false, false, false, true),
+    PT_K(pt_render_tiles_refr, true, false, false, false, false),     PT_K(pt_render_tiles_big_refr, true, false, false, false, false),
+    PT_K(pt_render_tiles_tri_refr, true, false, false, false, false), PT_K(pt_render_tiles_tri_big_refr, true, false, false, false, false),
+    PT_K(pt_whitted_tiles, false, false, false, false, false),        PT_K(pt_whitted_tiles_big, false, false, false, false, false),
+    PT_K(pt_whitted_tiles_tri, false, false, false, false, false),    PT_K(pt_whitted_tiles_tri_big, false, false, false, false, false),
+    PT_K(pt_render_tiles_mem, true, false, false, false, false),      PT_K(pt_whitted_tiles_mem, true, false, false, false, false),
+    PT_K(pt_render_tiles_tri_queued, false, true, false, false, true), PT_K(pt_render_tiles_tri_queued_chk, false, true, false, false, true),
+    PT_K(pt_render_tiles_tri_queued_sph, false, true, false, false, true),
+    PT_K(pt_render_tiles_pool_mem, false, false, true, false, true),  PT_K(pt_render_tiles_pool_mem_chk, false, false, true, false, true),
+    PT_K(pt_render_tiles_pool_mem_tri, false, false, true, false, true), PT_K(pt_render_tiles_pool_mem_tri_chk, false, false, true, false, true),
+    PT_K(pt_render_tiles_pool_mem_s, false, false, true, false, true), PT_K(pt_render_tiles_pool_mem_s_chk, false, false, true, false, true),
+    PT_KW(pt_render_tiles_refr_pool, true, false, false, false), PT_KW(pt_render_tiles_refr_pool_mem, true, false, true, false),
+    PT_KW(pt_render_tiles_tri_refr_pool, true, false, false, false),
+    PT_KW(pt_render_tiles_tri_queued_refr, true, true, false, true), PT_KW(pt_render_tiles_tri_queued_refr_sph, true, true, false, true),
+    PT_K(pt_render_tiles_tri_queued_chk_sph, false, true, false, false, true),
+    PT_K(pt_render_tiles_tri_queued_mem, false, true, true, false, true), PT_K(pt_render_tiles_tri_queued_mem_chk, false, true, true, false, true),
+#ifdef PT_DEV_KERNELS
+    PT_K(pt_render_tiles_v0, false, false, false, false, false),
+#endif
+};
 #undef PT_K
+#undef PT_KW
 
-/* which member of the kernel family a launch of this scene takes (the selection of
- * pt_launch_render, also reported by rt_hip_kernel_name for profiles and bench lines) */
-/* have_park_ws = false: the parked-walk kernels' workspace is missing (its allocation failed): the lane-waiting kernels */
-static int pt_pick_kernel(const PtSceneView &scene, uint32_t integrator, int variant, const char **name, bool have_park_ws = true)
+/* ---- which member a launch takes: ONE table ------------------------------------------------------------------------------
+ * A launch is classified by the six things the family is split by, and the first row of pt_pick_table that matches names the
+ * kernel.  The fallbacks (no ring workspace, windowed sums that do not fit, a pending-ray pool that could not be had at
+ * 4 x 512 stacks, scenes beyond fp32's comfortable range) are rows like any other.  A row field of ANY matches everything.
+ *
+ *   integ   PATH trace_path (raytracer.c:482-554) | CAST cast_ray (:556-641)
+ *   stage   STAGED   sphere geometry + materials fit the LDS staging budget and are staged
+ *           STREAM   they would fit, but the scene is a sphere scene of more than ~85 spheres: faster streamed (pt_stream_sized)
+ *           LARGE    beyond the staging budget (pt_geom_in_lds false)
+ *   mesh    NONE | FLAT triangles scanned through the flat filter staged in LDS (pt_filter_in_lds) | HIER triangles through the
+ *           hierarchy | HIERBIG the same with more than PT_FILT_LDS_MAX triangles (what a scene beyond the staging budget needs
+ *           for parked walks: HIERBIG rows also match where HIER is asked for -- see pt_row_matches)
+ *   mat     PLAIN | CHK any M_CHECKERED | REFR any M_REFRACTION (wins over CHK: the _refr bodies carry the checker code) |
+ *           for CAST: GLASS2 a material with M_REFLECTION and M_REFRACTION (two children per hit), else PLAIN
+ *   range   NORMAL | WIDE a centre or radius beyond 1e17 (NaN-safe compare filter, no sign tests, no parked walks)
+ *   park    YES the parked-walk body may run: its workspace exists and references fit 24-bit stack entries | NO
+ *   round   YES the mesh's bounding sphere shows a ray no more than its box (probe = the sphere alone) | NO
+ *   fit     YES the windowed sums of the pooled refraction kernels hold this launch (pt_refr_pool_fits per chunk) and, for the
+ *           parked-walk refraction kernels, the pending-ray pool has 4 x 512 stacks per slot | NO
+ */
+enum { ANY = -1 };
+enum PtInteg { PATH = 0, CAST = 1 };
+enum PtStage { STAGED = 0, STREAM = 1, LARGE = 2 };
+enum PtMesh { NONE = 0, FLAT = 1, HIER = 2, HIERBIG = 3 };
+enum PtMat { PLAIN = 0, CHK = 1, REFR = 2, GLASS2 = 3 };
+enum PtYesNo { NO = 0, YES = 1 };
+enum PtRange { NORMAL = 0, WIDE = 1 };
+struct PtPickKey
 {
-  const bool tris = scene.n_triangles != 0;
-  const bool big = !pt_filter_in_lds(scene);
-  const bool refr = scene.any_refract != 0, chk = scene.any_checker != 0;
-  const bool cast_ray = integrator == 1;
-  /* the parked-walk body's conditions: not the A/B variant 2, no scene beyond fp32's comfortable range (its filter needs the
-   * NaN-safe compares), references that fit the walk's 24-bit stack entries */
-  const bool can_park = variant != 2 && !scene.wide_range && scene.n_bvh_nodes < (1u << 23) && scene.n_triangles < (1u << (23 - PT_BVH_COUNT_BITS));
-  int which = cast_ray ? K_WHITTED + (tris ? 2 : 0) + (big ? 1 : 0) : (refr ? K_REFR : (chk ? K_CHK : K_TILES)) + (tris ? 2 : 0) + (big ? 1 : 0);
-  /* too large to stage, or cast_ray with two-child materials: the two general kernels */
-  const bool in_memory = !pt_geom_in_lds(scene) || (cast_ray && scene.any_mirror_glass);
-  if (in_memory)
+  int integ, stage, mesh, mat, range, park, round, fit;
+};
+struct PtPickRow
+{
+  int integ, stage, mesh, mat, range, park, round, fit;
+  int kernel;
+};
+static const PtPickRow pt_pick_table[] = {
+    /* integ stage   mesh     mat     range   park round fit   kernel */
+    /* ---- cast_ray: the static body; two-child materials or a scene beyond the staging budget: the general in-memory kernel */
+    {CAST, LARGE,  ANY,     ANY,    ANY,    ANY, ANY, ANY, K_WHITTED_MEM},
+    {CAST, ANY,    ANY,     GLASS2, ANY,    ANY, ANY, ANY, K_WHITTED_MEM},
+    {CAST, ANY,    NONE,    ANY,    NORMAL, ANY, ANY, ANY, K_WHITTED},
+    {CAST, ANY,    NONE,    ANY,    WIDE,   ANY, ANY, ANY, K_WHITTED_BIG},
+    {CAST, ANY,    FLAT,    ANY,    ANY,    ANY, ANY, ANY, K_WHITTED_TRI},
+    {CAST, ANY,    HIER,    ANY,    ANY,    ANY, ANY, ANY, K_WHITTED_TRI_BIG},
+    /* ---- trace_path, scenes beyond the staging budget */
+    {PATH, LARGE,  NONE,    REFR,   NORMAL, ANY, ANY, YES, K_REFR_POOL_MEM},
+    {PATH, LARGE,  ANY,     REFR,   ANY,    ANY, ANY, ANY, K_MEM},              /* ... with a mesh, out of range, or sums that do not fit: the static body */
+    {PATH, LARGE,  HIERBIG, PLAIN,  NORMAL, YES, ANY, ANY, K_TRI_QUEUED_MEM},
+    {PATH, LARGE,  HIERBIG, CHK,    NORMAL, YES, ANY, ANY, K_TRI_QUEUED_MEM_CHK},
+    {PATH, LARGE,  NONE,    PLAIN,  NORMAL, ANY, ANY, ANY, K_POOL_MEM_S},
+    {PATH, LARGE,  NONE,    CHK,    NORMAL, ANY, ANY, ANY, K_POOL_MEM_S_CHK},
+    {PATH, LARGE,  NONE,    PLAIN,  WIDE,   ANY, ANY, ANY, K_POOL_MEM},
+    {PATH, LARGE,  NONE,    CHK,    WIDE,   ANY, ANY, ANY, K_POOL_MEM_CHK},
+    {PATH, LARGE,  ANY,     PLAIN,  ANY,    ANY, ANY, ANY, K_POOL_MEM_TRI},     /* a small mesh, no ring workspace, or out of range */
+    {PATH, LARGE,  ANY,     CHK,    ANY,    ANY, ANY, ANY, K_POOL_MEM_TRI_CHK},
+    /* ---- trace_path, sphere scenes that fit but stream by preference */
+    {PATH, STREAM, NONE,    PLAIN,  NORMAL, ANY, ANY, ANY, K_POOL_MEM_S},
+    {PATH, STREAM, NONE,    CHK,    NORMAL, ANY, ANY, ANY, K_POOL_MEM_S_CHK},
+    {PATH, STREAM, NONE,    REFR,   NORMAL, ANY, ANY, YES, K_REFR_POOL_MEM},
+    {PATH, STREAM, NONE,    REFR,   NORMAL, ANY, ANY, NO,  K_REFR},
+    /* ---- trace_path, staged scenes: spheres only */
+    {PATH, STAGED, NONE,    PLAIN,  NORMAL, ANY, ANY, ANY, K_TILES},            /* the headline: BASELINE configs 1, 2, 4 */
+    {PATH, STAGED, NONE,    CHK,    NORMAL, ANY, ANY, ANY, K_CHK},
+    {PATH, STAGED, NONE,    REFR,   NORMAL, ANY, ANY, YES, K_REFR_POOL},
+    {PATH, STAGED, NONE,    REFR,   NORMAL, ANY, ANY, NO,  K_REFR},
+    {PATH, STAGED, NONE,    PLAIN,  WIDE,   ANY, ANY, ANY, K_BIG},
+    {PATH, STAGED, NONE,    CHK,    WIDE,   ANY, ANY, ANY, K_BIG_CHK},
+    {PATH, STAGED, NONE,    REFR,   WIDE,   ANY, ANY, ANY, K_BIG_REFR},
+    /* ---- ... with a small mesh (flat filter + fp32 pre-test): BASELINE config 3 */
+    {PATH, STAGED, FLAT,    PLAIN,  ANY,    ANY, ANY, ANY, K_TRI},
+    {PATH, STAGED, FLAT,    CHK,    ANY,    ANY, ANY, ANY, K_TRI_CHK},
+    {PATH, STAGED, FLAT,    REFR,   ANY,    ANY, ANY, YES, K_TRI_REFR_POOL},
+    {PATH, STAGED, FLAT,    REFR,   ANY,    ANY, ANY, NO,  K_TRI_REFR},
+    /* ---- ... with a mesh through the hierarchy: parked walks (BASELINE config 5), else the lane-waiting kernels */
+    {PATH, STAGED, HIER,    PLAIN,  NORMAL, YES, YES, ANY, K_TRI_QUEUED_SPH},
+    {PATH, STAGED, HIER,    PLAIN,  NORMAL, YES, NO,  ANY, K_TRI_QUEUED},
+    {PATH, STAGED, HIER,    CHK,    NORMAL, YES, YES, ANY, K_TRI_QUEUED_CHK_SPH},
+    {PATH, STAGED, HIER,    CHK,    NORMAL, YES, NO,  ANY, K_TRI_QUEUED_CHK},
+    {PATH, STAGED, HIER,    REFR,   NORMAL, YES, YES, YES, K_TRI_QUEUED_REFR_SPH},
+    {PATH, STAGED, HIER,    REFR,   NORMAL, YES, NO,  YES, K_TRI_QUEUED_REFR},
+    {PATH, STAGED, HIER,    PLAIN,  ANY,    ANY, ANY, ANY, K_TRI_BIG},          /* no ring workspace, or out of range */
+    {PATH, STAGED, HIER,    CHK,    ANY,    ANY, ANY, ANY, K_TRI_BIG_CHK},
+    {PATH, STAGED, HIER,    REFR,   ANY,    ANY, ANY, ANY, K_TRI_BIG_REFR},     /* ... or sums / pool that do not fit */
+};
+
+static bool pt_row_matches(const PtPickRow &r, const PtPickKey &k)
+{
+  auto ok = [](int row, int key) { return row == ANY || row == key; };
+  /* mesh: a row that asks for HIER takes HIERBIG scenes too (a big mesh is a hierarchy mesh); one that asks for HIERBIG only those */
+  const bool mesh_ok = r.mesh == ANY || r.mesh == k.mesh || (r.mesh == HIER && k.mesh == HIERBIG);
+  return ok(r.integ, k.integ) && ok(r.stage, k.stage) && mesh_ok && ok(r.mat, k.mat) && ok(r.range, k.range) && ok(r.park, k.park) &&
+         ok(r.round, k.round) && ok(r.fit, k.fit);
+}
+
+PtPickKey pt_classify(const PtSceneView &scene, const PtPickFacts &f)
+{
+  PtPickKey k;
+  const bool cast = f.integrator == 1u;
+  k.integ = cast ? CAST : PATH;
+  k.stage = !pt_geom_in_lds(scene) ? LARGE : ((!cast && pt_stream_sized(scene)) ? STREAM : STAGED);
+  k.range = scene.wide_range ? WIDE : NORMAL;
+  if (scene.n_triangles == 0u)
+    k.mesh = NONE;
+  else if (pt_filter_in_lds(scene))
+    k.mesh = FLAT;
+  else
+    k.mesh = (scene.n_triangles > PT_FILT_LDS_MAX && scene.n_bvh_nodes != 0u) ? HIERBIG : HIER;
+  if (cast)
+    k.mat = scene.any_mirror_glass ? GLASS2 : PLAIN;
+  else
+    k.mat = scene.any_refract ? REFR : (scene.any_checker ? CHK : PLAIN);
+  /* the parked-walk body's conditions: a ring workspace, references that fit the walk's 24-bit stack entries (range: the rows) */
+  k.park = (f.have_park_ws && scene.n_bvh_nodes < (1u << 23) && scene.n_triangles < (1u << (23 - PT_BVH_COUNT_BITS))) ? YES : NO;
+  k.round = scene.mesh_round ? YES : NO;
+  /* the pooled refraction kernels' windowed sums hold 2^31 pieces per word: a sample of a refractive scene has at most
+   * 2^(max_depth + 2) terms (a full binary tree of children), so a launch needs samples x 2^(max_depth + 2) <= 2^30 */
+  k.fit = (pt_refr_pool_fits(f.samples, f.max_depth) && (k.mesh < HIER || f.wide_pend_ok)) ? YES : NO;
+  return k;
+}
+
+#ifdef PT_DEV_KERNELS
+/* development builds (-DPT_DEV_KERNELS: `make variant NAME=dev DEFS=-DPT_DEV_KERNELS`, and the PT_DIAG twin): RT_HIP_KERNEL_VARIANT,
+ * read once per process, rewrites the key so that a scene takes another arm of the table (A/B), or names the literal kernel:
+ *   0 pt_render_tiles_v0 (the plainest statement of the algorithm)   2 hierarchy scenes on the lane-waiting kernels (park = NO)
+ *   3 scenes beyond the staging budget on the static in-memory kernel  4 ... on the compare-form pooled kernel
+ *   5 sphere scenes that would stream by preference are staged          7 refractive scenes on the static kernels (fit = NO) */
+int pt_dev_variant()
+{
+  static const int v = [] {
+    const char *e = getenv("RT_HIP_KERNEL_VARIANT");
+    return (e && e[0] >= '0' && e[0] <= '7' && e[0] != '1' && e[0] != '6') ? e[0] - '0' : 1;
+  }();
+  return v;
+}
+static int pt_dev_pick(PtPickKey &k)
+{
+  const int v = pt_dev_variant();
+  if (v == 0 && k.integ == PATH && k.stage != LARGE && k.mat != REFR)
+    return K_V0;
+  if (v == 2)
+    k.park = NO;
+  if (v == 3 && k.integ == PATH && k.stage == LARGE)
+    return K_MEM;
+  if (v == 4 && k.integ == PATH && k.stage == LARGE && k.mesh == NONE && k.mat != REFR)
+    return k.mat == CHK ? K_POOL_MEM_CHK : K_POOL_MEM;
+  if (v == 5 && k.stage == STREAM)
+    k.stage = STAGED;
+  if (v == 7)
+    k.fit = NO;
+  return -1;
+}
+#endif
+
+int pt_pick_kernel(const PtSceneView &scene, const PtPickFacts &f)
+{
+  PtPickKey k = pt_classify(scene, f);
+#ifdef PT_DEV_KERNELS
   {
-    which = cast_ray ? K_WHITTED_MEM : K_MEM;
-    /* trace_path without M_REFRACTION: the pooled body with geometry from memory (variant 3: the static kernel, for A/B) */
-    if (!cast_ray && !refr && variant != 3)
-      which = (!tris && !scene.wide_range && variant != 4) ? K_POOL_MEM_S + (chk ? 1 : 0)
-                                                           : K_POOL_MEM + (tris ? 2 : 0) + (chk ? 1 : 0); /* (variant 4: the compare-form kernel, for A/B) */
-    /* ... and with a mesh of more than 256 triangles: the parked-walk body with the spheres from memory (variants 3, 4: the
-     * kernels above, for A/B; a small mesh next to many spheres has no leaf-order pre-test table: it keeps them too) */
-    const bool big_mesh = scene.n_triangles > PT_FILT_LDS_MAX && scene.n_bvh_nodes != 0u;
-    if (!cast_ray && !refr && big_mesh && can_park && have_park_ws && variant != 3 && variant != 4)
-      which = chk ? K_TRI_QUEUED_MEM_CHK : K_TRI_QUEUED_MEM;
+    const int dev = pt_dev_pick(k);
+    if (dev >= 0)
+      return dev;
   }
-  else if (variant == 0 && !refr && !cast_ray)
-    which = K_V0;
-  else if (!cast_ray && variant != 5 && pt_prefer_streaming(scene))
-    which = K_POOL_MEM_S + (chk ? 1 : 0); /* a sphere scene that would fit the staging budget but is faster streamed (pt_device.h; variant 5: staged, for A/B) */
-  else if ((which == K_TRI_BIG || which == K_TRI_BIG_CHK) && can_park)
-    which = which == K_TRI_BIG ? (scene.mesh_round ? K_TRI_QUEUED_SPH : K_TRI_QUEUED)
-                               : (scene.mesh_round ? K_TRI_QUEUED_CHK_SPH : K_TRI_QUEUED_CHK); /* hierarchy scenes: parked walks (otherwise the lane-waiting pooled kernels) */
-  /* refractive sphere scenes that are streamed (beyond the staging budget, or beyond ~85 spheres by preference: pt_stream_sized) */
-  if (!cast_ray && refr && !tris && !scene.wide_range && variant != 7 && variant != 3 && (!pt_geom_in_lds(scene) || (variant != 5 && pt_stream_sized(scene))))
-    which = K_REFR_POOL_MEM;
-  /* small staged scenes with M_REFRACTION: the pooled body (variant 7: the static one, for A/B; the launcher also falls back
-   * to it for launches whose sample x depth product could overflow the windowed sums) */
-  if (which == K_REFR && variant != 7)
-    which = K_REFR_POOL;
-  if (which == K_TRI_REFR && variant != 7)
-    which = K_TRI_REFR_POOL; /* ... with a small mesh */
-  /* hierarchy scenes with M_REFRACTION: the parked-walk body's refraction form, under the conditions of its other forms */
-  if (which == K_TRI_BIG_REFR && variant != 7 && can_park && have_park_ws)
-    which = scene.mesh_round ? K_TRI_QUEUED_REFR_SPH : K_TRI_QUEUED_REFR;
-  if (!have_park_ws && pt_kernels[which].queued) /* no ring workspace: the lane-waiting kernels need none (the _mem forms are only picked with one) */
-    which = (which == K_TRI_QUEUED_CHK || which == K_TRI_QUEUED_CHK_SPH) ? K_TRI_BIG_CHK : K_TRI_BIG;
-  if (name)
-    *name = pt_kernels[which].name;
-  return which;
+#endif
+  for (const PtPickRow &r : pt_pick_table)
+    if (pt_row_matches(r, k))
+      return r.kernel;
+  return -1; /* unreachable: the table's last rows of every (integ, stage, mesh) block match ANY of the rest -- pinned by tests/test_pick_table.py */
 }
 
-bool pt_kernel_needs_pend_pool(const PtSceneView &scene, uint32_t integrator, int variant)
-{
-  return pt_kernels[pt_pick_kernel(scene, integrator, variant, nullptr)].pend_pool;
-}
+const char *pt_kernel_name_of(int which) { return which >= 0 && which < K_COUNT ? pt_kernels[which].name : ""; }
+int pt_kernel_count(void) { return K_COUNT; }
+bool pt_kernel_uses_pend_pool(int which) { return pt_kernels[which].pend_pool; }
+bool pt_kernel_is_queued(int which) { return pt_kernels[which].queued; }
+bool pt_kernel_takes_chunks(int which) { return pt_kernels[which].chunks; }
+bool pt_kernel_is_windowed(int which) { return pt_kernels[which].windowed; }
+uint32_t pt_kernel_pend_columns_of(int which) { return pt_kernels[which].wide_pend ? 4u * 512u : PT_PEND_COLUMNS; }
 
-/* stacks per slot of the pending-ray pool: the parked-walk refraction kernels keep up to 512 path ids per wave */
-uint32_t pt_kernel_pend_columns(const PtSceneView &scene, uint32_t integrator, int variant)
-{
-  return pt_kernels[pt_pick_kernel(scene, integrator, variant, nullptr)].wide_pend ? 4u * 512u : PT_PEND_COLUMNS;
-}
+/* launches per family member in this process (rt_hip_kernel_launches): what a test run actually exercised */
+static std::atomic<unsigned long long> pt_launch_counts[K_COUNT];
+unsigned long long pt_kernel_launches(int which) { return which >= 0 && which < K_COUNT ? pt_launch_counts[which].load() : 0ull; }
 
-const char *pt_kernel_name(const PtSceneView &scene, uint32_t integrator, int variant, bool have_park_ws)
+/* slots per XCD a pool must offer so that every resident workgroup of the kernels that take one finds a slot: CUs per XCD x
+ * the most workgroups of any such kernel a CU holds (occupancy without dynamic LDS: an upper bound), + 25 %.  Until round 5
+ * these were constants sized for 32 CUs x 4 workgroups with no slack (round-4 advisor finding). */
+uint32_t pt_pool_slots_per_xcd(bool park_pool)
 {
-  const char *name = nullptr;
-  (void)pt_pick_kernel(scene, integrator, variant, &name, have_park_ws);
-  return name;
+#ifdef PT_DEV_KERNELS
+  { /* development builds: RT_HIP_POOL_SLOTS=n fixes both pools at n slots per XCD (n = 1: acquisition fails for all but eight workgroups) */
+    const char *e = getenv("RT_HIP_POOL_SLOTS");
+    const unsigned long n = e ? strtoul(e, nullptr, 10) : 0ul;
+    if (n >= 1ul && n <= 4096ul)
+      return (uint32_t)n;
+  }
+#endif
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess)
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int most = 1;
+  for (int k = 0; k < K_COUNT; k++)
+  {
+    if (!(park_pool ? pt_kernels[k].queued : pt_kernels[k].pend_pool))
+      continue;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(pt_kernels[k].fn), PT_BLOCK, 0) == hipSuccess)
+      most = max(most, n);
+    else
+      (void)hipGetLastError();
+  }
+  if (most > 8)
+    most = 8; /* 2,048 threads per CU */
+  const uint32_t per_xcd = ((uint32_t)cus + PT_PARK_XCDS - 1u) / PT_PARK_XCDS;
+  const uint32_t want = per_xcd * (uint32_t)most;
+  return ((want + want / 4u) + 31u) & ~31u;
 }
 
 /* The camera-dependent tables of a scene for one near_R (two ~2 us kernels): the packed-fp32
@@ -806,37 +976,33 @@ hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float
   return hipGetLastError();
 }
 
-hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int variant)
+hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int which)
 {
+  if (which < 0 || which >= K_COUNT)
+    return hipErrorInvalidValue;
+  size_t extra_lds = 0;
+#ifdef PT_DEV_KERNELS
   /* development knob: RT_HIP_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup, to measure how a
    * kernel responds to fewer resident workgroups per CU */
-  static const size_t extra_lds = [] {
+  static const size_t extra_lds_env = [] {
     const char *e = getenv("RT_HIP_EXTRA_LDS");
     return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)0;
   }();
+  extra_lds = extra_lds_env;
+#endif
   size_t lds_bytes = pt_render_lds_bytes(launch.scene) + extra_lds;
-  int which = pt_pick_kernel(launch.scene, launch.integrator, variant, nullptr,
-                             launch.park_ws != nullptr && launch.park_slots_per_xcd != 0u);
-  /* the pooled refraction kernels' windowed sums hold 2^31 pieces per word: a sample of a refractive scene has at most
-   * 2^(max_depth + 2) terms (a full binary tree of children), so keep samples x 2^(max_depth + 2) <= 2^30 -- any other launch
-   * (4,097 spp at depth 16, say) takes the static kernel, whose fp64 sums have no such limit */
-  const bool windows_fit = pt_refr_pool_fits(launch.samples, launch.max_depth);
-  if (which == K_REFR_POOL && !windows_fit)
-    which = K_REFR;
-  if (which == K_REFR_POOL_MEM && !windows_fit)
-    which = pt_geom_in_lds(launch.scene) ? K_REFR : K_MEM;
-  if (which == K_TRI_REFR_POOL && !windows_fit)
-    which = K_TRI_REFR;
-  if (pt_kernels[which].wide_pend &&
-      (!windows_fit || launch.pend_slot_doubles < (uint64_t)launch.pend_entries * PT_PEND_FIELDS_HOST * 4u * 512u))
-    which = K_TRI_BIG_REFR; /* (... or when the pool was not sized for 4 x 512 stacks per slot) */
   const PtKernelInfo &k = pt_kernels[which];
   const PtKernelFn kernel = k.fn;
   if (k.stages_none)
     lds_bytes = extra_lds; /* the in-memory pooled kernels stage nothing, whatever the scene's size */
-  if (k.pend_pool && (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u))
-    return hipErrorInvalidValue; /* a kernel with a pending-ray stack needs its pool (rt_hip_shim.hip: pend_pool_for) */
+  if (k.pend_pool && (launch.pend_ws == nullptr || launch.pend_entries < (uint32_t)launch.max_depth + 2u ||
+                      launch.pend_slot_doubles < (uint64_t)launch.pend_entries * PT_PEND_FIELDS_HOST * pt_kernel_pend_columns_of(which)))
+    return hipErrorInvalidValue; /* a kernel with a pending-ray stack needs its pool, wide enough (rt_hip_shim.hip: pend_pool_for) */
   const bool queued = k.queued;
+  if (queued && (launch.park_ws == nullptr || launch.park_slots_per_xcd == 0u))
+    return hipErrorInvalidValue; /* the parked-walk kernels never run without their workspace (pt_pick_kernel: park) */
+  if (launch.sample_chunks > 1 && !k.chunks)
+    return hipErrorInvalidValue;
   if (queued) /* the spheres' filter pairs (staged forms), then per-lane traversal stacks (24-bit entries) sized by the tree, after the staged scene */
     lds_bytes += (k.stages_none ? (size_t)0 : (size_t)pt_filt_pair_slots(launch.scene.n_spheres) * 8u) +
                  (((size_t)max(launch.scene.bvh_depth, 1u) * PT_BLOCK * 3u + 15u) & ~(size_t)15u);
@@ -850,7 +1016,9 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
   }
   if (launch.sample_chunks > 1)
   {
-    hipError_t e = hipMemsetAsync(launch.acc_ws, 0, (size_t)launch.tile_count * PT_ACC_WS_WORDS * sizeof(unsigned long long), stream);
+    if ((launch.acc_windows != 0u) != k.windowed || launch.acc_ws == nullptr)
+      return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(launch.acc_ws, 0, (size_t)launch.tile_count * (k.windowed ? PT_ACC_WS_WORDS_WIN : PT_ACC_WS_WORDS) * sizeof(unsigned long long), stream);
     if (e != hipSuccess)
       return e;
   }
@@ -860,7 +1028,10 @@ hipError_t pt_launch_render(const PtLaunch &launch, hipStream_t stream, int vari
                      stream, launch);
   if (launch.sample_chunks > 1)
     hipLaunchKernelGGL(pt_resolve_tiles, dim3(launch.tile_count), dim3(PT_BLOCK), 0, stream, launch);
-  return hipGetLastError();
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess)
+    pt_launch_counts[which].fetch_add(1ull);
+  return e;
 }
 
 hipError_t pt_launch_selftest_intersect(int kind, const double *rays, const double *prims, const double *entry_src,

@@ -194,11 +194,11 @@ struct PendStack
  * (at most three) 32-bit pieces that fall into consecutive words, and each piece is added with an integer LDS atomic.
  * Integer addition commutes and associates, so the sums do not depend on the order or grouping of terms (any lane / wave /
  * tile / GPU assignment gives the same words), there is no rounding at all above 2^PT_WIN_E0, and a word overflows only
- * after 2^31 pieces (the launcher keeps samples x 2^(max_depth + 2) below 2^30).  Range: 2^-64 (bits below are dropped: 5e-20
+ * after 2^31 pieces (pt_refr_pool_fits keeps a sample chunk's samples x 2^(max_depth + 1) below 2^30; chunks are merged in
+ * carry-normalised form, win_normalize, whose words are below 2^32 each).  Range: 2^-64 (bits below are dropped: 5e-20
  * absolute per term) to 2^128, all a float32 pixel can hold; a term at or above that flags the pixel like a NaN.  (Six words: a
  * seventh would cost the kernel its fourth workgroup per CU.) */
-#define PT_WIN_N 6
-#define PT_WIN_E0 (-64)
+#define PT_WIN_E0 (-64) /* (PT_WIN_N: pt_device.h) */
 __device__ __forceinline__ bool win_add(unsigned long long *w, double x)
 { /* -> false: x is not finite or too large (the caller flags the pixel) */
   const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
@@ -225,8 +225,23 @@ __device__ __forceinline__ bool win_add(unsigned long long *w, double x)
   if (p2) atomicAdd(&w[k0 + 2], (unsigned long long)(sgn * (long long)p2));
   return true;
 }
-/* the sum: words combined from the top (each conversion and product is exact up to 2^-53 relative of its own word: the result is
- * within a few ulps of the exact sum, which is more than the reference's own left-to-right fp64 summation guarantees) */
+/* Carry-normalised form: words 0 .. PT_WIN_N - 2 in [0, 2^32), the top word takes the rest.  Exact (word k has weight 2^(32 k):
+ * what leaves a word upward is a multiple of 2^32) and CANONICAL: one integer total has one such form, whatever pieces it was
+ * added up from -- so win_value of the normalised words is the same double for every grouping of the samples (sample chunks
+ * merged in the workspace, tiles split over devices), and a merged word collects one piece below 2^32 per chunk. */
+__device__ __forceinline__ void win_normalize(unsigned long long *w)
+{
+#pragma unroll
+  for (int k = 0; k + 1 < PT_WIN_N; k++)
+  {
+    const long long c = (long long)w[k] >> 32; /* floor(w / 2^32) */
+    w[k] -= (unsigned long long)c << 32;
+    w[k + 1] += (unsigned long long)c;
+  }
+}
+/* the sum: words (normalised by the caller: win_normalize) combined from the top (each conversion and product is exact up to 2^-53
+ * relative of its own word: the result is within a few ulps of the exact sum, which is more than the reference's own
+ * left-to-right fp64 summation guarantees) */
 __device__ __forceinline__ double win_value(const unsigned long long *w)
 {
   double v = 0.0;
@@ -311,11 +326,17 @@ struct PoolStackT
 };
 typedef PoolStackT<128u, 0xFFu> PoolStack; /* render_tiles_pooled */
 
-/* a slot of a pool of `per` slots per XCD with one in-use flag each (zero between launches) */
-__device__ __forceinline__ uint32_t pt_pool_acquire(uint32_t *flags_base, uint32_t per)
+/* a slot of a pool of `per` slots per XCD with one in-use flag each (zero between launches).  None to be had after a bounded
+ * search (the pools are sized so that this cannot happen, pt_pool_slots_per_xcd): 0xFFFFFFFF, and `fail_bit` is ORed into the
+ * device's status word -- the caller's workgroup renders nothing, and the host reports the launch as failed (rt_hip_launch_status) */
+__device__ __forceinline__ uint32_t pt_pool_acquire(uint32_t *flags_base, uint32_t per, uint32_t *status, uint32_t fail_bit)
 {
   if (flags_base == nullptr || per == 0u)
+  {
+    if (status != nullptr)
+      atomicOr(status, fail_bit);
     return 0xFFFFFFFFu;
+  }
   /* s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, width 4): the XCD this wave runs on */
   const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
   uint32_t *flags = flags_base + xcc * per;
@@ -328,6 +349,8 @@ __device__ __forceinline__ uint32_t pt_pool_acquire(uint32_t *flags_base, uint32
     if ((probes & 15u) == 15u)
       __builtin_amdgcn_s_sleep(8);
   }
+  if (status != nullptr)
+    atomicOr(status, fail_bit);
   return 0xFFFFFFFFu;
 }
 

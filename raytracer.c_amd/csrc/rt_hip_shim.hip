@@ -9,6 +9,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -68,6 +70,7 @@ struct RtHipScene
    * time each held a copy (round-3 advisor finding).  Sharing is safe between concurrent launches of different scenes:
    * a workgroup takes a slot with an atomic flag, and the pool has more slots per XCD than workgroups can be resident. */
   mutable char *park_ws = nullptr;
+  mutable uint32_t park_slots_per_xcd = 0;
   mutable bool park_tried = false;
   void *blob = nullptr; /* one device allocation holding every array */
   double reach = 0;     /* >= |p| for every point p on a primitive of ordinary size (radius < 1000) */
@@ -276,19 +279,12 @@ struct BvhWide
   }
 };
 
-/* development switch: RT_HIP_KERNEL_VARIANT=0 selects the literal single-phase scan, 2 the pooled
- * (lane-waiting) kernels for hierarchy scenes instead of the parked-walk ones */
-int kernel_variant()
-{
-  static const int v = [] {
-    const char *e = getenv("RT_HIP_KERNEL_VARIANT");
-    /* 2: hierarchy scenes on the lane-waiting pooled kernels; 3: scenes beyond the LDS staging budget on the static in-memory kernel */
-    /* 4: such scenes on the compare-form pooled kernel; 5: mid-size sphere scenes staged in LDS although streaming is faster (pt_prefer_streaming) */
-    /* 7: small refractive sphere scenes on the static kernel instead of the pooled one */
-    return (e && e[0] >= '0' && e[0] <= '7' && e[0] != '1' && e[0] != '6') ? e[0] - '0' : 1;
-  }();
-  return v;
-}
+/* Fault injection for tests (rt_hip_selftest_fail_alloc): which of the shim's optional device allocations behave as if
+ * hipMalloc had failed, so that the fallback kernels are reachable -- and testable -- on a 288 GB device. */
+std::atomic<uint32_t> g_fail_alloc{0};
+
+/* the kernel the calling thread's last rt_hip_render_tiles* launched (rt_hip_last_launch_kernel) */
+thread_local int g_last_kernel = -1;
 
 /* The table set of `scene` for `near_R`, ready to be read by work submitted to `stream` after this
  * call (see TableSet).  *slot identifies it for release_tables(). */
@@ -421,45 +417,48 @@ struct ParkPool
 {
   char *ws = nullptr;
   int users = 0;
+  uint32_t slots_per_xcd = 0;
 };
 std::mutex g_park_mutex;
 ParkPool g_park[64];
 
-size_t park_flag_bytes()
+size_t park_flag_bytes(uint32_t slots_per_xcd)
 {
-  return ((size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD * sizeof(uint32_t) + 255) & ~(size_t)255;
+  return ((size_t)PT_PARK_XCDS * slots_per_xcd * sizeof(uint32_t) + 255) & ~(size_t)255;
 }
 
 /* -> the device's workspace (allocated and its flags zeroed at the first call), or nullptr when the allocation fails:
  * the scene then renders on the lane-waiting kernels, and rt_hip_kernel_name says so.  The current device is `device`. */
-char *park_acquire_ws(int device)
+char *park_acquire_ws(int device, uint32_t *slots_per_xcd)
 {
   if (device < 0 || device >= 64)
     return nullptr;
-  /* RT_HIP_NO_PARK_WS=1 (tests): behave as if the allocation had failed */
-  const char *no_ws = getenv("RT_HIP_NO_PARK_WS");
-  if (no_ws && no_ws[0] == '1')
+  if (g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_PARK_WS) /* tests: behave as if the allocation had failed */
     return nullptr;
   std::lock_guard<std::mutex> lock(g_park_mutex);
   ParkPool &p = g_park[device];
   if (!p.ws)
   {
-    const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD;
+    const uint32_t per = pt_pool_slots_per_xcd(true);
+    const size_t n_slots = (size_t)PT_PARK_XCDS * per;
     char *ws = nullptr;
-    if (hipMalloc(&ws, park_flag_bytes() + n_slots * (PT_BLOCK / 64) * (size_t)PT_PARK_WAVE_BYTES) != hipSuccess)
+    if (hipMalloc(&ws, park_flag_bytes(per) + n_slots * (PT_BLOCK / 64) * (size_t)PT_PARK_WAVE_BYTES) != hipSuccess)
     {
       (void)hipGetLastError();
       return nullptr;
     }
     /* the flags must be zero before a kernel on ANY stream looks at them (kernels leave them zero) */
-    if (hipMemset(ws, 0, park_flag_bytes()) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+    if (hipMemset(ws, 0, park_flag_bytes(per)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
     {
+      (void)hipGetLastError();
       (void)hipFree(ws);
       return nullptr;
     }
     p.ws = ws;
+    p.slots_per_xcd = per;
   }
   p.users++;
+  *slots_per_xcd = p.slots_per_xcd;
   return p.ws;
 }
 
@@ -474,6 +473,7 @@ void park_drop_ws(int device)
   {
     (void)hipFree(p.ws);
     p.ws = nullptr;
+    p.slots_per_xcd = 0;
   }
 }
 
@@ -484,13 +484,13 @@ void park_drop_ws(int device)
 struct PendPool
 {
   char *ws = nullptr;
-  uint32_t entries = 0, columns = 0;
+  uint32_t entries = 0, columns = 0, slots_per_xcd = 0;
 };
 std::mutex g_pend_mutex; /* held from the pool lookup until the launch that uses it is enqueued (so that a growing
                           * launch's hipDeviceSynchronize covers every kernel that holds the old pointer) */
 PendPool g_pend[64];
 
-size_t pend_flag_bytes() { return ((size_t)PT_PARK_XCDS * PT_PEND_SLOTS_PER_XCD * sizeof(uint32_t) + 255) & ~(size_t)255; }
+size_t pend_flag_bytes(uint32_t slots_per_xcd) { return ((size_t)PT_PARK_XCDS * slots_per_xcd * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
 /* caller holds g_pend_mutex; the current device is `device` */
 int pend_pool_for(int device, uint32_t entries, uint32_t columns, PtLaunch &L)
@@ -502,6 +502,13 @@ int pend_pool_for(int device, uint32_t entries, uint32_t columns, PtLaunch &L)
   {
     entries = std::max(entries, p.entries); /* grown in either direction, never shrunk */
     columns = std::max(columns, p.columns);
+    const uint32_t per = p.slots_per_xcd ? p.slots_per_xcd : pt_pool_slots_per_xcd(false);
+    const size_t slot_bytes = (size_t)entries * PT_PEND_FIELDS_HOST * columns * sizeof(double);
+    const size_t n_slots = (size_t)PT_PARK_XCDS * per;
+    /* tests: the request for 4 x 512 stacks per slot behaves as if hipMalloc had failed (BEFORE the old pool is given up) */
+    if (columns > PT_PEND_COLUMNS && (g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_WIDE_PEND))
+      return fail(RT_HIP_ENOMEM, "pending-ray pool for max_depth %u (%zu MB): allocation failure injected", entries - 2u,
+                  (pend_flag_bytes(per) + n_slots * slot_bytes) >> 20);
     if (p.ws)
     {
       HIP_TRY(hipDeviceSynchronize());
@@ -509,31 +516,88 @@ int pend_pool_for(int device, uint32_t entries, uint32_t columns, PtLaunch &L)
       p.ws = nullptr;
       p.entries = p.columns = 0;
     }
-    const size_t slot_bytes = (size_t)entries * PT_PEND_FIELDS_HOST * columns * sizeof(double);
-    const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PEND_SLOTS_PER_XCD;
     char *ws = nullptr;
-    hipError_t e = hipMalloc(&ws, pend_flag_bytes() + n_slots * slot_bytes);
+    hipError_t e = hipMalloc(&ws, pend_flag_bytes(per) + n_slots * slot_bytes);
     if (e != hipSuccess)
+    {
+      (void)hipGetLastError(); /* the caller may go on with a narrower pool: a later hipGetLastError() must not see this failure (round-4 advisor finding) */
       return fail(RT_HIP_ENOMEM, "pending-ray pool for max_depth %u (%zu MB): %s", entries - 2u,
-                  (pend_flag_bytes() + n_slots * slot_bytes) >> 20, hipGetErrorString(e));
-    e = hipMemset(ws, 0, pend_flag_bytes());
+                  (pend_flag_bytes(per) + n_slots * slot_bytes) >> 20, hipGetErrorString(e));
+    }
+    e = hipMemset(ws, 0, pend_flag_bytes(per));
     if (e == hipSuccess)
       e = hipStreamSynchronize(nullptr); /* the flags are zero before a kernel on any stream looks at them */
     if (e != hipSuccess)
     {
+      (void)hipGetLastError();
       (void)hipFree(ws);
       return fail(RT_HIP_ERUNTIME, "pending-ray pool: %s", hipGetErrorString(e));
     }
     p.ws = ws;
     p.entries = entries;
     p.columns = columns;
+    p.slots_per_xcd = per;
   }
   L.pend_flags = reinterpret_cast<uint32_t *>(p.ws);
-  L.pend_ws = reinterpret_cast<double *>(p.ws + pend_flag_bytes());
-  L.pend_slots_per_xcd = PT_PEND_SLOTS_PER_XCD;
+  L.pend_ws = reinterpret_cast<double *>(p.ws + pend_flag_bytes(p.slots_per_xcd));
+  L.pend_slots_per_xcd = p.slots_per_xcd;
   L.pend_entries = p.entries; /* slots are laid out for the pool's depth; a shallower launch uses a prefix of each */
   L.pend_slot_doubles = (uint64_t)p.entries * PT_PEND_FIELDS_HOST * p.columns;
   return RT_HIP_OK;
+}
+
+/* the per-device status word of render launches (PtLaunch.status, rt_hip_launch_status) */
+std::mutex g_status_mutex;
+uint32_t *g_status[64] = {nullptr};
+
+/* the current device is `device` */
+int status_word_for(int device, uint32_t **out)
+{
+  if (device < 0 || device >= 64)
+    return fail(RT_HIP_ENODEV, "device %d: no status word", device);
+  std::lock_guard<std::mutex> lock(g_status_mutex);
+  if (!g_status[device])
+  {
+    uint32_t *w = nullptr;
+    HIP_TRY(hipMalloc(&w, 256));
+    hipError_t e = hipMemset(w, 0, 256);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess)
+    {
+      (void)hipFree(w);
+      return fail(RT_HIP_ERUNTIME, "status word: %s", hipGetErrorString(e));
+    }
+    g_status[device] = w;
+  }
+  *out = g_status[device];
+  return RT_HIP_OK;
+}
+
+/* reads and clears the device's status word; the current device is `device` */
+int status_take(int device, uint32_t *flags)
+{
+  *flags = 0;
+  uint32_t *w = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_status_mutex);
+    w = (device >= 0 && device < 64) ? g_status[device] : nullptr;
+  }
+  if (!w)
+    return RT_HIP_OK; /* nothing has been launched on this device */
+  HIP_TRY(hipMemcpy(flags, w, sizeof *flags, hipMemcpyDeviceToHost));
+  if (*flags)
+    HIP_TRY(hipMemset(w, 0, sizeof *flags));
+  return RT_HIP_OK;
+}
+
+int status_to_error(uint32_t flags)
+{
+  if (!flags)
+    return RT_HIP_OK;
+  return fail(RT_HIP_ERUNTIME, "render launch failed on the device:%s%s -- the affected tiles were not rendered (they read NaN / 255)",
+              (flags & RT_HIP_FAIL_PEND_SLOT) ? " a workgroup found no free slot in the pending-ray pool;" : "",
+              (flags & RT_HIP_FAIL_PARK_SLOT) ? " a workgroup found no free slot in the parked-walk workspace;" : "");
 }
 
 void pend_pools_release()
@@ -549,6 +613,17 @@ void pend_pools_release()
       (void)hipFree(g_pend[d].ws);
       g_pend[d] = PendPool();
     }
+  {
+    std::lock_guard<std::mutex> slock(g_status_mutex);
+    for (int d = 0; d < 64; d++)
+      if (g_status[d])
+      {
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_status[d]);
+        g_status[d] = nullptr;
+      }
+  }
   (void)hipSetDevice(prev);
 }
 
@@ -609,6 +684,7 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
 void release_cache_impl();
 uint64_t cache_builds_impl();
 int set_device_map_impl(const int *map, int n);
+void last_phases_impl(double out[3]);
 } // namespace
 
 extern "C" {
@@ -632,6 +708,12 @@ int rt_hip_scene_create(const RtHipSphere *spheres, size_t n_spheres, const RtHi
 }
 
 void rt_hip_release_cache(void) { release_cache_impl(); }
+
+void rt_hip_last_image_phases(double seconds[3])
+{
+  if (seconds)
+    last_phases_impl(seconds);
+}
 
 int rt_hip_set_device_map(const int *map, int n)
 {
@@ -743,7 +825,13 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     {
       const double *q = meshes[m].vertices[k].pos;
       const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-      /* (a vertex far out, or non-finite, needs no flag of its own: it is part of `reach`, and a launch refuses
+      /* a non-finite coordinate is refused here: fmax(reach, NaN) would drop it silently, the hierarchy builder would sort
+       * NaN centroids (no strict weak ordering) and quantise them (undefined), and the kernels' UNSCALED division would lose
+       * its range argument (round-4 advisor finding).  The reference has no such check -- and no meaning for such a triangle:
+       * every comparison of its test (raytracer.c:137-150) is false or the triangle is never hit. */
+      if (!(len <= 1e300))
+        return fail(RT_HIP_EINVAL, "mesh %zu: vertex %zu has a non-finite coordinate", m, k);
+      /* (a vertex far out needs no flag of its own: it is part of `reach`, and a launch refuses
        * near_R = 1.5 (|camera| + reach) + 1 >= 1e15 as "not a usable finite bound" -- so every vertex a kernel ever sees
        * lies within 6.7e14 of the origin, which is what exact_triangle's UNSCALED division rests on, see below) */
       reach = std::fmax(reach, len);
@@ -953,6 +1041,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->view.any_checker = any_checker ? 1u : 0u;
   sc->view.mesh_round = mesh_round ? 1u : 0u;
   sc->view.any_refract = any_refract ? 1u : 0u;
+#ifdef PT_DEV_KERNELS
   {
     /* development knob (tools/many_spheres.py): RT_HIP_FORCE_BIG=1 sends a small scene to the scalar-table _big kernels,
      * which it otherwise reaches only through a centre or radius beyond 1e17 */
@@ -960,6 +1049,7 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     if (fb && fb[0] == '1')
       wide_range = true;
   }
+#endif
   sc->view.wide_range = wide_range ? 1u : 0u;
   sc->max_center = max_center;
   {
@@ -1046,28 +1136,115 @@ const char *rt_hip_kernel_name(const RtHipScene *scene, uint32_t integrator)
 {
   if (!scene)
     return "";
-  /* a scene whose parked-walk workspace could not be allocated runs on the lane-waiting kernels (pt_launch_render):
-   * report what is launched, so that an out-of-memory fallback cannot pass as a measurement of the parked-walk kernels */
+  /* a scene whose parked-walk workspace could not be allocated runs on the lane-waiting kernels: report what a launch
+   * takes, so that an out-of-memory fallback cannot pass as a measurement of the parked-walk kernels.  What is assumed of
+   * the launch itself: sums that fit, a pending-ray pool of full width -- rt_hip_last_launch_kernel() has the fact. */
   bool no_ws;
   {
     std::lock_guard<std::mutex> lock(scene->table_mutex);
-    no_ws = scene->park_tried && scene->park_ws == nullptr;
+    no_ws = (scene->park_tried && scene->park_ws == nullptr) || (g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_PARK_WS);
   }
-  return pt_kernel_name(scene->view, integrator, kernel_variant(), !no_ws);
+  const PtPickFacts facts = {integrator, 1, 0, !no_ws, !(g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_WIDE_PEND)};
+  return pt_kernel_name_of(pt_pick_kernel(scene->view, facts));
+}
+
+const char *rt_hip_last_launch_kernel(void) { return pt_kernel_name_of(g_last_kernel); }
+
+int rt_hip_kernel_count(void) { return pt_kernel_count(); }
+
+const char *rt_hip_kernel_launches(int index, uint64_t *launches)
+{
+  if (index < 0 || index >= pt_kernel_count())
+    return nullptr;
+  if (launches)
+    *launches = pt_kernel_launches(index);
+  return pt_kernel_name_of(index);
+}
+
+const char *rt_hip_kernel_for_class(const RtHipSceneClass *c)
+{
+  if (!c)
+    return "";
+  PtSceneView v;
+  memset(&v, 0, sizeof v);
+  v.n_spheres = c->n_spheres;
+  v.n_meshes = c->n_meshes;
+  v.n_triangles = c->n_triangles;
+  v.n_bvh_nodes = c->n_triangles ? std::max(1u, c->n_triangles / 8u) : 0u;
+  v.any_checker = c->any_checker ? 1u : 0u;
+  v.any_refract = c->any_refract ? 1u : 0u;
+  v.any_mirror_glass = c->any_mirror_glass ? 1u : 0u;
+  v.wide_range = c->wide_range ? 1u : 0u;
+  v.mesh_round = c->mesh_round ? 1u : 0u;
+  const PtPickFacts facts = {c->integrator, c->samples_per_chunk, c->max_depth, c->have_park_ws != 0, c->wide_pend_ok != 0};
+  return pt_kernel_name_of(pt_pick_kernel(v, facts));
+}
+
+void rt_hip_selftest_fail_alloc(uint32_t mask) { g_fail_alloc.store(mask); }
+
+int rt_hip_selftest_pool_slots(int device, uint32_t *park_slots_per_xcd, uint32_t *pend_slots_per_xcd)
+{
+  if (device < 0 || device >= usable_devices())
+    return fail(RT_HIP_ENODEV, "no HIP device %d", device);
+  DeviceScope scope(device);
+  HIP_TRY(scope.status);
+  if (park_slots_per_xcd)
+    *park_slots_per_xcd = pt_pool_slots_per_xcd(true);
+  if (pend_slots_per_xcd)
+    *pend_slots_per_xcd = pt_pool_slots_per_xcd(false);
+  return RT_HIP_OK;
+}
+
+int rt_hip_launch_status(int device, uint32_t *flags)
+{
+  uint32_t f = 0;
+  if (flags)
+    *flags = 0;
+  if (device < 0 || device >= usable_devices())
+    return fail(RT_HIP_ENODEV, "no HIP device %d", device);
+  DeviceScope scope(device);
+  HIP_TRY(scope.status);
+  int rc = status_take(device, &f);
+  if (rc)
+    return rc;
+  if (flags)
+    *flags = f;
+  return status_to_error(f);
 }
 
 size_t rt_hip_chunk_workspace_bytes(uint32_t tile_count)
+{ /* enough for any scene: the windowed sums of the M_REFRACTION forms are the larger record */
+  return (size_t)tile_count * PT_ACC_WS_WORDS_WIN * sizeof(unsigned long long);
+}
+
+size_t rt_hip_scene_chunk_workspace_bytes(const RtHipScene *scene, uint32_t tile_count)
 {
-  return (size_t)tile_count * PT_ACC_WS_WORDS * sizeof(unsigned long long);
+  const bool windowed = !scene || scene->view.any_refract;
+  return (size_t)tile_count * (windowed ? PT_ACC_WS_WORDS_WIN : PT_ACC_WS_WORDS) * sizeof(unsigned long long);
 }
 
 uint32_t rt_hip_suggest_chunks(const RtHipScene *scene, uint32_t tile_count, int32_t samples)
 {
-  if (!scene || tile_count == 0 || samples < 128)
+  return rt_hip_suggest_chunks_depth(scene, tile_count, samples, 0);
+}
+
+uint32_t rt_hip_suggest_chunks_depth(const RtHipScene *scene, uint32_t tile_count, int32_t samples, int32_t max_depth)
+{
+  if (!scene || tile_count == 0 || samples < 1)
     return 1;
+  /* scenes with M_REFRACTION: at least as many chunks as the windowed sums need (pt_refr_pool_fits per chunk) */
+  uint64_t need = 1;
+  if (scene->view.any_refract)
+  {
+    need = pt_refr_pool_chunks_needed(samples, max_depth);
+    if (need == 0 || need > (uint64_t)samples || need * tile_count > 0x7FFFFFFFull)
+      need = 1; /* no chunking fits (max_depth > 29): the static kernels, which do not split samples */
+  }
+  if (samples < 128)
+    return (uint32_t)need;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, scene->device) != hipSuccess)
-    return 1;
+    return (uint32_t)need;
   /* aim for >= 20 workgroups per resident slot (5 per CU), so the last, partly filled round
    * of the launch is a small fraction of it; keep >= 64 samples per chunk.  (One rank's share of the headline frame at
    * N = 8 / 4 / 2, ms by chunks: 2: 30.0, 4: 29.3, 6: 29.4, 8: 29.6, 16: 30.9 / 1: 59.1, 2: 57.7, 4: 57.5 / 1: 114.7, 2: 113.4.) */
@@ -1076,6 +1253,7 @@ uint32_t rt_hip_suggest_chunks(const RtHipScene *scene, uint32_t tile_count, int
   const uint64_t cap = (uint64_t)samples / 64;
   if (chunks > cap) chunks = cap;
   if (chunks > 16) chunks = 16;
+  if (chunks < need) chunks = need;
   return chunks < 1 ? 1u : (uint32_t)chunks;
 }
 
@@ -1109,10 +1287,14 @@ static void big_prune_for(const RtHipScene *scene, double near_R, double filt_sh
   L.big_delta = L.big_tmin = 0.f;
   for (int k = 0; k < 8; k++)
     L.big_qmin[k] = std::numeric_limits<float>::infinity();
+#ifdef PT_DEV_KERNELS
   static const bool off = [] {
     const char *e = getenv("RT_HIP_NO_BIG_PRUNE"); /* development switch (A/B) */
     return e && e[0] == '1';
   }();
+#else
+  const bool off = false;
+#endif
   /* the kernels whose sphere filter is the sign-test form from LDS: sphere-only small scenes, and hierarchy scenes whose
    * spheres fit the staging (the parked-walk kernels filter the spheres alone) */
   const bool sign_form = !scene->view.wide_range &&
@@ -1231,10 +1413,12 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
     mesh_bound_for(scene, L.near_R, L.mesh_bound);
     big_prune_for(scene, L.near_R, L.filt_shift, L);
     L.hull_margin = hull_margin_for(scene, L.near_R);
-    {
+#ifdef PT_DIAG
+    { /* the diagnostic build only: walk the rays the probe or the hull rule would not walk, and count any that find a triangle */
       const char *flag = getenv("RT_HIP_DIAG_WALK_REJECTED");
       L.diag_flags = (flag && flag[0] == '1') ? 1u : 0u;
     }
+#endif
     L.background = 10 / 255.0;
     L.t_start = 1.7976931348623157e308; /* DBL_MAX */
     L.w_minus_1 = (double)params->width - 1.0;
@@ -1265,64 +1449,91 @@ int rt_hip_render_tiles_chunked(const RtHipScene *scene, const RtHipCamera *came
   L.tile_stride = params->tile_stride;
   L.tile_count = params->tile_count;
   L.tiles_x = tx;
-  /* the static kernels (plain reference variant; M_REFRACTION; cast_ray; scenes too large to stage) do not split samples */
-  L.sample_chunks = (kernel_variant() == 0 || scene->view.any_refract || cast_ray ||
-                     (!pt_geom_in_lds(scene->view) && kernel_variant() == 3)) ? 1u : sample_chunks;
   L.integrator = cast_ray ? 1u : 0u;
   L.acc_ws = static_cast<unsigned long long *>(d_workspace);
-  if ((uint64_t)L.tile_count * L.sample_chunks > 0x7FFFFFFFull)
-    return fail(RT_HIP_EINVAL, "tile_count x sample_chunks exceeds the grid limit");
   L.tiles_rgb = d_tiles_rgb;
   L.tiles_rgb8 = d_tiles_rgb8;
   L.stats = reinterpret_cast<unsigned long long *>(d_stats);
 
   DeviceScope scope(scene->device);
   HIP_TRY(scope.status);
+  rc = status_word_for(scene->device, &L.status);
+  if (rc)
+    return rc;
   if (scene->view.n_bvh_nodes != 0 && !cast_ray)
   {
-    /* parked-walk workspace: the device's shared pool (flags + rings).  Without it pt_launch_render takes the
-     * lane-waiting kernels, and rt_hip_kernel_name reports those. */
+    /* parked-walk workspace: the device's shared pool (flags + rings).  Without it the pick table's park = NO rows apply
+     * (the lane-waiting kernels), and rt_hip_kernel_name reports those. */
     std::lock_guard<std::mutex> lock(scene->table_mutex);
     if (!scene->park_tried)
     {
       scene->park_tried = true;
-      scene->park_ws = park_acquire_ws(scene->device);
+      scene->park_ws = park_acquire_ws(scene->device, &scene->park_slots_per_xcd);
     }
     if (scene->park_ws)
     {
-      const size_t n_slots = (size_t)PT_PARK_XCDS * PT_PARK_SLOTS_PER_XCD;
-      (void)n_slots;
       L.park_flags = reinterpret_cast<uint32_t *>(scene->park_ws);
-      L.park_ws = scene->park_ws + park_flag_bytes();
-      L.park_slots_per_xcd = PT_PARK_SLOTS_PER_XCD;
+      L.park_ws = scene->park_ws + park_flag_bytes(scene->park_slots_per_xcd);
+      L.park_slots_per_xcd = scene->park_slots_per_xcd;
     }
   }
+  /* ---- which kernel (pt_kernel.hip: pt_pick_table), and how many sample chunks it takes ---- */
+  /* scenes with M_REFRACTION: the windowed sums of the pooled / parked-walk forms hold a bounded number of samples per chunk
+   * (pt_refr_pool_fits).  A caller that handed over a workspace gets at least as many chunks as that needs -- the image does
+   * not depend on the chunk count, and the workspace's size does not either; without a workspace the launch keeps its one
+   * chunk, and where that does not fit the table's fit = NO row (the static kernel of the family) renders it. */
+  if (!cast_ray && scene->view.any_refract && d_workspace)
+  {
+    const uint64_t need = pt_refr_pool_chunks_needed(params->samples, params->max_depth);
+    if (need > sample_chunks && need <= (uint64_t)params->samples && need * params->tile_count <= 0x7FFFFFFFull)
+      sample_chunks = (uint32_t)need;
+  }
+  const int32_t samples_per_chunk = (int32_t)(((int64_t)params->samples + sample_chunks - 1) / sample_chunks);
+  PtPickFacts facts = {L.integrator, samples_per_chunk, params->max_depth, L.park_ws != nullptr, true};
+  int which = pt_pick_kernel(L.scene, facts);
+  auto chunks_of = [&](int k) {
+    if (pt_kernel_takes_chunks(k))
+      return sample_chunks;
+    /* the static bodies (cast_ray, the fit = NO rows of M_REFRACTION) do not split samples */
+    return 1u;
+  };
+  L.sample_chunks = chunks_of(which);
+  L.acc_windows = pt_kernel_is_windowed(which) ? 1u : 0u;
+  if ((uint64_t)L.tile_count * L.sample_chunks > 0x7FFFFFFFull)
+    return fail(RT_HIP_EINVAL, "tile_count x sample_chunks exceeds the grid limit");
   size_t slot = 0;
   rc = acquire_tables(scene, L.near_R, static_cast<hipStream_t>(stream), &L.scene.filt, &L.scene.bvh_nodes, &slot);
   if (rc)
     return rc;
   hipError_t e;
-  if (pt_kernel_needs_pend_pool(L.scene, L.integrator, kernel_variant()))
+  if (pt_kernel_uses_pend_pool(which))
   {
     std::lock_guard<std::mutex> pend_lock(g_pend_mutex);
-    const uint32_t columns = pt_kernel_pend_columns(L.scene, L.integrator, kernel_variant());
-    rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, columns, L);
+    rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, pt_kernel_pend_columns_of(which), L);
     /* the parked-walk refraction kernels want four times the stacks per slot (1.2 GB at depth 5, 5.7 GB at 32): where that
-     * cannot be had, the pool of the other kernels will do -- pt_launch_render then takes the static kernel of the family */
-    if (rc == RT_HIP_ENOMEM && columns > PT_PEND_COLUMNS)
-      rc = pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, PT_PEND_COLUMNS, L);
+     * cannot be had, the pool of the other kernels will do -- the table's fit = NO row names the static kernel of the family */
+    if (rc == RT_HIP_ENOMEM && pt_kernel_pend_columns_of(which) > PT_PEND_COLUMNS)
+    {
+      facts.wide_pend_ok = false;
+      which = pt_pick_kernel(L.scene, facts);
+      L.sample_chunks = chunks_of(which);
+      L.acc_windows = pt_kernel_is_windowed(which) ? 1u : 0u;
+      rc = pt_kernel_uses_pend_pool(which) ? pend_pool_for(scene->device, (uint32_t)params->max_depth + 2u, pt_kernel_pend_columns_of(which), L)
+                                           : RT_HIP_OK;
+    }
     if (rc)
     {
       release_tables(scene, slot, static_cast<hipStream_t>(stream));
       return rc;
     }
-    e = pt_launch_render(L, static_cast<hipStream_t>(stream), kernel_variant());
+    e = pt_launch_render(L, static_cast<hipStream_t>(stream), which);
   }
   else
-    e = pt_launch_render(L, static_cast<hipStream_t>(stream), kernel_variant());
+    e = pt_launch_render(L, static_cast<hipStream_t>(stream), which);
   release_tables(scene, slot, static_cast<hipStream_t>(stream));
   if (e != hipSuccess)
-    return fail(RT_HIP_ERUNTIME, "pt_render_tiles launch: %s", hipGetErrorString(e));
+    return fail(RT_HIP_ERUNTIME, "%s launch: %s", pt_kernel_name_of(which), hipGetErrorString(e));
+  g_last_kernel = which;
   return RT_HIP_OK;
 }
 
@@ -1508,6 +1719,7 @@ struct ImageCtx
 };
 ImageCtx g_ctx;
 std::mutex g_ctx_mutex;
+double g_last_phases[3] = {0, 0, 0}; /* rt_hip_last_image_phases */
 
 /* The logical -> physical device map of rt_hip_render_image (rt_hip_set_device_map, or RT_HIP_DEVICE_MAP=0,0,1 read at
  * the first frame).  Empty = the identity.  Guarded by g_ctx_mutex. */
@@ -1772,9 +1984,11 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   }
   int prev = 0;
   (void)hipGetDevice(&prev);
+  const auto tick0 = std::chrono::steady_clock::now();
   rc = ctx_prepare(spheres, n_spheres, meshes, n_meshes, G, phys, W, H, prev);
   if (rc)
     return rc;
+  const auto tick1 = std::chrono::steady_clock::now();
   ImageCtx &c = g_ctx;
   std::vector<ImageCtx::Dev> &dev = c.dev;
   /* a failure below leaves the cached context in an unknown state: drop it */
@@ -1824,9 +2038,9 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
       p.tile_first = (uint32_t)g + k0 * (uint32_t)G;
       p.tile_stride = (uint32_t)G;
       p.tile_count = k1 - k0;
-      const uint32_t chunks = rt_hip_suggest_chunks(d.scene, p.tile_count, p.samples);
+      const uint32_t chunks = p.integrator == RT_HIP_CAST_RAY ? 1u : rt_hip_suggest_chunks_depth(d.scene, p.tile_count, p.samples, p.max_depth);
       if (chunks > 1 && !d.ws)
-        IMG_TRY(hipMalloc(&d.ws, rt_hip_chunk_workspace_bytes(d.count)));
+        IMG_TRY(hipMalloc(&d.ws, rt_hip_scene_chunk_workspace_bytes(d.scene, d.count)));
       rc = rt_hip_render_tiles_chunked(d.scene, camera, &p, chunks, d.ws, d.tiles + (size_t)k0 * 192,
                                        d.tiles8 + (size_t)k0 * 192, d.stats, d.stream);
       if (rc)
@@ -1936,6 +2150,24 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     IMG_TRY(hipStreamSynchronize(dev[g].stream));
   }
 
+  const auto tick2 = std::chrono::steady_clock::now();
+  /* ---- did every workgroup find its pool slots?  (the status word of each physical device) ---- */
+  uint32_t fail_flags = 0;
+  for (int g = 0; g < G; g++)
+    if (c.lead[g] == g)
+    {
+      IMG_TRY(hipSetDevice(phys[g]));
+      uint32_t f = 0;
+      rc = status_take(phys[g], &f);
+      if (rc)
+      {
+        ctx_release(g_ctx);
+        (void)hipSetDevice(prev);
+        return rc;
+      }
+      fail_flags |= f;
+    }
+
   /* ---- results ---- */
   IMG_TRY(hipSetDevice(phys[0]));
   if (h_image_rgb)
@@ -1962,6 +2194,17 @@ int render_image_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
     *kernel_seconds = worst;
   (void)hipSetDevice(prev);
 #undef IMG_TRY
+  {
+    const auto tick3 = std::chrono::steady_clock::now();
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double>(b - a).count();
+    };
+    g_last_phases[0] = secs(tick0, tick1); /* context: scene compare, or upload + buffers + workspaces + communicators */
+    g_last_phases[1] = secs(tick1, tick2); /* launches, kernels, gather, scatter -- until every stream is idle */
+    g_last_phases[2] = secs(tick2, tick3); /* the frame, bytes and counters over PCIe */
+  }
+  if (fail_flags)
+    return status_to_error(fail_flags); /* the buffers hold what was rendered; the unrendered tiles read NaN / 255 */
   if (cancelled)
     return fail(RT_HIP_ECANCELLED, "render cancelled: the image holds the tiles finished so far");
   return RT_HIP_OK;
@@ -1979,6 +2222,12 @@ int set_device_map_impl(const int *map, int n)
   g_device_map_env_read = true; /* an explicit map (or its removal) overrides RT_HIP_DEVICE_MAP */
   g_device_map.assign(map, map + n);
   return RT_HIP_OK;
+}
+
+void last_phases_impl(double out[3])
+{
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  memcpy(out, g_last_phases, sizeof g_last_phases);
 }
 
 void release_cache_impl()

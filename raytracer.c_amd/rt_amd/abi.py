@@ -13,6 +13,8 @@ HOST_PATH = os.path.join(PKG_DIR, "host", "libraytracer_amd.so")
 M_DEFAULT, M_REFLECTION, M_REFRACTION, M_CHECKERED = 2, 4, 8, 16
 TILE, TILE_PIXELS, TILE_FLOATS = 8, 64, 192
 STAT_RAYS, STAT_CASTS, STAT_TESTS, STAT_SAMPLES, NSTATS = 0, 1, 2, 3, 4
+FAIL_ALLOC_PARK_WS, FAIL_ALLOC_WIDE_PEND = 1, 2   # rt_hip_selftest_fail_alloc
+FAIL_PEND_SLOT, FAIL_PARK_SLOT = 1, 2             # rt_hip_launch_status
 
 
 class Vec2(C.Structure):
@@ -98,6 +100,8 @@ SHIM_SYMBOLS = {
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_hip_chunk_workspace_bytes": (C.c_size_t, [C.c_uint32]),
     "rt_hip_suggest_chunks": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_int32]),
+    "rt_hip_suggest_chunks_depth": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32]),
+    "rt_hip_scene_chunk_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
     "rt_hip_render_tiles_chunked": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RtHipParams), C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_hip_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
@@ -110,6 +114,14 @@ SHIM_SYMBOLS = {
     "rt_hip_release_cache": (None, []),
     "rt_hip_cache_builds": (C.c_uint64, []),
     "rt_hip_set_device_map": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "rt_hip_last_image_phases": (None, [C.POINTER(C.c_double)]),
+    "rt_hip_last_launch_kernel": (C.c_char_p, []),
+    "rt_hip_kernel_count": (C.c_int, []),
+    "rt_hip_kernel_launches": (C.c_char_p, [C.c_int, C.POINTER(C.c_uint64)]),
+    "rt_hip_kernel_for_class": (C.c_char_p, [C.c_void_p]),
+    "rt_hip_launch_status": (C.c_int, [C.c_int, C.POINTER(C.c_uint32)]),
+    "rt_hip_selftest_fail_alloc": (None, [C.c_uint32]),
+    "rt_hip_selftest_pool_slots": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_hip_render_image": (C.c_int, [C.POINTER(Object), C.c_size_t, C.POINTER(RtHipMesh), C.c_size_t,
                                       C.POINTER(Camera), C.POINTER(RtHipParams), C.c_int, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),

@@ -60,14 +60,25 @@ class GpuScene:
     def kernel_name(self, integrator="path"):
         return self.shim.rt_hip_kernel_name(self.handle, abi.INTEGRATORS[integrator]).decode()
 
+    def last_launch_kernel(self):
+        """the kernel this thread's last render_tiles() launched (the launch's own facts can name another than kernel_name())"""
+        return self.shim.rt_hip_last_launch_kernel().decode()
+
+    def launch_status(self):
+        """device-side failures of render launches since the last call (0 = none); raises ShimError when any"""
+        flags = C.c_uint32(0)
+        _check(self.shim.rt_hip_launch_status(self.device, C.byref(flags)), "rt_hip_launch_status")
+        return flags.value
+
     def hull_facets(self):
         """(triangles marked as hull facets with the stored normal pointing outward, ... inward)"""
         plus, minus = C.c_uint32(0), C.c_uint32(0)
         _check(self.shim.rt_hip_scene_hull_facets(self.handle, C.byref(plus), C.byref(minus)), "rt_hip_scene_hull_facets")
         return plus.value, minus.value
 
-    def suggest_chunks(self, count, samples=None):
-        return int(self.shim.rt_hip_suggest_chunks(self.handle, count, samples or self.scene.samples))
+    def suggest_chunks(self, count, samples=None, max_depth=None):
+        return int(self.shim.rt_hip_suggest_chunks_depth(self.handle, count, samples or self.scene.samples,
+                                                         self.scene.max_depth if max_depth is None else max_depth))
 
     def render_tiles(self, seed, first, stride, count, tiles=None, tiles8=None, stats=None, samples=None,
                      max_depth=None, chunks=1, workspace=None, integrator="path", camera=None):
@@ -86,7 +97,7 @@ class GpuScene:
         p = self.params(seed, first, stride, count, samples, max_depth, integrator)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if chunks > 1 and workspace is None:
-            workspace = torch.empty(self.shim.rt_hip_chunk_workspace_bytes(max(count, 1)), dtype=torch.uint8, device=dev)
+            workspace = torch.empty(self.shim.rt_hip_scene_chunk_workspace_bytes(self.handle, max(count, 1)), dtype=torch.uint8, device=dev)
         self._workspace = workspace  # keep alive until the stream has used it
         _check(self.shim.rt_hip_render_tiles_chunked(self.handle, C.byref(camera if camera is not None else self.scene.camera),
                                                      C.byref(p), chunks,
@@ -114,10 +125,12 @@ class GpuScene:
     def render_image(self, seed, samples=None, max_depth=None, integrator="path"):
         """Whole image on this one GPU -> (image f32 [H,W,3], image8 u8 [H,W,3], stats dict), synchronised."""
         total = n_tiles(self.scene.width, self.scene.height)
+        chunks = 1 if integrator != "path" else self.suggest_chunks(total, samples, max_depth)
         tiles, tiles8, stats = self.render_tiles(seed, 0, 1, total, samples=samples, max_depth=max_depth,
-                                                 integrator=integrator)
+                                                 integrator=integrator, chunks=chunks)
         image, image8 = self.untile(tiles, tiles8, 0, 1, total)
         torch.cuda.synchronize(tiles.device)
+        self.launch_status()   # a workgroup without its pool slot fails the frame here, not as NaN pixels
         st = stats.cpu().tolist()
         return image, image8, dict(rays=st[abi.STAT_RAYS], casts=st[abi.STAT_CASTS], tests=st[abi.STAT_TESTS],
                                    samples=st[abi.STAT_SAMPLES])

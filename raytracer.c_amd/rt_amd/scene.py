@@ -112,3 +112,49 @@ def custom_scene(objects, width, height, samples, max_depth, cam_pos, cam_target
                _keep=keep)
     sc.free = lambda: None  # vertex arrays are Python-owned
     return sc
+
+
+def mesh_view_tiles(sc):
+    """Classify the frame's 8x8 tiles by how the camera sees the scene's triangles' bounding ball: -> dict of tile-id arrays
+    `silhouette` (the four corner pixels' un-jittered camera rays, get_camera_ray raytracer.c:375-384, disagree about hitting
+    the ball: the tile straddles the mesh's outline), `inside` (all four hit), `outside` (none hits: such a tile can see the
+    mesh only through a bounce).  For picking parity samples where the resolution-dependent rules of the hierarchy kernels
+    (tile cones against the ball, the probe) decide differently inside one tile."""
+    import numpy as np
+    v = []
+    for m in range(sc.n_meshes):
+        n = 3 * sc.meshes[m].mesh.num_triangles
+        a = np.ctypeslib.as_array(C.cast(sc.meshes[m].mesh.vertices, C.POINTER(C.c_double)), shape=(n, 5))
+        v.append(a[:, :3].copy())
+    v = np.concatenate(v)
+    centre = 0.5 * (v.min(axis=0) + v.max(axis=0))
+    radius = float(np.sqrt(((v - centre) ** 2).sum(axis=1).max()))
+    cam = sc.camera
+    pos = np.array(cam.position.tuple())
+    hor, ver, llc = np.array(cam.horizontal.tuple()), np.array(cam.vertical.tuple()), np.array(cam.lower_left_corner.tuple())
+    w, h = sc.width, sc.height
+    tx, ty = (w + 7) // 8, (h + 7) // 8
+    xs = np.minimum(np.arange(tx + 1) * 8, w - 1)
+    ys = np.minimum(np.arange(ty + 1) * 8, h - 1)
+    u = xs / (w - 1.0)
+    vv = ys / (h - 1.0)
+    # dir = normalize(pos - (llc + H u + V v)), origin = pos
+    d = pos[None, None, :] - (llc[None, None, :] + hor[None, None, :] * u[None, :, None] + ver[None, None, :] * vv[:, None, None])
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    L = centre - pos
+    tca = (d * L).sum(axis=2)
+    d2 = (L * L).sum() - tca * tca
+    hit = (tca > 0) & (d2 <= radius * radius)          # at the (ty + 1) x (tx + 1) grid corners
+    n_hit = hit[:-1, :-1].astype(int) + hit[1:, :-1] + hit[:-1, 1:] + hit[1:, 1:]
+    ids = np.arange(tx * ty, dtype=np.uint32).reshape(ty, tx)
+    return dict(silhouette=ids[(n_hit > 0) & (n_hit < 4)], inside=ids[n_hit == 4], outside=ids[n_hit == 0],
+                ball=(tuple(centre), radius))
+
+
+def pick_evenly(ids, n):
+    """n of the ids, evenly spaced through their order"""
+    import numpy as np
+    ids = np.asarray(ids)
+    if len(ids) <= n:
+        return ids.copy()
+    return ids[(np.arange(n) * len(ids)) // n]

@@ -348,7 +348,45 @@ def meshes():
     return out
 
 
+def _wide_job(args):
+    cfg, spp, px = args
+    sc = S.build_scene(cfg, samples=spp)
+    mean, rgb8, st = oracle_py.RefMeshOracle(sc.max_depth).render_pixels(sc, SEED, pixels=px)
+    return mean, rgb8, st["rays"], st["tests"]
+
+
+def c5_wide(n_sil=64, n_in=64, n_out=128, spp=2):
+    """BASELINE configs[4] at its OWN 3840x2160, few samples, many tiles: 256 tiles = 16,384 pixels x 2 spp
+    through the reference's compiled code with its mesh scan revived -- 64 tiles that straddle the mesh's outline, 64 inside
+    it, 128 spread over the rest of the frame (rt_amd.scene.mesh_view_tiles) -- so that the resolution-dependent conservative
+    rules of the hierarchy kernels are pinned against the reference across the 4K frame, not only on six tiles"""
+    import multiprocessing as mp
+    sc = S.build_scene(5, samples=spp)
+    view = S.mesh_view_tiles(sc)
+    tiles = np.concatenate([S.pick_evenly(view["silhouette"], n_sil), S.pick_evenly(view["inside"], n_in),
+                            S.pick_evenly(view["outside"], n_out)]).astype(np.uint32)
+    px = tile_pixels(sc.width, sc.height, tiles)
+    n_proc = min(os.cpu_count() or 1, 16)
+    parts = [px[i::n_proc] for i in range(n_proc)]
+    with mp.get_context("spawn").Pool(n_proc) as pool:
+        res = pool.map(_wide_job, [(5, spp, p) for p in parts])
+    mean = np.zeros((len(px), 3))
+    rgb8 = np.zeros((len(px), 3), dtype=np.uint8)
+    for i, (m, b, _, _) in enumerate(res):
+        mean[i::n_proc] = m
+        rgb8[i::n_proc] = b
+    out = dict(tiles=tiles, mean=mean, rgb8=rgb8, stats=np.array([sum(r[2] for r in res), sum(r[3] for r in res)]),
+               dims=np.array([sc.width, sc.height, spp, sc.max_depth]), groups=np.array([n_sil, n_in, n_out]))
+    print("c5_wide", len(tiles), "tiles", len(px), "pixels, stats", out["stats"].tolist(), flush=True)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "c5_wide":
+        assert oracle_py.ref_mesh_available(), "build oracle/_ref first (make oracle, needs /root/reference)"
+        np.savez_compressed(os.path.join(HERE, "c5_wide.npz"), **c5_wide())
+        print("c5_wide.npz", os.path.getsize(os.path.join(HERE, "c5_wide.npz")), "bytes")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "meshes":
         assert oracle_py.ref_mesh_available(), "build oracle/_ref first (make oracle, needs /root/reference)"
         np.savez_compressed(os.path.join(HERE, "meshes.npz"), **meshes())

@@ -12,6 +12,10 @@ from util import assert_parity, tile_pixels
 
 pytestmark = pytest.mark.gpu
 
+# the development build of the shim (make shim-dev: -DPT_DEV_KERNELS): the switches that move a scene to another arm of the
+# pick table, or swap the hierarchy builder, exist only there -- loaded by CHILD processes through RT_HIP_SHIM_PATH
+DEV_LIB = __import__("os").path.join(ROOT, "raytracer.c_amd", "csrc", "librt_hip_dev.so")
+
 
 @pytest.fixture(scope="module")
 def gpu():
@@ -1227,12 +1231,13 @@ def test_refraction_on_the_pooled_body(gpu, pt):
         inside = S.custom_scene(objs, 64, 40, 6, depth, (0.3, 0.1, 0.8), (0.4, 0.3, -2.0))
         st = _full(gpu, pt, inside, hdr=True)
         assert st["rays"] > 64 * 40 * 6 * 4      # the trees really branch
-    # the static kernel (RT_HIP_KERNEL_VARIANT=7, read once per process: a child) gives the same image to float rounding and the same counters
+    # the static kernel (the development build's RT_HIP_KERNEL_VARIANT=7, read once per process: a child) gives the same image to float rounding and the same counters
     code = ("import sys, json, torch; sys.path[:0] = [%r, %r]; from rt_amd import gpu as G; from util import glass_scene; "
             "sc = glass_scene(96, 64, 12, 7); gs = G.GpuScene(sc); img, img8, st = gs.render_image(%d); "
             "print(json.dumps({'k': gs.kernel_name(), 'st': st, 'sum': float(img.double().sum()), 'img8': int(img8.long().sum())}))"
             % (os.path.join(ROOT, "raytracer.c_amd"), os.path.join(ROOT, "tests"), SEED))
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RT_HIP_KERNEL_VARIANT="7"), capture_output=True, text=True, timeout=300)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RT_HIP_KERNEL_VARIANT="7", RT_HIP_SHIM_PATH=DEV_LIB),
+                       capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-1500:]
     import json
     other = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -1323,25 +1328,69 @@ def test_render_image_reuses_its_context_between_frames(gpu, pt):
 
 
 def test_hierarchy_kernel_without_its_workspace(gpu, pt):
-    """the parked-walk kernels must render correctly when their ring workspace is missing (allocation
-    failure): every ray that can reach the mesh is then walked from its lane's registers"""
-    import os
-    from rt_amd import scene as S
+    """a hierarchy scene whose ring workspace cannot be allocated (rt_hip_selftest_fail_alloc: the allocation behaves as
+    failed) takes the pick table's park = NO row -- the lane-waiting kernel, every ray that can reach the mesh walked from its
+    lane's registers -- says so, and renders the same bits"""
+    import torch
+    from rt_amd import abi, scene as S
+    shim = abi.load_shim()
     sc = S.build_scene(5, 72, 40, 6)
-    os.environ["RT_HIP_NO_PARK_WS"] = "1"
+    shim.rt_hip_selftest_fail_alloc(abi.FAIL_ALLOC_PARK_WS)
     try:
         gs = gpu.GpuScene(sc)
-        assert gs.kernel_name() == "pt_render_tiles_tri_queued_sph"  # config 5's mesh is round: the probe is its bounding sphere
+        assert gs.kernel_name() == "pt_render_tiles_tri_big"
         img, img8, st = gs.render_image(SEED)
+        assert gs.last_launch_kernel() == "pt_render_tiles_tri_big"
     finally:
-        del os.environ["RT_HIP_NO_PARK_WS"]
+        shim.rt_hip_selftest_fail_alloc(0)
     mean, rgb8, ost = pt.render_pixels(sc, SEED)
     assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="config 5 without ring workspace")
+    assert gs.kernel_name() == "pt_render_tiles_tri_big", "a scene that met no workspace keeps saying so"
     gs.close()
     gs = gpu.GpuScene(sc)  # and with it: the same image, bit for bit
+    assert gs.kernel_name() == "pt_render_tiles_tri_queued_sph"  # config 5's mesh is round: the probe is its bounding sphere
     img2, img82, st2 = gs.render_image(SEED)
-    import torch
+    assert gs.last_launch_kernel() == "pt_render_tiles_tri_queued_sph"
     assert torch.equal(img, img2) and torch.equal(img8, img82) and st == st2
+    gs.close()
+    # the checkered form of the fallback
+    sc.objects[0].flags |= abi.M_CHECKERED
+    shim.rt_hip_selftest_fail_alloc(abi.FAIL_ALLOC_PARK_WS)
+    try:
+        gs = gpu.GpuScene(sc)
+        img, img8, st = gs.render_image(SEED)
+        assert gs.last_launch_kernel() == "pt_render_tiles_tri_big_chk"
+    finally:
+        shim.rt_hip_selftest_fail_alloc(0)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="config 5, checkered wall, without ring workspace")
+    gs.close()
+    sc.free()
+
+
+def test_glass_mesh_when_the_wide_pending_ray_pool_cannot_be_had(gpu, pt):
+    """the parked-walk refraction kernels want 4 x 512 pending-ray stacks per pool slot; where that allocation fails the
+    ordinary pool and the static kernel of the family render the scene (the table's fit = NO row) -- and the failed hipMalloc
+    must not surface as the launch's error (round-4 advisor finding: its sticky error used to)"""
+    from rt_amd import abi, scene as S
+    shim = abi.load_shim()
+    shim.rt_hip_release_cache()          # drops the pending-ray pool: the next launch has to allocate one
+    sc = S.build_scene(5, 72, 40, 6, max_depth=5)
+    sc.meshes[0].flags = abi.M_REFRACTION
+    shim.rt_hip_selftest_fail_alloc(abi.FAIL_ALLOC_WIDE_PEND)
+    try:
+        gs = gpu.GpuScene(sc)
+        assert gs.kernel_name() == "pt_render_tiles_tri_big_refr"
+        img, img8, st = gs.render_image(SEED)
+        assert gs.last_launch_kernel() == "pt_render_tiles_tri_big_refr"
+    finally:
+        shim.rt_hip_selftest_fail_alloc(0)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="glass mesh, narrow pool", hdr=True)
+    img2, img82, st2 = gs.render_image(SEED)   # the pool can be had now: the parked-walk kernel, same counters, same image to rounding
+    assert gs.last_launch_kernel() == "pt_render_tiles_tri_queued_refr_sph"
+    assert st2 == st
+    assert_parity(img2.cpu().numpy(), img82.cpu().numpy(), st2, mean, rgb8, ost, what="glass mesh, wide pool", hdr=True)
     gs.close()
     sc.free()
 
@@ -1366,7 +1415,7 @@ def test_checkered_materials_with_a_round_mesh_take_the_sphere_probe_kernel(gpu,
     sc.free()
 
 
-@pytest.mark.parametrize("case", ["config5", "convex", "nested", "deep"])
+@pytest.mark.parametrize("case", ["config5", "convex", "nested", "deep", "deeper"])
 def test_glass_mesh_through_the_hierarchy_on_the_parked_walk_body(gpu, pt, case):
     """hierarchy scenes with M_REFRACTION (pt_render_tiles_tri_queued_refr[_sph], end of round 4): windowed pixel sums, pending
     second children whose stack id travels with the path through the waiting list AND the ring, the hull-facet rule for both
@@ -1374,8 +1423,9 @@ def test_glass_mesh_through_the_hierarchy_on_the_parked_walk_body(gpu, pt, case)
     config5: the 10,240-triangle sphere turned to glass (+ a glass sphere); convex: a glass polyhedron with a second body
     inside it (children that leave a hull facet of the outer body must still find the inner one where the rule does not
     apply); nested: depth 12 and many samples per pixel (long pools: ids are taken and given back thousands of times); deep:
-    max_depth 29 -- samples x 2^(max_depth + 2) beyond what the windowed sums hold, so the launcher takes the static kernel of the
-    family (which finds the wide pool's slots laid out for it as well)"""
+    max_depth 29 -- the windowed sums hold ONE sample per chunk there (samples_per_chunk x 2^(max_depth + 1) <= 2^30), so the
+    frame is rendered in as many sample chunks as it has samples; deeper: max_depth 30 fits no chunking, the launch takes
+    the static kernel of the family (which finds the wide pool's slots laid out for it as well)"""
     from rt_amd import abi, scene as S
     from util import convex_body_scene, fixed_point_floor
     if case == "config5":
@@ -1393,11 +1443,15 @@ def test_glass_mesh_through_the_hierarchy_on_the_parked_walk_body(gpu, pt, case)
             sc.meshes[m].flags = abi.M_REFRACTION | (abi.M_CHECKERED if m else 0)
     else:
         sc = convex_body_scene(5, 32, 20, 2)[0]
-        sc.max_depth = 29
+        sc.max_depth = 29 if case == "deep" else 30
         sc.meshes[0].flags = abi.M_REFRACTION
     gs = gpu.GpuScene(sc)
     assert gs.kernel_name().startswith("pt_render_tiles_tri_queued_refr"), gs.kernel_name()
     img, img8, st = gs.render_image(SEED)
+    # what the launch itself took (rt_hip_last_launch_kernel): the scene's row, unless the launch's own facts name another
+    assert gs.last_launch_kernel() == ("pt_render_tiles_tri_big_refr" if case == "deeper" else gs.kernel_name())
+    if case == "deep":
+        assert gs.suggest_chunks(gpu.n_tiles(sc.width, sc.height)) == sc.samples == 2
     mean, rgb8, ost = pt.render_pixels(sc, SEED)
     assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"glass mesh, {case}", hdr=True,
                   abs_floor=fixed_point_floor(sc))
@@ -1412,44 +1466,33 @@ def test_glass_mesh_through_the_hierarchy_on_the_parked_walk_body(gpu, pt, case)
 
 
 @pytest.mark.parametrize("seed", [3, 4])
-def test_hierarchy_builders_give_the_same_frame(gpu, pt, seed):
+def test_hierarchy_builders_give_the_same_frame(gpu, pt, seed, tmp_path):
     """the hierarchy only decides WHICH triangles get the exact test: the surface-area builder (round 4; 64 bins, within the
-    least depth leaves of 15 allow) and the median builder of rounds 1-3 (RT_HIP_BVH_MEDIAN=1) must render the same bits --
-    on a lopsided mesh, where they differ most: three clusters of triangles whose sizes range over two decades, one cluster
-    holding most of them (so the depth cap rules out most area splits near the root), plus duplicated and degenerate
-    triangles; and the frame equals the oracle's linear scan"""
+    least depth leaves of 15 allow) and the median builder of rounds 1-3 (the development build's RT_HIP_BVH_MEDIAN=1: a child
+    process on librt_hip_dev.so) must render the same bits -- on a lopsided mesh, where they differ most: three clusters of
+    triangles whose sizes range over two decades, one cluster holding most of them (so the depth cap rules out most area
+    splits near the root), plus duplicated and degenerate triangles; and the frame equals the oracle's linear scan"""
     import os
-    import numpy as np
-    import torch
-    from rt_amd import abi, scene as S
-    rng = np.random.default_rng(seed)
-    tris = []
-    for centre, spread, size, count in (((-6.0, 2.0, 0.0), 1.5, 0.05, 900), ((5.0, 3.0, -2.0), 4.0, 1.5, 60), ((0.0, 6.0, 4.0), 0.4, 0.01, 240)):
-        for _ in range(count):
-            c = np.asarray(centre) + rng.normal(size=3) * spread
-            a, b = rng.normal(size=3) * size, rng.normal(size=3) * size
-            tris.append([tuple(c), tuple(c + a), tuple(c + b)])
-    tris += tris[:40]                                                  # exact duplicates: the (t, index) rule under both orders
-    tris += [[(1.0, 1.0, 1.0), (1.0, 1.0, 1.0), (2.0, 1.0, 1.0)]]      # a degenerate one
-    meshes = [dict(flags=abi.M_DEFAULT, color=(0.8, 0.7, 0.6), triangles=tris)]
-    objs = [dict(flags=abi.M_DEFAULT, radius=4.0, center=(0, 18, 0), color=(1, 1, 1), emission=(8, 8, 8)),
-            dict(flags=abi.M_DEFAULT, radius=1000.0, center=(0, -1004, 0), color=(0.6, 0.6, 0.6)),
-            dict(flags=abi.M_REFLECTION, radius=2.0, center=(2, 0, 6), color=(0.9, 0.9, 0.9))]
-    sc = S.custom_scene(objs, 64, 40, 6, 6, (4, 6, 22), (0, 2, 0), meshes=meshes)
+    import subprocess
+    import sys
+    from util import lopsided_mesh_scene
+    sc = lopsided_mesh_scene(seed)
     assert sc.n_triangles > 256
-    frames = []
-    for median in (False, True):
-        if median:
-            os.environ["RT_HIP_BVH_MEDIAN"] = "1"
-        try:
-            gs = gpu.GpuScene(sc)
-            assert gs.kernel_name().startswith("pt_render_tiles_tri_queued")
-            frames.append(gs.render_image(SEED))
-            gs.close()
-        finally:
-            os.environ.pop("RT_HIP_BVH_MEDIAN", None)
-    (img, img8, st), (img_m, img8_m, st_m) = frames
-    assert torch.equal(img, img_m) and torch.equal(img8, img8_m) and st == st_m
+    gs = gpu.GpuScene(sc)
+    assert gs.kernel_name().startswith("pt_render_tiles_tri_queued")
+    img, img8, st = gs.render_image(SEED)
+    gs.close()
+    out = str(tmp_path / "median.npz")
+    code = ("import sys, numpy as np, torch; sys.path[:0] = [%r, %r]; from rt_amd import gpu as G; from util import lopsided_mesh_scene; "
+            "sc = lopsided_mesh_scene(%d); gs = G.GpuScene(sc); img, img8, st = gs.render_image(%d); "
+            "np.savez(%r, img=img.cpu().numpy(), img8=img8.cpu().numpy(), st=np.array([st['rays'], st['casts'], st['tests'], st['samples']]))"
+            % (os.path.join(ROOT, "raytracer.c_amd"), os.path.join(ROOT, "tests"), seed, SEED, out))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RT_HIP_BVH_MEDIAN="1", RT_HIP_SHIM_PATH=DEV_LIB),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1500:]
+    m = np.load(out)
+    assert np.array_equal(m["img"], img.cpu().numpy()) and np.array_equal(m["img8"], img8.cpu().numpy())
+    assert m["st"].tolist() == [st["rays"], st["casts"], st["tests"], st["samples"]]
     mean, rgb8, ost = pt.render_pixels(sc, SEED)
     assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what="lopsided mesh, surface-area hierarchy")
 
@@ -1726,3 +1769,202 @@ def test_inside_a_mesh_every_ray_is_parked(gpu, pt):
     gs.close()
     st = _full(gpu, pt, sc)
     assert st["casts"] > 3 * 48 * 32 * 48, "paths should bounce around inside the shell"
+
+
+# ---- one small scene per row of the kernel pick table: every shipped kernel under an oracle comparison ---------------------
+# (class of util.class_scene, integrator, allocation faults injected, the kernel the launch must take).  Together with
+# tests/test_pick_table.py (the same rows without a GPU) and tests/test_zz_kernel_coverage.py (what this run launched).
+_PW, _WP = 1, 2   # abi.FAIL_ALLOC_PARK_WS, FAIL_ALLOC_WIDE_PEND
+PICK_ROWS = [
+    (dict(n_packed=4), "path", 0, "pt_render_tiles"),
+    (dict(n_packed=4, chk=True), "path", 0, "pt_render_tiles_chk"),
+    (dict(n_packed=4, refr=True), "path", 0, "pt_render_tiles_refr_pool"),
+    (dict(n_packed=4, refr=True, depth=30), "path", 0, "pt_render_tiles_refr"),
+    (dict(n_packed=4, wide=True), "path", 0, "pt_render_tiles_big"),
+    (dict(n_packed=4, wide=True, chk=True), "path", 0, "pt_render_tiles_big_chk"),
+    (dict(n_packed=4, wide=True, refr=True), "path", 0, "pt_render_tiles_big_refr"),
+    (dict(n_packed=4, tris=40), "path", 0, "pt_render_tiles_tri"),
+    (dict(n_packed=4, tris=40, mesh_chk=True), "path", 0, "pt_render_tiles_tri_chk"),
+    (dict(n_packed=4, tris=40, mesh_refr=True), "path", 0, "pt_render_tiles_tri_refr_pool"),
+    (dict(n_packed=4, tris=40, mesh_refr=True, depth=30), "path", 0, "pt_render_tiles_tri_refr"),
+    (dict(n_packed=4, tris=400), "path", 0, "pt_render_tiles_tri_queued"),
+    (dict(n_packed=4, tris=400, chk=True), "path", 0, "pt_render_tiles_tri_queued_chk"),
+    (dict(n_packed=4, tris=400, round_mesh=True), "path", 0, "pt_render_tiles_tri_queued_sph"),
+    (dict(n_packed=4, tris=400, round_mesh=True, mesh_chk=True), "path", 0, "pt_render_tiles_tri_queued_chk_sph"),
+    (dict(n_packed=4, tris=400, mesh_refr=True), "path", 0, "pt_render_tiles_tri_queued_refr"),
+    (dict(n_packed=4, tris=400, round_mesh=True, mesh_refr=True), "path", 0, "pt_render_tiles_tri_queued_refr_sph"),
+    (dict(n_packed=4, tris=400), "path", _PW, "pt_render_tiles_tri_big"),
+    (dict(n_packed=4, tris=400, wide=True), "path", 0, "pt_render_tiles_tri_big"),
+    (dict(n_packed=4, tris=400, chk=True), "path", _PW, "pt_render_tiles_tri_big_chk"),
+    (dict(n_packed=4, tris=400, mesh_refr=True), "path", _WP, "pt_render_tiles_tri_big_refr"),
+    (dict(n_packed=4, tris=400, mesh_refr=True, depth=30), "path", 0, "pt_render_tiles_tri_big_refr"),
+    (dict(n_packed=120), "path", 0, "pt_render_tiles_pool_mem_s"),
+    (dict(n_packed=120, chk=True), "path", 0, "pt_render_tiles_pool_mem_s_chk"),
+    (dict(n_packed=120, refr=True), "path", 0, "pt_render_tiles_refr_pool_mem"),
+    (dict(n_packed=300), "path", 0, "pt_render_tiles_pool_mem_s"),
+    (dict(n_packed=300, refr=True), "path", 0, "pt_render_tiles_refr_pool_mem"),
+    (dict(n_packed=300, refr=True, depth=30), "path", 0, "pt_render_tiles_mem"),
+    (dict(n_packed=300, wide=True), "path", 0, "pt_render_tiles_pool_mem"),
+    (dict(n_packed=300, wide=True, chk=True), "path", 0, "pt_render_tiles_pool_mem_chk"),
+    (dict(n_packed=300, tris=60), "path", 0, "pt_render_tiles_pool_mem_tri"),
+    (dict(n_packed=300, tris=60, chk=True), "path", 0, "pt_render_tiles_pool_mem_tri_chk"),
+    (dict(n_packed=300, tris=400), "path", 0, "pt_render_tiles_tri_queued_mem"),
+    (dict(n_packed=300, tris=400, mesh_chk=True), "path", 0, "pt_render_tiles_tri_queued_mem_chk"),
+    (dict(n_packed=300, tris=400), "path", _PW, "pt_render_tiles_pool_mem_tri"),
+    (dict(n_packed=300, tris=400, mesh_refr=True), "path", 0, "pt_render_tiles_mem"),
+    (dict(n_packed=4, chk=True, refr=True), "whitted", 0, "pt_whitted_tiles"),
+    (dict(n_packed=4, wide=True), "whitted", 0, "pt_whitted_tiles_big"),
+    (dict(n_packed=4, tris=40), "whitted", 0, "pt_whitted_tiles_tri"),
+    (dict(n_packed=4, tris=400), "whitted", 0, "pt_whitted_tiles_tri_big"),
+    (dict(n_packed=4, glass2=True), "whitted", 0, "pt_whitted_tiles_mem"),
+    (dict(n_packed=300, tris=60), "whitted", 0, "pt_whitted_tiles_mem"),
+]
+
+
+@pytest.mark.parametrize("cls,integrator,faults,kernel", PICK_ROWS,
+                         ids=[f"{k}:{i}:{'+'.join(f'{a}={b}' for a, b in c.items())}{':fault%d' % f if f else ''}" for c, i, f, k in PICK_ROWS])
+def test_every_row_of_the_pick_table_renders_the_oracle_s_frame(gpu, pt, cls, integrator, faults, kernel):
+    from rt_amd import abi
+    from util import class_scene, fixed_point_floor
+    shim = abi.load_shim()
+    sc = class_scene(**cls)
+    if faults & _WP:
+        shim.rt_hip_release_cache()      # no pending-ray pool yet: the launch has to ask for the wide one
+    shim.rt_hip_selftest_fail_alloc(faults)
+    try:
+        gs = gpu.GpuScene(sc)
+        assert gs.kernel_name(integrator) == kernel or cls.get("depth") == 30   # (the launch's own facts: below)
+        img, img8, st = gs.render_image(SEED, integrator=integrator)
+        assert gs.last_launch_kernel() == kernel
+    finally:
+        shim.rt_hip_selftest_fail_alloc(0)
+    mean, rgb8, ost = pt.render_pixels(sc, SEED, integrator=integrator)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"{kernel} {cls}", hdr=True,
+                  abs_floor=fixed_point_floor(sc))
+    gs.close()
+    sc.free()
+
+
+@pytest.mark.parametrize("kind", ["spheres", "streamed", "small_mesh", "glass_mesh"])
+def test_refraction_kernels_take_sample_chunks(gpu, pt, kind):
+    """round 5: the M_REFRACTION forms of the pooled and parked-walk kernels split a tile's samples over workgroups like the
+    others -- each chunk's windowed sums (win_add) are carry-normalised and merged as integers, pt_resolve_tiles normalises the
+    total: the frame is the one-chunk frame BIT FOR BIT for every chunk count and tile partition, and equals the oracle's"""
+    import torch
+    from rt_amd import abi, scene as S
+    from util import class_scene, fixed_point_floor, glass_scene
+    if kind == "spheres":
+        sc, kernel = glass_scene(72, 48, 22, 6), "pt_render_tiles_refr_pool"          # 22 spp: chunks of unequal size
+    elif kind == "streamed":
+        sc, kernel = class_scene(n_packed=120, refr=True, width=56, height=40, samples=10), "pt_render_tiles_refr_pool_mem"
+    elif kind == "small_mesh":
+        sc, kernel = class_scene(n_packed=4, tris=40, mesh_refr=True, samples=9), "pt_render_tiles_tri_refr_pool"
+    else:
+        sc = S.build_scene(5, 96, 54, 12, 6)
+        sc.meshes[0].flags = abi.M_REFRACTION
+        kernel = "pt_render_tiles_tri_queued_refr_sph"
+    gs = gpu.GpuScene(sc)
+    total = gpu.n_tiles(sc.width, sc.height)
+    ref_t, ref_t8, ref_s = gs.render_tiles(SEED, 0, 1, total)
+    torch.cuda.synchronize()
+    assert gs.last_launch_kernel() == kernel
+    for chunks in (2, 3, 7, sc.samples):
+        t, t8, s = gs.render_tiles(SEED, 0, 1, total, chunks=chunks)
+        torch.cuda.synchronize()
+        assert gs.last_launch_kernel() == kernel
+        assert torch.equal(t, ref_t) and torch.equal(t8, ref_t8), (kind, chunks)
+        assert torch.equal(s, ref_s), (kind, chunks, s.tolist(), ref_s.tolist())
+    # a strided partition in three chunks
+    t_odd, t8_odd, _ = gs.render_tiles(SEED, 1, 2, total // 2, chunks=3)
+    torch.cuda.synchronize()
+    assert torch.equal(ref_t[1::2][: total // 2], t_odd[: total // 2]) and torch.equal(ref_t8[1::2][: total // 2], t8_odd[: total // 2])
+    gs.launch_status()
+    img, img8 = gs.untile(ref_t, ref_t8, 0, 1, total)
+    torch.cuda.synchronize()
+    st = dict(zip(("rays", "casts", "tests", "samples"), ref_s.cpu().tolist()))
+    mean, rgb8, ost = pt.render_pixels(sc, SEED)
+    assert_parity(img.cpu().numpy(), img8.cpu().numpy(), st, mean, rgb8, ost, what=f"chunked refraction, {kind}", hdr=True,
+                  abs_floor=fixed_point_floor(sc))
+    gs.close()
+    sc.free()
+
+
+def test_the_refraction_cliff_is_gone(gpu):
+    """until round 5 a launch of a glass mesh left the parked-walk kernel for the static one (3x slower) as soon as
+    samples x 2^(max_depth + 2) passed 2^30 -- 4,097 spp at depth 16.  Now the launch is cut into the sample chunks its windowed
+    sums need: BASELINE configs[4]'s scene with its mesh turned to glass at 3840x2160, 16,384 spp, depth 16 (two chunks
+    needed) stays on pt_render_tiles_tri_queued_refr_sph -- tiles on the mesh, its outline and the floor, bit-equal for 2, 4 and
+    7 chunks; without a workspace the same launch falls back, says so, and renders the same pixels to float rounding"""
+    import torch
+    from rt_amd import abi, scene as S
+    sc = S.build_scene(5, None, None, 16384, 16)
+    sc.meshes[0].flags = abi.M_REFRACTION
+    gs = gpu.GpuScene(sc)
+    view = S.mesh_view_tiles(sc)
+    tiles = [int(view["inside"][len(view["inside"]) // 2]), int(view["silhouette"][7]), int(view["outside"][-3000])]
+    total = gpu.n_tiles(sc.width, sc.height)   # (a whole 4K frame has enough tiles: the suggestion is what the sums need, no more)
+    assert gs.suggest_chunks(total) == 2 and gs.suggest_chunks(total, samples=8192) == 1 and gs.suggest_chunks(total, samples=8193) == 2
+    assert gs.suggest_chunks(total, samples=64, max_depth=29) == 64 and gs.suggest_chunks(total, samples=64, max_depth=30) == 1
+    out = {}
+    for chunks in (2, 4, 7):
+        got = []
+        for t in tiles:
+            tl, tl8, st = gs.render_tiles(SEED, t, 1, 1, chunks=chunks)
+            torch.cuda.synchronize()
+            assert gs.last_launch_kernel() == "pt_render_tiles_tri_queued_refr_sph", (chunks, gs.last_launch_kernel())
+            got.append((tl.clone(), tl8.clone(), st.clone()))
+        out[chunks] = got
+    for chunks in (4, 7):
+        for a, b in zip(out[2], out[chunks]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), chunks
+    # one chunk asked for, a workspace handed over: the shim raises the count to what the sums need
+    ws = torch.empty(gs.shim.rt_hip_scene_chunk_workspace_bytes(gs.handle, 1), dtype=torch.uint8, device="cuda")
+    tl, tl8, st = gs.render_tiles(SEED, tiles[0], 1, 1, chunks=1, workspace=ws)
+    torch.cuda.synchronize()
+    assert gs.last_launch_kernel() == "pt_render_tiles_tri_queued_refr_sph"
+    assert torch.equal(tl, out[2][0][0]) and torch.equal(st, out[2][0][2])
+    # ... and none: the table's fit = NO row
+    tl, tl8, st = gs.render_tiles(SEED, tiles[0], 1, 1)
+    torch.cuda.synchronize()
+    assert gs.last_launch_kernel() == "pt_render_tiles_tri_big_refr"
+    assert torch.equal(st, out[2][0][2])
+    a, b = tl.double().cpu().numpy(), out[2][0][0].double().cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max()
+    gs.launch_status()
+    gs.close()
+    sc.free()
+
+
+def test_golden_config5_wide_at_its_own_resolution(gpu):
+    """tests/golden/c5_wide.npz (make_golden.py c5_wide: the reference's compiled trace_path() with its mesh scan revived):
+    256 tiles = 16,384 pixels of BASELINE configs[4] at its OWN 3840x2160, 2 spp -- 64 tiles that straddle the mesh's
+    outline, 64 inside it, 128 over the rest of the frame, which see the mesh only through a bounce.  Each tile rendered on
+    its own; pixels, bytes, rays and tests of the subset against the fixture.  (bench.py carries the same comparison on
+    1,024 tiles at 4 spp into the driver's line: configs[config 5].parity.wide.)"""
+    import torch
+    from rt_amd import scene as S
+    fr = np.load(GOLD + "/c5_wide.npz", allow_pickle=False)
+    w, h, spp, depth = [int(v) for v in fr["dims"]]
+    sc = S.build_scene(5, samples=spp)
+    assert (sc.width, sc.height, sc.max_depth) == (w, h, depth) == (3840, 2160, 16)
+    view = S.mesh_view_tiles(sc)
+    n_sil, n_in, n_out = [int(v) for v in fr["groups"]]
+    tiles = fr["tiles"]
+    # the fixture's tiles are what the classification gives today (the groups mean what they say)
+    assert set(tiles[:n_sil].tolist()) <= set(view["silhouette"].tolist()) and set(tiles[n_sil:n_sil + n_in].tolist()) <= set(view["inside"].tolist())
+    assert set(tiles[n_sil + n_in:].tolist()) <= set(view["outside"].tolist()) and len(tiles) == 256
+    gs = gpu.GpuScene(sc)
+    t_all = torch.empty((len(tiles), 64, 3), dtype=torch.float32, device="cuda")
+    t8_all = torch.empty((len(tiles), 64, 3), dtype=torch.uint8, device="cuda")
+    stats = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for k, t in enumerate(tiles):
+        gs.render_tiles(SEED, int(t), 1, 1, t_all[k:k + 1], t8_all[k:k + 1], stats)
+    torch.cuda.synchronize()
+    gs.launch_status()
+    assert gs.last_launch_kernel() == "pt_render_tiles_tri_queued_sph"
+    st = stats.cpu().tolist()
+    ost = dict(rays=int(fr["stats"][0]), tests=int(fr["stats"][1]))
+    assert_parity(t_all.cpu().numpy().reshape(-1, 3), t8_all.cpu().numpy().reshape(-1, 3), dict(rays=st[0], tests=st[2]), fr["mean"],
+                  fr["rgb8"], ost, what="config 5 at 3840x2160, 256 tiles x 2 spp")
+    gs.close()
+    sc.free()

@@ -327,7 +327,9 @@ def test_hierarchy_builder_invariants(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     so = str(tmp_path / "libbvh_harness.so")
     # (tools/asan_host.sh sets RT_BVH_HARNESS_FLAGS="-g -fsanitize=address,undefined" and preloads the sanitizer runtimes)
-    subprocess.run(["g++", "-std=c++17", "-O1", "-shared", "-fPIC"] + os.environ.get("RT_BVH_HARNESS_FLAGS", "").split() + ["-I", os.path.join(root, "include"), "-I",
+    # -DPT_DEV_KERNELS: the median-only arm (RT_HIP_BVH_MEDIAN) exists in development builds only; -Bsymbolic: the harness must call ITS
+    # BvhBuild (inline members are weak symbols, and librt_hip.so -- loaded RTLD_GLOBAL by other tests -- exports the product's)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-DPT_DEV_KERNELS", "-Wl,-Bsymbolic"] + os.environ.get("RT_BVH_HARNESS_FLAGS", "").split() + ["-I", os.path.join(root, "include"), "-I",
                     os.path.join(root, "raytracer.c_amd", "csrc"), os.path.join(root, "tests", "bvh_harness.cpp"), "-o", so], check=True)
     lib = C.CDLL(so)
     lib.bvh_check.restype = C.c_int

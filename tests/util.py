@@ -3,6 +3,10 @@ import numpy as np
 
 RMS_TOL = 1e-4  # BASELINE.json north_star: per-channel RMS of the linear float framebuffer
 
+# how many oracle comparisons (assert_parity calls that passed) this process has made: tests/conftest.py attributes the
+# kernel launches of a test to "under an oracle comparison" when this moved during it (tests/test_zz_kernel_coverage.py)
+PARITY_PASSED = [0]
+
 
 def channel_rms(a, b):
     d = np.asarray(a, dtype=np.float64).reshape(-1, 3) - np.asarray(b, dtype=np.float64).reshape(-1, 3)
@@ -54,6 +58,7 @@ def assert_parity(gpu_img, gpu_img8, gpu_stats, mean, rgb8, stats, what="", hdr=
         assert gpu_stats["tests"] == stats["tests"], f"{what}: tests {gpu_stats['tests']} != {stats['tests']}"
         if "casts" in stats:
             assert gpu_stats["casts"] == stats["casts"]
+    PARITY_PASSED[0] += 1
 
 
 def fixed_point_floor(sc):
@@ -365,3 +370,71 @@ def fdlibm_atan2(y, x):
         left = np.where(y_neg, (r - pi_lo) - pi, pi - (r - pi_lo))
         right = np.where(y_neg, -r, r)
         return np.where(x_neg, left, right)
+
+
+def lopsided_mesh_scene(seed):
+    """three clusters of triangles whose sizes range over two decades, one holding most of them, plus exact duplicates and a
+    degenerate triangle, under a light, on a floor, next to a mirror: where the two hierarchy builders differ most"""
+    from rt_amd import abi, scene as S
+    rng = np.random.default_rng(seed)
+    tris = []
+    for centre, spread, size, count in (((-6.0, 2.0, 0.0), 1.5, 0.05, 900), ((5.0, 3.0, -2.0), 4.0, 1.5, 60), ((0.0, 6.0, 4.0), 0.4, 0.01, 240)):
+        for _ in range(count):
+            c = np.asarray(centre) + rng.normal(size=3) * spread
+            a, b = rng.normal(size=3) * size, rng.normal(size=3) * size
+            tris.append([tuple(c), tuple(c + a), tuple(c + b)])
+    tris += tris[:40]                                                  # exact duplicates: the (t, index) rule under both orders
+    tris += [[(1.0, 1.0, 1.0), (1.0, 1.0, 1.0), (2.0, 1.0, 1.0)]]      # a degenerate one
+    meshes = [dict(flags=abi.M_DEFAULT, color=(0.8, 0.7, 0.6), triangles=tris)]
+    objs = [dict(flags=abi.M_DEFAULT, radius=4.0, center=(0, 18, 0), color=(1, 1, 1), emission=(8, 8, 8)),
+            dict(flags=abi.M_DEFAULT, radius=1000.0, center=(0, -1004, 0), color=(0.6, 0.6, 0.6)),
+            dict(flags=abi.M_REFLECTION, radius=2.0, center=(2, 0, 6), color=(0.9, 0.9, 0.9))]
+    return S.custom_scene(objs, 64, 40, 6, 6, (4, 6, 22), (0, 2, 0), meshes=meshes)
+
+
+def class_scene(n_packed=4, tris=0, chk=False, refr=False, glass2=False, wide=False, mesh_refr=False, mesh_chk=False,
+                round_mesh=False, depth=5, width=48, height=32, samples=3, seed=1):
+    """a small scene of a chosen CLASS of the kernel pick table (pt_kernel.hip, pt_pick_table): config 4's room with `n_packed`
+    packed spheres (8 + n_packed spheres: <= 85 staged, 86..256 streamed by preference, beyond that too large to stage),
+    optionally a mesh of `tris` triangles (a bumpy sheet; round_mesh: a tessellated ball instead, whose bounding sphere is the
+    better probe), material flags on chosen objects, and -- wide -- a floor sphere of radius 1e19 through the room (a centre
+    or radius beyond 1e17 is what `wide_range` means)"""
+    from rt_amd import abi, scene as S
+    room = packed_room(n_packed, seed, width, height, samples, depth)
+    objs = [dict(flags=int(room.objects[i].flags), radius=float(room.objects[i].radius), center=room.objects[i].center.tuple(),
+                 color=room.objects[i].color.tuple(), emission=room.objects[i].emission.tuple()) for i in range(room.n_objects)]
+    room.free()
+    if chk:
+        objs[0]["flags"] |= abi.M_CHECKERED          # a wall
+    if refr:
+        objs[8]["flags"] = abi.M_REFRACTION          # the first packed sphere
+        objs[8]["color"] = (0.95, 0.95, 0.95)
+        objs[8]["emission"] = (0.0, 0.0, 0.0)
+    if glass2:
+        objs[9]["flags"] = abi.M_REFLECTION | abi.M_REFRACTION
+        objs[9]["emission"] = (0.0, 0.0, 0.0)
+    if wide:
+        objs.append(dict(flags=abi.M_DEFAULT, radius=1e19, center=(0.0, -1e19 - 12.0, 0.0), color=(0.6, 0.7, 0.5)))
+    meshes = []
+    if tris:
+        rng = np.random.default_rng(500 + seed)
+        tl = []
+        if round_mesh:
+            n_lat = max(2, int(round((tris / 4.0) ** 0.5)))
+            n_lon = max(3, tris // (2 * n_lat))
+            c, r = np.array([2.0, -3.0, 8.0]), 7.0
+
+            def p(i, j):
+                th, ph = np.pi * i / n_lat, 2.0 * np.pi * j / n_lon
+                return tuple(c + r * np.array([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)]))
+            for i in range(n_lat):
+                for j in range(n_lon):
+                    tl.append([p(i, j), p(i + 1, j), p(i + 1, j + 1)])
+                    tl.append([p(i, j), p(i + 1, j + 1), p(i, j + 1)])
+        else:
+            for _ in range(tris):
+                b = np.array([rng.uniform(-22, 22), rng.uniform(-14, 14), rng.uniform(-18, 18)])
+                tl.append([tuple(b) + (0.0, 0.0), tuple(b + rng.normal(size=3) * 2.0) + (1.0, 0.0), tuple(b + rng.normal(size=3) * 2.0) + (0.0, 1.0)])
+        flags = abi.M_REFRACTION if mesh_refr else abi.M_DEFAULT
+        meshes = [dict(flags=flags | (abi.M_CHECKERED if mesh_chk else 0), color=(0.9, 0.85, 0.8), triangles=tl)]
+    return S.custom_scene(objs, width, height, samples, depth, (0, 0, 50), (0, 0, 0), meshes=meshes)
