@@ -11,7 +11,7 @@
  * makes a ray that can reach the mesh WAIT in its lane until enough lanes wait, then walks the
  * hierarchy with the waiting lanes only: the lanes in between idle (loop occupancy 55 % on config
  * 5) and a walk batch holds ~32 rays whose lengths range from 2 to 25 visits (12 % of the lanes
- * busy inside walks; profiles/r02a_c5_pmc.txt: 30 % VALU lane utilisation overall).  Here such a
+ * busy inside walks; profiles/archive/r02a_c5_pmc.txt: 30 % VALU lane utilisation overall).  Here such a
  * ray is PARKED instead: its state (origin, direction, throughput, RNG state, flat-scan result:
  * 96 bytes) goes to a per-wave ring in global memory and its lane takes the next job at once.
  * When PT_PARK_WALK rays are parked the whole wave turns to walking them: every lane takes a ray
@@ -69,10 +69,6 @@ struct ParkRing
   double *f;   /* the wave's PT_PARK_Q x 128 bytes */
   uint32_t *u; /* the same memory as words */
 };
-#ifdef PT_PARK_ONE_RECORD /* round 2's layout, for A/B */
-__device__ __forceinline__ uint32_t ring_fi(uint32_t field, uint32_t e) { return e * 16u + field; }
-__device__ __forceinline__ uint32_t ring_ui(uint32_t field, uint32_t e) { return e * 32u + 2u * PT_PARK_F64_FIELDS + field; }
-#else
 __device__ __forceinline__ uint32_t ring_fi(uint32_t field, uint32_t e)
 { /* fields: 0-2 o, 3-5 d, 6-8 T, 9 rng, 10 min_t, 11-12 last u, v */
   return field < 6u ? e * 8u + field
@@ -83,7 +79,6 @@ __device__ __forceinline__ uint32_t ring_ui(uint32_t field, uint32_t e)
 { /* fields: 0 best, 1 depth << 6 | pixel slot (+ PT_DIAG flags), 2 last index, 3 (REFR kernels) stack id | stack height << 16 */
   return field < 2u ? e * 16u + 14u + field : PT_PARK_Q * 24u + e * 8u + 2u + field;
 }
-#endif
 
 /* ring loads bypass the vector L1 (agent-scope relaxed = `sc1`): a slot's earlier owner on this CU
  * may have left lines of it there */
@@ -129,12 +124,6 @@ struct WalkStack
 {
   uint16_t *lo; /* [levels][PT_BLOCK] */
   uint8_t *hi;  /* [levels][PT_BLOCK] */
-#ifdef PT_BVH_WIDE
-  /* the four-wide walk can hold three entries per level: those beyond the LDS array's `cap` levels (rare) go to an
-   * overflow area behind the wave's ring in the workspace, [entry][lane], read and written by the owning lane only */
-  uint32_t cap;
-  uint32_t *ovf;
-#endif
 };
 #define PT_WALK_LEAF_FLAG24 0x800000u
 __device__ __forceinline__ uint32_t walk_ref24(uint32_t ref) /* PT_BVH_LEAF_FLAG (bit 31) moves to bit 23 */
@@ -144,81 +133,15 @@ __device__ __forceinline__ uint32_t walk_ref24(uint32_t ref) /* PT_BVH_LEAF_FLAG
 __device__ __forceinline__ uint32_t walk_ref32(uint32_t r24) { return (r24 & 0x7FFFFFu) | ((r24 & PT_WALK_LEAF_FLAG24) << 8); }
 __device__ __forceinline__ void walk_push(const WalkStack &st, uint32_t sp, uint32_t ref)
 {
-#ifdef PT_BVH_WIDE
-  if (sp >= st.cap)
-  { /* (L1-bypassing both ways, like every access to the workspace) */
-    __hip_atomic_store(st.ovf + (size_t)min(sp - st.cap, 31u) * 64u + (threadIdx.x & 63u), ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-#endif
   const uint32_t r = walk_ref24(ref);
   st.lo[sp * PT_BLOCK + threadIdx.x] = (uint16_t)r;
   st.hi[sp * PT_BLOCK + threadIdx.x] = (uint8_t)(r >> 16);
 }
 __device__ __forceinline__ uint32_t walk_pop(const WalkStack &st, uint32_t sp)
 {
-#ifdef PT_BVH_WIDE
-  if (sp >= st.cap)
-    return __hip_atomic_load(st.ovf + (size_t)min(sp - st.cap, 31u) * 64u + (threadIdx.x & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
   return walk_ref32((uint32_t)st.lo[sp * PT_BLOCK + threadIdx.x] | ((uint32_t)st.hi[sp * PT_BLOCK + threadIdx.x] << 16));
 }
 
-#ifdef PT_BVH_WIDE
-/* One visit of the four-wide walk: the boxes of node `ref`'s (up to) four children against the ray -- the binary visit's
- * slab test, bounds and NaN rules (bvh_test_children), two children per packed instruction.  Leaves the nearest hit child in
- * `ref` and pushes the others; -> false when no child is hit (the caller pops or finishes). */
-__device__ __forceinline__ bool bvhw_visit(const float *__restrict__ wnodes, uint32_t &ref, const BvhRay &R, bool far_origin, float tmax,
-                                           const WalkStack &stack, uint32_t &sp)
-{
-  const float widen = 6.0f * 5.9604644775390625e-08f;
-  const float4 *node = reinterpret_cast<const float4 *>(wnodes + PT_BVHW_NODE_WORDS * (size_t)ref);
-  const float4 xl = node[0], xh = node[1], yl = node[2], yh = node[3], zl = node[4], zh = node[5], rr = node[6];
-  /* (lo, hi) planes of children (0, 1) and (2, 3) */
-  const f32x2 ax1 = (f32x2{xl.x, xl.y} - R.ox) * R.ix, ax2 = (f32x2{xh.x, xh.y} - R.ox) * R.ix;
-  const f32x2 bx1 = (f32x2{xl.z, xl.w} - R.ox) * R.ix, bx2 = (f32x2{xh.z, xh.w} - R.ox) * R.ix;
-  const f32x2 ay1 = (f32x2{yl.x, yl.y} - R.oy) * R.iy, ay2 = (f32x2{yh.x, yh.y} - R.oy) * R.iy;
-  const f32x2 by1 = (f32x2{yl.z, yl.w} - R.oy) * R.iy, by2 = (f32x2{yh.z, yh.w} - R.oy) * R.iy;
-  const f32x2 az1 = (f32x2{zl.x, zl.y} - R.oz) * R.iz, az2 = (f32x2{zh.x, zh.y} - R.oz) * R.iz;
-  const f32x2 bz1 = (f32x2{zl.z, zl.w} - R.oz) * R.iz, bz2 = (f32x2{zh.z, zh.w} - R.oz) * R.iz;
-  float tn[4], tf[4];
-  tn[0] = hw_max3(hw_min(ax1.x, ax2.x), hw_min(ay1.x, ay2.x), hw_min(az1.x, az2.x));
-  tf[0] = hw_min3(hw_max(ax1.x, ax2.x), hw_max(ay1.x, ay2.x), hw_max(az1.x, az2.x));
-  tn[1] = hw_max3(hw_min(ax1.y, ax2.y), hw_min(ay1.y, ay2.y), hw_min(az1.y, az2.y));
-  tf[1] = hw_min3(hw_max(ax1.y, ax2.y), hw_max(ay1.y, ay2.y), hw_max(az1.y, az2.y));
-  tn[2] = hw_max3(hw_min(bx1.x, bx2.x), hw_min(by1.x, by2.x), hw_min(bz1.x, bz2.x));
-  tf[2] = hw_min3(hw_max(bx1.x, bx2.x), hw_max(by1.x, by2.x), hw_max(bz1.x, bz2.x));
-  tn[3] = hw_max3(hw_min(bx1.y, bx2.y), hw_min(by1.y, by2.y), hw_min(bz1.y, bz2.y));
-  tf[3] = hw_min3(hw_max(bx1.y, bx2.y), hw_max(by1.y, by2.y), hw_max(bz1.y, bz2.y));
-  const uint32_t r[4] = {__float_as_uint(rr.x), __float_as_uint(rr.y), __float_as_uint(rr.z), __float_as_uint(rr.w)};
-  bool hit[4];
-  float near_d = __builtin_inff();
-  int near_c = -1;
-#pragma unroll
-  for (int c = 0; c < 4; c++)
-  {
-    const float n_ = tn[c] - fabsf(tn[c]) * widen, f_ = tf[c] + fabsf(tf[c]) * widen;
-    /* (a missing child has an inverted box; far origins keep every REAL child) */
-    hit[c] = r[c] != PT_BVHW_EMPTY && (far_origin || (f_ >= n_ && f_ >= 0.0f && n_ <= tmax));
-    if (hit[c] && (near_c < 0 || n_ < near_d))
-    {
-      near_d = n_;
-      near_c = c;
-    }
-  }
-  if (near_c < 0)
-    return false;
-#pragma unroll
-  for (int c = 3; c >= 0; c--) /* (the others wait, in reverse child order) */
-    if (hit[c] && c != near_c)
-    {
-      walk_push(stack, sp, r[c]);
-      sp++;
-    }
-  ref = r[near_c];
-  return true;
-}
-#endif
 
 /* The wave walks the n_new parked rays at ring positions first, first + 1, ... (see the header
  * comment): refill, then either one node visit for the lanes that hold an inner node or the exact
@@ -302,18 +225,6 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
 #ifdef PT_DIAG
         visits++;
 #endif
-#ifdef PT_BVH_WIDE
-        if (!bvhw_visit(S.bvh_nodes + pt_bvhw_offset_words(S.n_bvh_nodes), ref, R, far_origin, wtmax, stack, sp))
-        {
-          if (sp == 0)
-            finished = true;
-          else
-          {
-            sp--;
-            ref = walk_pop(stack, sp);
-          }
-        }
-#else
         bool hit0, hit1;
         float tn0, tn1;
         uint32_t r0, r1;
@@ -334,7 +245,6 @@ __device__ __forceinline__ void walk_parked(const SceneCtx &S, const ParkRing &r
           sp--;
           ref = walk_pop(stack, sp);
         }
-#endif
       }
     }
     else if (at_leaf)
@@ -482,10 +392,6 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
                                                                pt_filt_pair_slots(S.n_sph))
                                                             : (size_t)0));
     stack.hi = reinterpret_cast<uint8_t *>(stack.lo + (size_t)levels * PT_BLOCK);
-#ifdef PT_BVH_WIDE
-    stack.cap = levels; /* the LDS array keeps the binary walk's size; deeper entries overflow (WalkStack) */
-    stack.ovf = nullptr; /* set below, once the wave's ring is known */
-#endif
   }
   {
     unsigned long long *z = &pix_sum_all[0][0];
@@ -545,9 +451,6 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
     ring.f = reinterpret_cast<double *>(base);
     ring.u = reinterpret_cast<uint32_t *>(base);
   }
-#ifdef PT_BVH_WIDE
-  stack.ovf = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ring.f) + PT_PARK_Q * 128u + 512u);
-#endif
   /* REFR: the windowed pixel sums of this wave's tile live in the LAST bytes of its workspace region, not in LDS: in LDS the
    * four tiles' 36.9 KB left two workgroups per CU, and at two waves per SIMD this kernel waits (VALU busy 53 %: the walk's
    * dependent fetches, the ring's round trips).  Integer atomics at the XCD's L2 instead -- only lanes whose trip has a

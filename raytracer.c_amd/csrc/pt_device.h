@@ -71,13 +71,6 @@
 #ifndef PT_BVH_COUNT_BITS
 #define PT_BVH_COUNT_BITS 4 /* bits of a leaf reference that hold its triangle count (PT_BVH_LEAF < 2^bits) */
 #endif
-/* -DPT_BVH_WIDE (make variant NAME=wide DEFS="-DPT_BVH_WIDE"; round 4's experiment): the parked walks
- * traverse a FOUR-wide hierarchy -- each binary node's grandchildren as one node of 128 bytes (one L2 line): six float4 of
- * planes (x lo, x hi, y lo, y hi, z lo, z hi of children 0..3), four references -- so that a walk makes half as many
- * dependent node fetches.  Built next to the binary nodes, which the probe and every other kernel keep using. */
-#define PT_BVHW_SRC_DOUBLES 32 /* fp64 source node: 4 x (min xyz, max xyz), 4 refs (2 doubles), pad */
-#define PT_BVHW_NODE_WORDS 32  /* 128-byte device node */
-#define PT_BVHW_EMPTY PT_BVH_LEAF_FLAG /* a leaf reference of zero triangles: no child */
 #define PT_BVH_LEAF_FLAG 0x80000000u
 #define PT_BVH_STACK 24       /* per-lane traversal stack (LDS): tree depth limit */
 #define PT_GEOM_STRIDE 4     /* LDS doubles per sphere: cx cy cz r2 */
@@ -89,11 +82,7 @@
  * (workgroups) per XCD the pool provides: 32 CUs x at most 5 resident workgroups, with slack */
 #define PT_PARK_WIN_BYTES 9216u /* the refraction form's windowed pixel sums of the wave's tile: 64 pixels x 3 channels x 6 words (the LAST bytes of a wave's region) */
 #ifndef PT_PARK_WAVE_BYTES
-#ifdef PT_BVH_WIDE
-#define PT_PARK_WAVE_BYTES (65536u + 512u + 8192u + PT_PARK_WIN_BYTES) /* + 32 overflow entries of the four-wide walk's traversal stacks (64 lanes x 4 bytes each) */
-#else
 #define PT_PARK_WAVE_BYTES (65536u + 512u + PT_PARK_WIN_BYTES) /* 512 entries of 128 bytes (pt_body_queued.h, PT_PARK_Q: why 512), then the tile's 64 per-pixel RNG keys, then the windows */
-#endif
 #endif
 /* slots per XCD of the two pools (this one and the pending-ray pool below): derived per device from the occupancy of the kernels
  * that take slots, with 25 % slack (pt_pool_slots_per_xcd).  The development build (librt_hip_dev.so) takes RT_HIP_POOL_SLOTS=n
@@ -167,18 +156,7 @@ struct PtSceneView
   uint32_t wide_range;               /* a centre or radius beyond 1e17: fp32 sums could overflow */
   uint32_t any_mirror_glass;         /* a material with M_REFLECTION and M_REFRACTION: cast_ray traces two children per hit */
   uint32_t bvh_depth;                /* inner nodes on the longest root-to-leaf path: the traversal stack a lane needs */
-  /* PT_BVH_WIDE builds: the four-wide hierarchy (pt_device.h, top); the device nodes follow the binary ones in bvh_nodes */
-  const double *bvhw_src;
-  uint32_t n_bvhw_nodes, bvhw_depth;
 };
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-static inline size_t pt_bvhw_offset_words(uint32_t n_bvh_nodes)
-{ /* where the wide nodes start in the bvh_nodes buffer: behind the binary nodes, 128-byte aligned */
-  return (((size_t)n_bvh_nodes * PT_BVH_NODE_WORDS + 31u) / 32u) * 32u;
-}
-
 /* Small scenes keep the filter table in LDS and (sphere-only ones) use the sign-test form of
  * the filter, whose NaN-free argument needs every |c|, r <= 1e17; everything else streams the
  * table through scalar loads and keeps the NaN-safe compares. */

@@ -624,25 +624,6 @@ __device__ __forceinline__ void scan_filtered(const double *geom, const double *
       tri_hi = cand_hi & m_hi;
       cand_lo &= ~m_lo; /* what is left in cand_*: sphere candidates */
       cand_hi &= ~m_hi;
-#ifdef PT_MESH_BOUND /* round 4's one experiment on config 3: built, correct, NO GAIN -- not in the shipped kernel */
-      if (FILT_LDS && !far_origin && mesh_bound != nullptr)
-      { /* ---- the bounding sphere of ALL triangles first (the probe's own test and thresholds, bvh_probe /
-         * mesh_bound_for): a triangle's filter entry is the sphere around its centroid through its farthest corner, and for
-         * the right triangles of a box those reach far beyond the box (config 3's cube: 14.5 from its centre against a
-         * bounding sphere of 10.4) -- a ray that misses the mesh's own ball drops every triangle candidate at once instead
-         * of taking them through the pre-test.  Conservative like the probe (the PT_DIAG build re-checks every dropped
-         * triangle with the exact test, as for the filter: 0 violations).  Measured (profiles/r04_c3_mesh_bound_ab.txt):
-         * bounding-sphere candidates per ray 0.83 -> 0.67, but pre-test WAVE iterations per trip only 1.83 -> 1.74 -- the
-         * lanes whose rays go near the cube set the wave's pace, and those pass the ball too --, 18.62 -> 18.66 ms. ---- */
-        const MeshBound &mb = *mesh_bound;
-        const float lx = mb.cx - ox, ly = mb.cy - oy, lz = mb.cz - oz;
-        const float tca = __builtin_fmaf(lz, dz.x, __builtin_fmaf(ly, dy.x, lx * dx.x));
-        const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
-        const float d2 = __builtin_fmaf(-tca, tca, ll);
-        if ((tca < mb.neg_tol) | (d2 > mb.r2_hi)) /* NaNs compare false: kept */
-          tri_lo = tri_hi = 0u;
-      }
-#endif
       if (FILT_LDS && !far_origin)
       {
         /* ---- phase 1b: per-lane fp32 pre-test of the lane's own triangle candidates (tri_may_hit32) ---- */

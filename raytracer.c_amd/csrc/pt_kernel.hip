@@ -456,30 +456,6 @@ extern "C" __global__ __launch_bounds__(256) void pt_build_bvh(const double *bvh
   }
 }
 
-/* PT_BVH_WIDE builds: the four-wide device nodes for one near_R -- the same widening and outward rounding as pt_build_bvh,
- * planes grouped per axis: x lo of children 0..3, x hi, y lo, y hi, z lo, z hi, then the four references. */
-extern "C" __global__ __launch_bounds__(256) void pt_build_bvh_wide(const double *src_nodes, uint32_t n_nodes, double near_R, float *nodes)
-{
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x)
-  {
-    const double *src = src_nodes + PT_BVHW_SRC_DOUBLES * (size_t)i;
-    float *dst = nodes + PT_BVHW_NODE_WORDS * (size_t)i;
-    const double e = 5.9604644775390625e-08;
-    for (int c = 0; c < 4; c++)
-      for (int k = 0; k < 3; k++)
-      {
-        const double lo = src[6 * c + k], hi = src[6 * c + 3 + k];
-        const bool none = lo > hi; /* no child: the box stays inverted */
-        dst[8 * k + c] = none ? 3.0e38f : __double2float_rd(lo - 4.0 * e * (near_R + fabs(lo)));
-        dst[8 * k + 4 + c] = none ? -3.0e38f : __double2float_ru(hi + 4.0 * e * (near_R + fabs(hi)));
-      }
-    const uint32_t *refs = reinterpret_cast<const uint32_t *>(src + 24);
-    for (int c = 0; c < 4; c++)
-      dst[24 + c] = __uint_as_float(refs[c]);
-    dst[28] = dst[29] = dst[30] = dst[31] = 0.f;
-  }
-}
-
 /* HULL FACETS (scene creation, once): triangle F is one if every corner p of every triangle of the scene has
  * m . (p - v0_F) <= tau for m = +n_F (PT_HULL_PLUS: the stored normal points outward) or m = -n_F (PT_HULL_MINUS).
  * What it buys (render_tiles_queued): a ray that starts at a hit point on F -- within delta of F's plane -- with
@@ -964,9 +940,6 @@ hipError_t pt_launch_build_tables(const PtSceneView &scene, double near_R, float
   if (n_nodes)
     hipLaunchKernelGGL(pt_build_bvh, dim3(min(1024u, (n_nodes + 255u) / 256u)), dim3(256), 0, stream, scene.bvh_src,
                        n_nodes, near_R, bvh_nodes);
-  if (scene.n_bvhw_nodes) /* PT_BVH_WIDE builds */
-    hipLaunchKernelGGL(pt_build_bvh_wide, dim3(min(1024u, (scene.n_bvhw_nodes + 255u) / 256u)), dim3(256), 0, stream, scene.bvhw_src,
-                       scene.n_bvhw_nodes, near_R, bvh_nodes + pt_bvhw_offset_words(n_nodes));
   /* the pre-test table behind the pair table: in scan order for small scenes (staged in LDS with the pairs), in the
    * hierarchy's leaf order for large meshes (read from HBM at the leaves) */
   if (scene.n_triangles != 0 && (pt_filter_in_lds(scene) || n_nodes != 0))

@@ -228,57 +228,6 @@ void triangle_entry(const double *p0, const double *p1, const double *p2, double
 
 /* ---- bounding-volume hierarchy over triangles: BvhBuild, in bvh_build.h (host C++, shared with the CPU test of its invariants) ---- */
 
-/* The four-wide hierarchy of PT_BVH_WIDE builds (pt_device.h): every binary node's grandchildren collapsed into one node.
- * A child that is a leaf stays one child; an inner child contributes its two children. */
-struct BvhWide
-{
-  const std::vector<double> *bin; /* the binary source nodes */
-  std::vector<double> nodes;      /* PT_BVHW_SRC_DOUBLES per node */
-  int depth = 0;
-
-  uint32_t build(uint32_t bin_node, int level)
-  {
-    const uint32_t me = (uint32_t)(nodes.size() / PT_BVHW_SRC_DOUBLES);
-    nodes.resize(nodes.size() + PT_BVHW_SRC_DOUBLES, 0.0);
-    depth = std::max(depth, level + 1);
-    double box[4][6];
-    uint32_t ref[4], n = 0;
-    const double *b = &(*bin)[PT_BVH_SRC_DOUBLES * (size_t)bin_node];
-    uint32_t r2[2];
-    memcpy(r2, b + 12, sizeof r2);
-    for (int c = 0; c < 2; c++)
-    {
-      if (r2[c] & PT_BVH_LEAF_FLAG)
-      {
-        if ((r2[c] & ((1u << PT_BVH_COUNT_BITS) - 1u)) == 0u)
-          continue; /* the empty second child of a one-leaf mesh */
-        memcpy(box[n], b + 6 * c, sizeof box[n]);
-        ref[n++] = r2[c];
-      }
-      else
-      {
-        const double *g = &(*bin)[PT_BVH_SRC_DOUBLES * (size_t)r2[c]];
-        uint32_t g2[2];
-        memcpy(g2, g + 12, sizeof g2);
-        for (int k = 0; k < 2; k++)
-        {
-          memcpy(box[n], g + 6 * k, sizeof box[n]);
-          ref[n++] = g2[k];
-        }
-      }
-    }
-    uint32_t out_ref[4] = {PT_BVHW_EMPTY, PT_BVHW_EMPTY, PT_BVHW_EMPTY, PT_BVHW_EMPTY};
-    for (uint32_t k = 0; k < n; k++)
-      out_ref[k] = (ref[k] & PT_BVH_LEAF_FLAG) ? ref[k] : build(ref[k], level + 1);
-    double *w = &nodes[PT_BVHW_SRC_DOUBLES * (size_t)me]; /* after the recursion: nodes may have moved */
-    for (uint32_t k = 0; k < 4; k++)
-      for (int a = 0; a < 6; a++)
-        w[6 * k + a] = k < n ? box[k][a] : (a < 3 ? 1e300 : -1e300); /* no child: an inverted box */
-    memcpy(w + 24, out_ref, sizeof out_ref);
-    return me;
-  }
-};
-
 /* Fault injection for tests (rt_hip_selftest_fail_alloc): which of the shim's optional device allocations behave as if
  * hipMalloc had failed, so that the fallback kernels are reachable -- and testable -- on a 288 GB device. */
 std::atomic<uint32_t> g_fail_alloc{0};
@@ -923,15 +872,6 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
       return fail(RT_HIP_ELIMIT, "triangle hierarchy depth %d exceeds the traversal stack (%d)", bvh.depth, PT_BVH_STACK);
   }
   const size_t n_bvh_nodes = bvh.nodes.size() / PT_BVH_SRC_DOUBLES;
-  BvhWide wide;
-#ifdef PT_BVH_WIDE
-  if (n_bvh_nodes != 0)
-  {
-    wide.bin = &bvh.nodes;
-    (void)wide.build(0u, 0);
-  }
-#endif
-  const size_t n_bvhw_nodes = wide.nodes.size() / PT_BVHW_SRC_DOUBLES;
   std::vector<double> tgeom_leaf(9 * bvh.order.size());
   for (size_t k = 0; k < bvh.order.size(); k++)
     memcpy(&tgeom_leaf[9 * k], &tgeom[9 * (size_t)bvh.order[k]], 9 * sizeof(double));
@@ -951,13 +891,10 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   const size_t filt_bytes = pt_filt_bytes((uint32_t)n_spheres, (uint32_t)n_tri);
   const size_t off_bvh_src = off_filt + pad(filt_bytes);
   const size_t off_bvh_nodes = off_bvh_src + pad(bvh.nodes.size() * 8);
-  /* (PT_BVH_WIDE builds: the four-wide device nodes follow the binary ones in the same buffer, pt_bvhw_offset_words) */
-  const size_t bvh_nodes_bytes = n_bvhw_nodes ? (pt_bvhw_offset_words((uint32_t)n_bvh_nodes) + n_bvhw_nodes * PT_BVHW_NODE_WORDS) * 4
-                                              : n_bvh_nodes * PT_BVH_NODE_WORDS * 4;
+  const size_t bvh_nodes_bytes = n_bvh_nodes * PT_BVH_NODE_WORDS * 4;
   const size_t off_bvh_tri = off_bvh_nodes + pad(bvh_nodes_bytes);
   const size_t off_tgeom_leaf = off_bvh_tri + pad(bvh.order.size() * 4);
-  const size_t off_bvhw_src = off_tgeom_leaf + pad(tgeom_leaf.size() * 8);
-  const size_t total = off_bvhw_src + pad(wide.nodes.size() * 8) + 256;
+  const size_t total = off_tgeom_leaf + pad(tgeom_leaf.size() * 8) + 256;
 
   DeviceScope scope(device);
   HIP_TRY(scope.status);
@@ -986,7 +923,6 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   if (e == hipSuccess) e = up(off_bvh_src, bvh.nodes.data(), bvh.nodes.size() * 8);
   if (e == hipSuccess) e = up(off_bvh_tri, bvh.order.data(), bvh.order.size() * 4);
   if (e == hipSuccess) e = up(off_tgeom_leaf, tgeom_leaf.data(), tgeom_leaf.size() * 8);
-  if (e == hipSuccess) e = up(off_bvhw_src, wide.nodes.data(), wide.nodes.size() * 8);
   if (e != hipSuccess)
   {
     (void)hipFree(sc->blob);
@@ -1007,9 +943,6 @@ int scene_create_impl(const RtHipSphere *spheres, size_t n_spheres, const RtHipM
   sc->mesh_c_norm = std::sqrt(mesh_c[0] * mesh_c[0] + mesh_c[1] * mesh_c[1] + mesh_c[2] * mesh_c[2]) * (1.0 + 1e-12);
   sc->filt_bytes = filt_bytes;
   sc->bvh_nodes_bytes = bvh_nodes_bytes;
-  sc->view.bvhw_src = reinterpret_cast<const double *>(base + off_bvhw_src);
-  sc->view.n_bvhw_nodes = (uint32_t)n_bvhw_nodes;
-  sc->view.bvhw_depth = (uint32_t)wide.depth;
   sc->view.material = reinterpret_cast<const double *>(base + off_mat);
   sc->view.color_raw = reinterpret_cast<const double *>(base + off_craw);
   sc->view.geom4 = reinterpret_cast<const double *>(base + off_geom4);

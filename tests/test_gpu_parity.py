@@ -748,6 +748,14 @@ def test_wide_range_scene_keeps_the_nan_safe_filter(gpu, pt):
     with pytest.raises(gpu.ShimError, match="finite bound"):
         gs.render_image(SEED)
     gs.close()
+    # a NON-FINITE vertex is refused when the scene is created (round-4 advisor finding: fmax(reach, NaN) used to drop it, the
+    # hierarchy builder then sorted NaN centroids); the reference has no meaning for such a triangle either -- every comparison
+    # of its test is false
+    for bad in (float("nan"), float("inf")):
+        nan_tri = [[(-3, -4.9, 3, 0, 0), (bad, -4.9, 3, 1, 0), (0, 2, 3, 0, 1)]]
+        with pytest.raises(gpu.ShimError, match="non-finite coordinate"):
+            gpu.GpuScene(S.custom_scene(objs[1:4], 16, 16, 1, 2, (0, 4, 30), (0, 0, 0),
+                                        meshes=[dict(flags=abi.M_DEFAULT, color=(0.9, 0.8, 0.2), triangles=nan_tri)]))
 
 
 def test_bench_two_ranks_rehearsal(gpu):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """config 3's scene (the cube mesh + 5 spheres) with one sphere and the cube turned M_REFRACTION, 1920x1080 x 64 spp, depth 8:
-the pooled refraction kernel for small mesh scenes (pt_render_tiles_tri_refr_pool) against the static one (RT_HIP_KERNEL_VARIANT=7).
+the pooled refraction kernel for small mesh scenes (pt_render_tiles_tri_refr_pool) against the static one (RT_HIP_KERNEL_VARIANT=7, with RT_HIP_SHIM_PATH=raytracer.c_amd/csrc/librt_hip_dev.so: the switch exists in the development build only).
 `python tools/glass_mesh_probe.py 5 [spp]`: config 5's scene instead (10,240 triangles through the hierarchy, 3840x2160, depth 5 as the
 reference's MAX_DEPTH): first as it is (the parked-walk kernel), then with the mesh turned M_REFRACTION -- the family that still
 runs on the static body with lane-waiting walks (pt_render_tiles_tri_big_refr)"""

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Which member of the kernel family a scene takes (rt_hip_kernel_name), for a set of representative scenes, under the default
-selection and under every development variant (RT_HIP_KERNEL_VARIANT is read once per process: one child each).
+selection and under every development variant (RT_HIP_KERNEL_VARIANT exists in the development build only, librt_hip_dev.so, and is
+read once per process: one child each, all on that library -- its default column is the product's pick table, pinned without a GPU
+by tests/test_pick_table.py).
 usage: python tools/kernel_pick_table.py            (needs a GPU: scenes are created on the device)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,6 +38,7 @@ variants = ["default", "0", "2", "3", "4", "5", "7"]
 for v in variants:
     env = dict(os.environ)
     env.pop("RT_HIP_KERNEL_VARIANT", None)
+    env["RT_HIP_SHIM_PATH"] = os.path.join(ROOT, "raytracer.c_amd", "csrc", "librt_hip_dev.so")
     if v != "default":
         env["RT_HIP_KERNEL_VARIANT"] = v
     p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=300)

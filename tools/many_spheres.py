@@ -5,7 +5,8 @@
   RT_HIP_FORCE_BIG=1        a small scene on the scalar-table `_big` kernel (geometry staged in LDS)
   RT_HIP_KERNEL_VARIANT=4   a scene beyond the budget on the compare-form pooled kernel (pt_render_tiles_pool_mem: no culling, no wall pruning)
   RT_HIP_KERNEL_VARIANT=3   a scene beyond the budget on round 3's static in-memory kernel (pt_render_tiles_mem)
-One child process per (scene, knob): the knobs are read once per process.
+One child process per (scene, knob): the knobs are read once per process -- and exist in the development build only
+(librt_hip_dev.so, `make shim-dev`), which children with a knob load through RT_HIP_SHIM_PATH.
 usage: python tools/many_spheres.py [--spp 64] [--check] 248 249 292 992 3992      (packed spheres; + 8 walls and lights)"""
 import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -83,7 +84,8 @@ if __name__ == "__main__":
         for kn in knobs:
             cmd = [sys.executable, os.path.abspath(__file__), "--child", str(n), "--spp", str(a.spp), "--width", str(a.width),
                    "--height", str(a.height)] + (["--check"] if a.check and not kn else []) + (["--glass"] if a.glass else [])
-            p = subprocess.run(cmd, env=dict(os.environ, **kn), capture_output=True, text=True, timeout=1500)
+            dev = {"RT_HIP_SHIM_PATH": os.path.join(ROOT, "raytracer.c_amd", "csrc", "librt_hip_dev.so")} if kn else {}
+            p = subprocess.run(cmd, env=dict(os.environ, **kn, **dev), capture_output=True, text=True, timeout=1500)
             try:
                 d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
                 d["knob"] = " ".join(f"{k}={v}" for k, v in kn.items())

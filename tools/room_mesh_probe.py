@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rooms of n packed spheres (beyond the LDS staging budget) with config 5's 10,240-triangle mesh in them, 1920x1080 x 16 spp:
 the parked-walk body with the spheres from memory (pt_render_tiles_tri_queued_mem) against the lane-waiting pooled kernel it
-replaces (RT_HIP_KERNEL_VARIANT=4: pt_render_tiles_pool_mem_tri).   usage: python tools/room_mesh_probe.py [n_spheres]"""
+replaces (RT_HIP_KERNEL_VARIANT=4 on raytracer.c_amd/csrc/librt_hip_dev.so through RT_HIP_SHIM_PATH: pt_render_tiles_pool_mem_tri).   usage: python tools/room_mesh_probe.py [n_spheres]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("raytracer.c_amd", "tests"):
