@@ -48,6 +48,19 @@ def test_bench_gpus_2_started_directly_launches_its_own_ranks():
     assert len(d["rank_kernel_ms"]["per_rank"]) == 2
 
 
+def test_bench_four_ranks_rehearsal_assembles_the_one_gpu_frame():
+    """four ranks sharing this box's GPU (gloo): the interleaved partition at a rank count that leaves the ranks unequal
+    tile counts on config 1's 32 x 32 tiles + ragged edge, gathered, scattered, and compared on rank 0 with a one-GPU render of
+    a strided sample -- `assembly_check` at more than two ranks.  (Not eight: a GPU box admits six processes on its card, this
+    test process is one of them; the eight-rank assembly runs on the CPU over gloo in tests/test_dist_cpu.py, and eight
+    LOGICAL devices run through the C host's path in tests/test_gpu_devmap.py.)"""
+    d = _child([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "1", "--width", "250", "--height", "250", "--spp", "4",
+                "--steps", "1", "--warmup", "1", "--cpu-tiles", "0", "--no-configs"], env={"RT_BENCH_REHEARSE": "1"}, timeout=400)
+    assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and "REHEARSAL" in d["config"]["parallelism"]
+    assert d["assembly_check"]["bit_identical_to_one_gpu"] is True and d["assembly_check"]["tiles"] == 1024
+    assert len(d["rank_kernel_ms"]["per_rank"]) == 4
+
+
 def test_bench_gpus_n_without_enough_gpus_says_so():
     """more ranks than GPUs and no rehearsal switch: one JSON line with an error, non-zero exit, nothing launched"""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
