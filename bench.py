@@ -1108,7 +1108,8 @@ def main():
     # whole-call time (PCIe-inclusive; never `value`), then the same frame on 8 LOGICAL devices mapped onto this GPU -- the
     # multi-device path executed and compared bit for bit on the one GPU there is -- and the C command-line host's process
     # wall time by phase.  A failure or time-out is reported, never fatal.
-    if not rehearse and not args.shard and os.environ.get("RT_BENCH_HOST_PATH", "1") != "0":
+    # (N = 1: with the other extras of the default line only -- `--no-configs` runs, i.e. profiling passes and A/Bs, skip them)
+    if not rehearse and not args.shard and os.environ.get("RT_BENCH_HOST_PATH", "1") != "0" and (world > 1 or not args.no_configs):
         if rank == 0:
             out["host_path"] = run_host_path_child(args, world)
             if world == 1:
