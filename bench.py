@@ -421,6 +421,8 @@ def parity_numbers(gpu_rgb, gpu_rgb8, gpu_rays, gpu_casts, sample, hdr=False):
     if hdr:
         out["bar"] += f"; HDR scene: RMS bar scaled by the largest value compared -> {bar:.3g}"
     out["ok"] = bool(finite and (rms <= bar).all() and out["u8_max_diff"] <= 1 and counters_equal)
+    if hdr:   # (what the north star's own absolute bar says, scaled or not)
+        out["passes_unscaled_bar"] = bool(finite and (rms <= RMS_BAR).all())
     return out
 
 

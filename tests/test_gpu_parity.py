@@ -819,6 +819,14 @@ def test_bench_host_path_and_config_array(gpu):
     assert set(got) == {2, 3, 4, 5} or set(got) == {2, 3, 5}
     assert got[3]["kernel"] == "pt_render_tiles_tri" and got[5]["kernel"] == "pt_render_tiles_tri_queued_sph"
     assert all("error" not in c and c["kernel_ms"] > 0 and c["ray_bounces_per_s"] > 0 for c in got.values())
+    # round 5: the C host's whole call rides in the N = 1 line -- on one device, on 8 LOGICAL devices mapped onto this GPU (the
+    # multi-device path, bit-equal), and as the command-line host's process with its phase clock
+    hp, h8, cli = d["host_path"], d["host_path_logical8"], d["cli_host"]
+    assert "error" not in hp and hp["n_devices"] == 1 and hp["kernel"] == "pt_render_tiles" and min(hp["call_ms"]) >= min(hp["kernel_ms"]) > 0
+    assert set(hp["phase_ms"]) >= {"context", "launch_to_idle", "copy_out"} and hp["first_call_ms"] > min(hp["call_ms"])
+    assert "error" not in h8 and h8["n_devices"] == 8 and h8["logical_devices_on_one_gpu"] and h8["equals_one_device_frame"] is True
+    assert "error" not in cli and cli["process_wall_ms"] > 0 and cli["rays"] == d["ray_count_per_step"]
+    assert set(cli["phase_ms"]) == {"HIP_runtime_start", "context", "render", "copy_out", "PNG"}
     # every entry says whether its committed PMC / PT_DIAG figures still describe the kernels (never a stale number)
     for c in got.values():
         if c.get("pmc_stale"):

@@ -14,7 +14,7 @@ RT_HIP_SHIM_PATH=$DIAGSO timeout -k 10 300 python tools/diag.py 3 256 --json pro
 RT_HIP_SHIM_PATH=$DIAGSO timeout -k 10 300 python tools/diag.py 2 64 --json profiles/diag_c2.json > gpurun_out/diag2_$TAG.log 2>&1; echo "diag 2 exit $?"
 RT_HIP_SHIM_PATH=$DIAGSO timeout -k 10 300 python tools/diag.py 1 4 --json profiles/diag_c1.json > gpurun_out/diag1_$TAG.log 2>&1; echo "diag 1 exit $?"
 RT_HIP_SHIM_PATH=$DIAGSO timeout -k 10 300 python tools/diag.py 5 64 > gpurun_out/diag5_64_$TAG.log 2>&1
-mkdir -p gpurun_out/profiles_new; cp profiles/diag_c*.json gpurun_out/profiles_new/ 2>/dev/null
+rm -rf gpurun_out/profiles_new; mkdir -p gpurun_out/profiles_new; cp profiles/diag_c*.json gpurun_out/profiles_new/ 2>/dev/null
 TAG=$TAG CONFIG=4 SPP=0 bash tools/gpu_pmc_cfg.sh 2>&1 | tail -13
 TAG=$TAG CONFIG=5 SPP=$C5SPP bash tools/gpu_pmc_cfg.sh 2>&1 | tail -13
 TAG=$TAG CONFIG=3 SPP=0 bash tools/gpu_pmc_cfg.sh 2>&1 | tail -13
