@@ -65,7 +65,7 @@ struct RtHipScene
   mutable uint64_t table_clock = 0;
   size_t filt_bytes = 0, bvh_nodes_bytes = 0;
   /* workspace of the parked-walk kernels (scenes with a triangle hierarchy): in-use flags, then the rings
-   * (pt_device.h).  ONE per device, shared by every scene on it and counted (park_acquire_ws / park_drop_ws): the 462 MB
+   * (pt_device.h).  ONE per device, shared by every scene on it and counted (park_acquire_ws / park_drop_ws): the 385 MB (round 4: 462; round 3: 406)
    * used to be allocated per scene -- a test suite's every 48 x 32 fuzz scene paid it, and scenes alive at the same
    * time each held a copy (round-3 advisor finding).  Sharing is safe between concurrent launches of different scenes:
    * a workgroup takes a slot with an atomic flag, and the pool has more slots per XCD than workgroups can be resident. */
@@ -427,8 +427,8 @@ void park_drop_ws(int device)
 }
 
 /* the per-device pool of pending-ray stacks of the two-child kernels (pt_scene_ctx.h, PendStack): flags, then
- * PT_PARK_XCDS x PT_PEND_SLOTS_PER_XCD slots of `entries` x 10 fields x PT_PEND_COLUMNS doubles.  Sized by the deepest launch
- * seen so far (max_depth + 2 entries: 294 MB at the reference's MAX_DEPTH 5, 1.4 GB at the limit of 32); grown -- after
+ * PT_PARK_XCDS x slots_per_xcd (pt_pool_slots_per_xcd: 160 on an MI355X) slots of `entries` x 10 fields x PT_PEND_COLUMNS doubles.  Sized by the deepest launch
+ * seen so far (max_depth + 2 entries: 367 MB at the reference's MAX_DEPTH 5, 1.8 GB at the limit of 32); grown -- after
  * the device has drained -- when a launch needs more, never shrunk; rt_hip_release_cache() frees it. */
 struct PendPool
 {
@@ -449,13 +449,14 @@ int pend_pool_for(int device, uint32_t entries, uint32_t columns, PtLaunch &L)
   PendPool &p = g_pend[device];
   if (p.entries < entries || p.columns < columns)
   {
+    const bool asks_wide = columns > PT_PEND_COLUMNS && p.columns < columns; /* this launch is what asks for 4 x 512 stacks per slot */
     entries = std::max(entries, p.entries); /* grown in either direction, never shrunk */
     columns = std::max(columns, p.columns);
     const uint32_t per = p.slots_per_xcd ? p.slots_per_xcd : pt_pool_slots_per_xcd(false);
     const size_t slot_bytes = (size_t)entries * PT_PEND_FIELDS_HOST * columns * sizeof(double);
     const size_t n_slots = (size_t)PT_PARK_XCDS * per;
     /* tests: the request for 4 x 512 stacks per slot behaves as if hipMalloc had failed (BEFORE the old pool is given up) */
-    if (columns > PT_PEND_COLUMNS && (g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_WIDE_PEND))
+    if (asks_wide && (g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_WIDE_PEND))
       return fail(RT_HIP_ENOMEM, "pending-ray pool for max_depth %u (%zu MB): allocation failure injected", entries - 2u,
                   (pend_flag_bytes(per) + n_slots * slot_bytes) >> 20);
     if (p.ws)
@@ -1075,7 +1076,8 @@ const char *rt_hip_kernel_name(const RtHipScene *scene, uint32_t integrator)
   bool no_ws;
   {
     std::lock_guard<std::mutex> lock(scene->table_mutex);
-    no_ws = (scene->park_tried && scene->park_ws == nullptr) || (g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_PARK_WS);
+    /* (a scene that has met its workspace keeps it, whatever is injected later; one that has not yet would not get it now) */
+    no_ws = scene->park_tried ? scene->park_ws == nullptr : (g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_PARK_WS) != 0;
   }
   const PtPickFacts facts = {integrator, 1, 0, !no_ws, !(g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_WIDE_PEND)};
   return pt_kernel_name_of(pt_pick_kernel(scene->view, facts));

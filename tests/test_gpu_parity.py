@@ -1813,7 +1813,8 @@ PICK_ROWS = [
     (dict(n_packed=4, tris=400, wide=True), "path", 0, "pt_render_tiles_tri_big"),
     (dict(n_packed=4, tris=400, chk=True), "path", _PW, "pt_render_tiles_tri_big_chk"),
     (dict(n_packed=4, tris=400, mesh_refr=True), "path", _WP, "pt_render_tiles_tri_big_refr"),
-    (dict(n_packed=4, tris=400, mesh_refr=True, depth=30), "path", 0, "pt_render_tiles_tri_big_refr"),
+    # (the same kernel through sums that do not fit -- max_depth 30 -- is test_glass_mesh_through_the_hierarchy...[deeper]: a small
+    # convex body; on this room's 400-triangle sheet a depth-30 tree takes two minutes)
     (dict(n_packed=120), "path", 0, "pt_render_tiles_pool_mem_s"),
     (dict(n_packed=120, chk=True), "path", 0, "pt_render_tiles_pool_mem_s_chk"),
     (dict(n_packed=120, refr=True), "path", 0, "pt_render_tiles_refr_pool_mem"),
