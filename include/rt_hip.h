@@ -305,6 +305,12 @@ int rt_hip_render_image(const RtHipSphere *spheres, size_t n_spheres, const RtHi
 void rt_hip_release_cache(void);
 uint64_t rt_hip_cache_builds(void);
 
+/* What the shim holds on `device` besides scenes and frames, bytes (0: not allocated): the parked-walk workspace (scenes with a
+ * mesh hierarchy; freed with the last such scene) and the pending-ray pool (two-child materials; grows to the deepest and widest
+ * launch, is rebuilt to fit after 16 launches in a row needed at most a quarter of a pool above 1 GB, freed by
+ * rt_hip_release_cache()).  INTEGRATION.md has the sizes. */
+int rt_hip_pool_bytes(int device, size_t *park_ws_bytes, size_t *pend_pool_bytes);
+
 /* Where the host time of the last rt_hip_render_image() went, seconds: [0] context (scene compare; on a rebuild: upload,
  * buffers, workspaces, communicators), [1] launches + kernels + gather + scatter until every stream is idle, [2] the frame,
  * bytes and counters over PCIe. */

@@ -10,7 +10,7 @@
  * slice + 4, ...; the four slice sums of a pixel are combined by xor-shuffles in a fixed
  * order.  Floating-point sums have no range limit, which is what scenes with M_REFRACTION
  * need (see render_tiles_pooled); VARIANT 0 of it is the plain reference kernel
- * (RT_HIP_KERNEL_VARIANT=0). */
+ * (RT_HIP_KERNEL_VARIANT=0 of the development build, librt_hip_dev.so). */
 /* WHITTED: 0 = trace_path, 1 = cast_ray for scenes where no material has both M_REFLECTION and
  * M_REFRACTION (one child per hit at most: no pending-ray stack), 2 = cast_ray with the stack */
 template <int VARIANT, bool REFRACT, bool CHECKER, bool TRIS, bool FILT_LDS, int WHITTED, bool GEOM_LDS>

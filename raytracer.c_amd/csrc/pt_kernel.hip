@@ -37,7 +37,7 @@
  * pt_whitted_tiles[..] (static body: refraction's two-child tree where the pooled kernel does not apply, and cast_ray,
  * raytracer.c:556-641), see pt_pick_kernel.
  *
- * pt_render_tiles_v0 (kept for A/B and as the plainest statement of the algorithm): static
+ * pt_render_tiles_v0 (development builds only, -DPT_DEV_KERNELS: kept for A/B and as the plainest statement of the algorithm): static
  * assignment lane = (pixel, sample slice), literal scan, fp64 partial sums combined by
  * xor-shuffles in a fixed order.
  *
@@ -101,7 +101,8 @@ PT_KERNEL(pt_render_tiles, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, fal
 PT_KERNEL(pt_render_tiles_big, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES), false, false, false)
 PT_KERNEL(pt_render_tiles_tri, __launch_bounds__(PT_BLOCK, PT_MIN_WAVES_TRI), false, true, true)
 PT_KERNEL(pt_render_tiles_tri_big, __launch_bounds__(PT_BLOCK, 4), false, true, false) /* 24 KB of traversal stacks: 4 workgroups per CU */
-/* the hierarchy kernels with parked walks; the pooled ones above stay selectable (RT_HIP_KERNEL_VARIANT=2) for A/B */
+/* the hierarchy kernels with parked walks; the pooled ones above are the table's park = NO rows (no ring workspace, or a scene beyond
+ * fp32's comfortable range), and RT_HIP_KERNEL_VARIANT=2 of the development build for A/B */
 #ifndef PT_MIN_WAVES_QUEUED
 #define PT_MIN_WAVES_QUEUED 4
 #endif
@@ -821,7 +822,7 @@ PtPickKey pt_classify(const PtSceneView &scene, const PtPickFacts &f)
 }
 
 #ifdef PT_DEV_KERNELS
-/* development builds (-DPT_DEV_KERNELS: `make variant NAME=dev DEFS=-DPT_DEV_KERNELS`, and the PT_DIAG twin): RT_HIP_KERNEL_VARIANT,
+/* development builds (-DPT_DEV_KERNELS: `make shim-dev` -> librt_hip_dev.so): RT_HIP_KERNEL_VARIANT,
  * read once per process, rewrites the key so that a scene takes another arm of the table (A/B), or names the literal kernel:
  *   0 pt_render_tiles_v0 (the plainest statement of the algorithm)   2 hierarchy scenes on the lane-waiting kernels (park = NO)
  *   3 scenes beyond the staging budget on the static in-memory kernel  4 ... on the compare-form pooled kernel

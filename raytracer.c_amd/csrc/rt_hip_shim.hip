@@ -434,7 +434,12 @@ struct PendPool
 {
   char *ws = nullptr;
   uint32_t entries = 0, columns = 0, slots_per_xcd = 0;
+  uint32_t small_streak = 0; /* consecutive launches that needed at most a quarter of it (pend_pool_for: when it shrinks) */
 };
+/* a pool above PEND_SHRINK_ABOVE bytes is given up for one that fits after PEND_SHRINK_AFTER launches in a row needed at most a
+ * quarter of it: one max_depth-29 glass-mesh launch used to pin 6.5 GB until rt_hip_release_cache() (round-4 advisor finding) */
+constexpr size_t PEND_SHRINK_ABOVE = (size_t)1 << 30;
+constexpr uint32_t PEND_SHRINK_AFTER = 16;
 std::mutex g_pend_mutex; /* held from the pool lookup until the launch that uses it is enqueued (so that a growing
                           * launch's hipDeviceSynchronize covers every kernel that holds the old pointer) */
 PendPool g_pend[64];
@@ -447,6 +452,22 @@ int pend_pool_for(int device, uint32_t entries, uint32_t columns, PtLaunch &L)
   if (device < 0 || device >= 64)
     return fail(RT_HIP_ENODEV, "device %d: no pending-ray pool", device);
   PendPool &p = g_pend[device];
+  if (p.ws && p.entries >= entries && p.columns >= columns)
+  { /* large enough.  Far too large, for a while now?  Then the device drains once and the pool is rebuilt to fit. */
+    const size_t have_bytes = (size_t)PT_PARK_XCDS * p.slots_per_xcd * p.entries * PT_PEND_FIELDS_HOST * p.columns * sizeof(double);
+    if (have_bytes > PEND_SHRINK_ABOVE && (uint64_t)entries * columns * 4u <= (uint64_t)p.entries * p.columns)
+    {
+      if (++p.small_streak >= PEND_SHRINK_AFTER)
+      {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(p.ws);
+        p.ws = nullptr;
+        p.entries = p.columns = p.small_streak = 0;
+      }
+    }
+    else
+      p.small_streak = 0;
+  }
   if (p.entries < entries || p.columns < columns)
   {
     const bool asks_wide = columns > PT_PEND_COLUMNS && p.columns < columns; /* this launch is what asks for 4 x 512 stacks per slot */
@@ -487,6 +508,7 @@ int pend_pool_for(int device, uint32_t entries, uint32_t columns, PtLaunch &L)
     p.entries = entries;
     p.columns = columns;
     p.slots_per_xcd = per;
+    p.small_streak = 0;
   }
   L.pend_flags = reinterpret_cast<uint32_t *>(p.ws);
   L.pend_ws = reinterpret_cast<double *>(p.ws + pend_flag_bytes(p.slots_per_xcd));
@@ -1127,6 +1149,25 @@ int rt_hip_selftest_pool_slots(int device, uint32_t *park_slots_per_xcd, uint32_
     *park_slots_per_xcd = pt_pool_slots_per_xcd(true);
   if (pend_slots_per_xcd)
     *pend_slots_per_xcd = pt_pool_slots_per_xcd(false);
+  return RT_HIP_OK;
+}
+
+int rt_hip_pool_bytes(int device, size_t *park_ws_bytes, size_t *pend_pool_bytes)
+{
+  if (device < 0 || device >= 64 || device >= usable_devices())
+    return fail(RT_HIP_ENODEV, "no HIP device %d", device);
+  if (park_ws_bytes)
+  {
+    std::lock_guard<std::mutex> lock(g_park_mutex);
+    const ParkPool &p = g_park[device];
+    *park_ws_bytes = p.ws ? park_flag_bytes(p.slots_per_xcd) + (size_t)PT_PARK_XCDS * p.slots_per_xcd * (PT_BLOCK / 64) * (size_t)PT_PARK_WAVE_BYTES : 0;
+  }
+  if (pend_pool_bytes)
+  {
+    std::lock_guard<std::mutex> lock(g_pend_mutex);
+    const PendPool &p = g_pend[device];
+    *pend_pool_bytes = p.ws ? pend_flag_bytes(p.slots_per_xcd) + (size_t)PT_PARK_XCDS * p.slots_per_xcd * p.entries * PT_PEND_FIELDS_HOST * p.columns * sizeof(double) : 0;
+  }
   return RT_HIP_OK;
 }
 

@@ -115,6 +115,7 @@ SHIM_SYMBOLS = {
     "rt_hip_cache_builds": (C.c_uint64, []),
     "rt_hip_set_device_map": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "rt_hip_last_image_phases": (None, [C.POINTER(C.c_double)]),
+    "rt_hip_pool_bytes": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rt_hip_last_launch_kernel": (C.c_char_p, []),
     "rt_hip_kernel_count": (C.c_int, []),
     "rt_hip_kernel_launches": (C.c_char_p, [C.c_int, C.POINTER(C.c_uint64)]),

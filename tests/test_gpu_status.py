@@ -105,3 +105,44 @@ def test_pool_sizes_are_derived_from_the_device_with_slack():
         assert n % 32 == 0 and per_xcd * 1.25 <= n <= per_xcd * 8 * 1.25 + 32, (n, per_xcd)
     if cus.value == 256:
         assert park.value >= 160 and pend.value >= 160
+
+
+def test_the_pending_ray_pool_grows_to_a_deep_launch_and_shrinks_back():
+    """one deep glass-mesh launch needs ~6.5 GB of pending-ray stacks (31 entries x 2,048 columns x 1,280 slots); the pool used
+    to stay that large until rt_hip_release_cache() (round-4 advisor finding).  Now it is rebuilt to fit once 16 launches in a
+    row needed at most a quarter of it -- and the frames on either side of the rebuild are the same"""
+    import ctypes as C
+    import torch
+    from rt_amd import abi, gpu as G
+    from util import convex_body_scene, glass_scene
+    shim = abi.load_shim()
+    shim.rt_hip_release_cache()
+    park, pend = C.c_size_t(0), C.c_size_t(0)
+
+    def pend_bytes():
+        assert shim.rt_hip_pool_bytes(0, C.byref(park), C.byref(pend)) == 0
+        return pend.value
+    assert pend_bytes() == 0
+    deep = convex_body_scene(5, 32, 20, 2)[0]
+    deep.max_depth = 29
+    deep.meshes[0].flags = abi.M_REFRACTION
+    gs = G.GpuScene(deep)
+    gs.render_image(SEED)
+    assert gs.last_launch_kernel().startswith("pt_render_tiles_tri_queued_refr")
+    big = pend_bytes()
+    assert big > 5 << 30 and park.value > 300 << 20
+    gs.close()
+    small_sc = glass_scene(64, 40, 4, 5)
+    gs = G.GpuScene(small_sc)
+    first = gs.render_image(SEED)
+    for k in range(14):
+        gs.render_image(SEED)
+        assert pend_bytes() == big, k          # 15 small launches so far: still the deep launch's pool
+    again = gs.render_image(SEED)              # the 16th: rebuilt to fit
+    small = pend_bytes()
+    assert small < 1 << 30 and small * 8 < big, (small, big)
+    assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1]) and first[2] == again[2]
+    gs.launch_status()
+    gs.close()
+    shim.rt_hip_release_cache()
+    assert pend_bytes() == 0
