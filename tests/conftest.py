@@ -25,6 +25,8 @@ def pytest_configure(config):
 
 def _ensure_built():
     need = [os.path.join(ROOT, "raytracer.c_amd", "csrc", "librt_hip.so"),
+            os.path.join(ROOT, "raytracer.c_amd", "csrc", "librt_hip_dev.so"),    # children of the GPU tests: development switches
+            os.path.join(ROOT, "raytracer.c_amd", "csrc", "librt_hip_diag.so"),   # ... and the PT_DIAG re-checks
             os.path.join(ROOT, "raytracer.c_amd", "host", "libraytracer_amd.so"),
             os.path.join(ROOT, "oracle", "libpt_oracle.so")]
     if not all(os.path.exists(p) for p in need):
