@@ -42,9 +42,17 @@ The JSON line also carries
   integrators   (N = 1) trace_path's M_REFRACTION branch (a glass scene; config 5's mesh turned to glass, 4K) and cast_ray, 1920x1080, with
                 kernel, registers / scratch, and a parity block each;
   assembly_check (N > 1) the frame gathered from the N ranks against rank 0's own render of 2,048 of its tiles, bit for bit;
-  phase_ms, ranks_seen, rank_kernel_ms, host_path   (N > 1) where a frame's time goes, how many
-                ranks RCCL really connected, and the single-process C path
-                (rt_hip_render_image over N devices) timed in a child process.
+  phase_ms, ranks_seen, rank_kernel_ms   (N > 1) where a frame's time goes, how many ranks RCCL really connected;
+  host_path     the single-process C path -- rt_hip_render_image, what render() of the raytracer.h boundary calls -- timed in a
+                child process: N > 1 over the N devices (grouped RCCL send / recv inside the shim), N = 1 the headline's
+                whole-call time (scene compare, launches, the frame over PCIe; never `value`) with its phase split;
+  host_path_logical8  (N = 1) the same frame on 8 LOGICAL devices mapped onto this GPU (rt_hip_set_device_map): the C host's
+                multi-device code path executed on the one GPU there is, its frame compared bit for bit with the one-device
+                frame (not a scaling measurement);
+  cli_host      (N = 1) the C command-line host as a process: wall time from start to exit for this workload, by phase
+                (HIP runtime start, context, render, copy-out, PNG);
+  configs[config 5].parity.wide   65,536 pixels of the 3840x2160 frame at 4 spp against the compiled reference (tiles on the
+                mesh's outline, inside it, and elsewhere), next to the two tiles at the full 4096 spp.
 """
 import argparse
 import json
