@@ -51,7 +51,7 @@ def _same(a, b):
 
 
 def _scene(which):
-    from rt_amd import scene as S
+    from rt_amd import abi, scene as S
     if which == "config2":      # 800 x 600 = 7,500 tiles: 7500 mod 8 = 4 (ragged over 8 devices), full size, few samples
         return S.build_scene(2, 800, 600, 4)
     if which == "config3":      # triangles + spheres (pt_render_tiles_tri), edge tiles on both axes
@@ -60,16 +60,27 @@ def _scene(which):
         return S.build_scene(4, 2050, 5, 8, max_depth=6)
     if which == "tiles4":       # fewer tiles than devices at G = 8: devices 4..7 hold nothing
         return S.build_scene(1, 16, 16, 4)
+    if which == "glass":        # M_REFRACTION: the logical devices' kernels take slots of ONE pending-ray pool concurrently
+        from util import glass_scene
+        return glass_scene(120, 72, 6, 6)
+    if which == "glass_mesh":   # ... and of one parked-walk workspace; 12 spp at depth 27: three sample chunks per tile (windowed sums)
+        sc = S.build_scene(5, 40, 24, 12, 27)
+        sc.meshes[0].flags = abi.M_REFRACTION
+        return sc
     raise KeyError(which)
 
 
-@pytest.mark.parametrize("which", ["config2", "config3", "tiles257", "tiles4"])
+@pytest.mark.parametrize("which", ["config2", "config3", "tiles257", "tiles4", "glass", "glass_mesh"])
 def test_logical_devices_give_the_one_device_frame_bit_for_bit(gpu, pt, which):
+    from util import fixed_point_floor
     sc = _scene(which)
     _set_map(0)
     one = gpu.render_image_host(sc, SEED, n_devices=1)
     mean, rgb8, ost = pt.render_pixels(sc, SEED)
-    assert_parity(one[0], one[1], one[2], mean, rgb8, ost, what=f"{which} G=1")
+    assert_parity(one[0], one[1], one[2], mean, rgb8, ost, what=f"{which} G=1", hdr=which.startswith("glass"),
+                  abs_floor=fixed_point_floor(sc))
+    if which == "glass_mesh":
+        assert gpu.abi.load_shim().rt_hip_last_launch_kernel() == b"pt_render_tiles_tri_queued_refr_sph"
     _set_map(8)
     for G in (2, 3, 8):
         got = gpu.render_image_host(sc, SEED, n_devices=G)
