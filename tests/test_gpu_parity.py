@@ -1985,3 +1985,24 @@ def test_golden_config5_wide_at_its_own_resolution(gpu):
                   fr["rgb8"], ost, what="config 5 at 3840x2160, 256 tiles x 2 spp")
     gs.close()
     sc.free()
+
+
+def test_chunk_suggestions_know_the_body_a_scene_takes(gpu):
+    """rt_hip_suggest_chunks_depth: the pooled kernels render a tile per workgroup (>= 20 workgroups per resident slot, >= 64
+    samples per chunk); the parked-walk kernels a tile per WAVE, and a chunk of theirs must be longer (>= 30 rounds of
+    workgroups, >= 128 samples per chunk: tools/shard_chunks.py, profiles/r05_shard_chunks.txt -- one rank's share of config 5
+    at N = 8 and 4096 spp: 505 ms with round 4's 2 chunks, 447 with 8, ideal 418).  A whole frame keeps one chunk."""
+    from rt_amd import scene as S
+    c4 = gpu.GpuScene(S.build_scene(4))
+    total4 = gpu.n_tiles(1920, 1080)
+    assert [c4.suggest_chunks((total4 + n - 1) // n) for n in (1, 2, 4, 8)] == [1, 2, 4, 7]
+    c4.close()
+    sc5 = S.build_scene(5)
+    c5 = gpu.GpuScene(sc5)
+    assert c5.kernel_name() == "pt_render_tiles_tri_queued_sph"
+    total5 = gpu.n_tiles(3840, 2160)
+    assert [c5.suggest_chunks((total5 + n - 1) // n) for n in (1, 2, 4, 8)] == [1, 2, 4, 8]                  # its own 4096 spp
+    assert [c5.suggest_chunks((total5 + n - 1) // n, samples=256) for n in (1, 2, 4, 8)] == [1, 2, 2, 2]   # >= 128 samples per chunk
+    assert c5.suggest_chunks(total5 // 8, samples=200) == 1
+    c5.close()
+    sc5.free()
