@@ -1223,12 +1223,14 @@ uint32_t rt_hip_suggest_chunks_depth(const RtHipScene *scene, uint32_t tile_coun
     return (uint32_t)need;
   /* which body the scene takes: the parked-walk kernels render a tile per WAVE (four per workgroup, four workgroups per CU),
    * and a chunk of theirs must be longer -- a wave amortises its walk batches and its final, partly filled walk over its pool */
-  bool queued;
+  bool queued, windowed;
   {
     std::lock_guard<std::mutex> lock(scene->table_mutex);
     const bool have_ws = scene->park_tried ? scene->park_ws != nullptr : (g_fail_alloc.load() & RT_HIP_FAIL_ALLOC_PARK_WS) == 0;
     const PtPickFacts facts = {RT_HIP_TRACE_PATH, (int32_t)(((uint64_t)samples + need - 1) / need), max_depth, have_ws, true};
-    queued = pt_kernel_is_queued(pt_pick_kernel(scene->view, facts));
+    const int which = pt_pick_kernel(scene->view, facts);
+    queued = pt_kernel_is_queued(which);
+    windowed = pt_kernel_is_windowed(which);
   }
   uint64_t want, min_chunk_samples;
   if (queued)
@@ -1239,16 +1241,18 @@ uint32_t rt_hip_suggest_chunks_depth(const RtHipScene *scene, uint32_t tile_coun
      * (ideal 418); 256 spp 1: 39.2, 2: 37.1, 4: 41.8, 8: 42.6 (ideal 27.0).  Round 4's rule (tiles, not workgroups; 64 samples)
      * gave 2 and 4. */
     want = 30ull * 4ull * 4ull * (uint64_t)prop.multiProcessorCount;
-    min_chunk_samples = 128;
   }
   else
   {
     /* aim for >= 20 workgroups per resident slot (5 per CU), so the last, partly filled round
-     * of the launch is a small fraction of it; keep >= 64 samples per chunk.  (One rank's share of the headline frame at
+     * of the launch is a small fraction of it.  (One rank's share of the headline frame at
      * N = 8 / 4 / 2, ms by chunks: 2: 30.0, 4: 29.3, 6: 29.4, 8: 29.6, 16: 30.9 / 1: 59.1, 2: 57.7, 4: 57.5 / 1: 114.7, 2: 113.4.) */
     want = 20ull * 5ull * (uint64_t)prop.multiProcessorCount;
-    min_chunk_samples = 64;
   }
+  /* a chunk keeps >= 128 samples (a workgroup's fixed costs -- staging, keys, culling, the resolve pass -- against its pool: config 3's
+   * share at N = 8, 256 spp, ms by chunks 1: 2.63, 2: 2.61, 4: 2.70, 8: 3.01); the M_REFRACTION forms >= 64 (a refractive sample
+   * is two to three times the rays: the glass mesh's share at N = 8, 256 spp 2: 48.8, 4: 45.9, 8: 46.9) */
+  min_chunk_samples = windowed ? 64 : 128;
   uint64_t chunks = (want + tile_count - 1) / tile_count;
   const uint64_t cap = (uint64_t)samples / min_chunk_samples;
   if (chunks > cap) chunks = cap;

@@ -1988,10 +1988,10 @@ def test_golden_config5_wide_at_its_own_resolution(gpu):
 
 
 def test_chunk_suggestions_know_the_body_a_scene_takes(gpu):
-    """rt_hip_suggest_chunks_depth: the pooled kernels render a tile per workgroup (>= 20 workgroups per resident slot, >= 64
-    samples per chunk); the parked-walk kernels a tile per WAVE, and a chunk of theirs must be longer (>= 30 rounds of
-    workgroups, >= 128 samples per chunk: tools/shard_chunks.py, profiles/r05_shard_chunks.txt -- one rank's share of config 5
-    at N = 8 and 4096 spp: 505 ms with round 4's 2 chunks, 447 with 8, ideal 418).  A whole frame keeps one chunk."""
+    """rt_hip_suggest_chunks_depth: the pooled kernels render a tile per workgroup (>= 20 workgroups per resident slot); the
+    parked-walk kernels a tile per WAVE (>= 30 rounds of workgroups); a chunk keeps >= 128 samples, of an M_REFRACTION form
+    >= 64 (tools/shard_chunks.py, profiles/r05_shard_chunks.txt -- one rank's share of config 5 at N = 8 and 4096 spp: 505 ms
+    with round 4's 2 chunks, 447 with 8, ideal 418).  A whole frame keeps one chunk."""
     from rt_amd import scene as S
     c4 = gpu.GpuScene(S.build_scene(4))
     total4 = gpu.n_tiles(1920, 1080)
@@ -2005,4 +2005,11 @@ def test_chunk_suggestions_know_the_body_a_scene_takes(gpu):
     assert [c5.suggest_chunks((total5 + n - 1) // n, samples=256) for n in (1, 2, 4, 8)] == [1, 2, 2, 2]   # >= 128 samples per chunk
     assert c5.suggest_chunks(total5 // 8, samples=200) == 1
     c5.close()
+    sc5.meshes[0].flags = gpu.abi.M_REFRACTION                      # the glass mesh: >= 64 samples per chunk
+    g5 = gpu.GpuScene(sc5)
+    assert [g5.suggest_chunks((total5 + n - 1) // n, samples=256, max_depth=5) for n in (1, 2, 4, 8)] == [1, 2, 4, 4]
+    g5.close()
     sc5.free()
+    c3 = gpu.GpuScene(S.build_scene(3))                             # config 3's own 256 spp: two chunks at most
+    assert [c3.suggest_chunks((total4 + n - 1) // n) for n in (1, 2, 4, 8)] == [1, 2, 2, 2]
+    c3.close()
