@@ -414,11 +414,16 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   PHASE(10);
 
   const uint32_t wave = threadIdx.x >> 6;
-  /* work units = tile_count x sample_chunks, chunk-major (consecutive units are different tiles); wave w of
+  /* work units = tile_count x sample_chunks, chunk-major (consecutive units are different tiles; REFR: tile-major, below); wave w of
    * workgroup b takes unit 4 b + w; the last workgroup may have waves without a unit (pool = 0) */
   const uint32_t unit = blockIdx.x * (PT_BLOCK / 64) + wave;
   const bool has_unit = unit < L.tile_count * L.sample_chunks;
-  const uint32_t slot = has_unit ? unit % L.tile_count : 0u, chunk = has_unit ? unit / L.tile_count : 0u;
+  /* (the refraction form: TILE-major -- a workgroup's four waves render four chunks of ONE tile: they walk the same part of the
+   * hierarchy, and their windowed sums and pending-ray stacks touch the same lines; one rank's share of the glass mesh at N = 8,
+   * 256 spp, four chunks: 45.9 -> 40.6 ms of an ideal 37.8.  The plain forms lose 3.5 % that way: profiles/r05_shard_order_experiments.txt) */
+  constexpr bool TILE_MAJOR = REFR;
+  const uint32_t slot = !has_unit ? 0u : (TILE_MAJOR ? unit / L.sample_chunks : unit % L.tile_count);
+  const uint32_t chunk = !has_unit ? 0u : (TILE_MAJOR ? unit % L.sample_chunks : unit / L.tile_count);
   const uint32_t tile = L.tile_first + slot * L.tile_stride;
   const uint32_t tx0 = (tile % L.tiles_x) * PT_TILE, ty0 = (tile / L.tiles_x) * PT_TILE;
   const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - tx0);
@@ -953,7 +958,8 @@ __device__ __forceinline__ void render_tiles_queued(const PtLaunch &L)
   {
     /* the tile's numbers once more (see wave_now) */
     const uint32_t unit_e = blockIdx.x * (PT_BLOCK / 64) + wave_now();
-    const uint32_t slot = unit_e % L.tile_count, chunk = unit_e / L.tile_count;
+    const uint32_t slot = TILE_MAJOR ? unit_e / L.sample_chunks : unit_e % L.tile_count;
+    const uint32_t chunk = TILE_MAJOR ? unit_e % L.sample_chunks : unit_e / L.tile_count;
     const uint32_t tile_e = L.tile_first + slot * L.tile_stride;
     const uint32_t vcols = min((uint32_t)PT_TILE, (uint32_t)L.width - (tile_e % L.tiles_x) * PT_TILE);
     const uint32_t vrows = min((uint32_t)PT_TILE, (uint32_t)L.height - (tile_e / L.tiles_x) * PT_TILE);
